@@ -1,0 +1,153 @@
+/*
+ * znippy_hip.h — C ABI of the MI355X-native per-chunk codec + hash path for the Znippy
+ * archive format.  Plain pointers and sizes only; no C++/torch/HIP types in signatures
+ * (a HIP stream is passed as `void*`).  Integer status codes, no exceptions, caller-
+ * allocated outputs.  Thread-safe for concurrent calls on DISTINCT contexts.
+ *
+ * What each entry point replaces in the reference (paths relative to the reference root):
+ *   znippy_compress_bound        zl_compress_bound             znippy-common/src/codec.rs:L32,L45
+ *   znippy_compress              CompressCtx::compress_into    znippy-common/src/codec.rs:L43-55
+ *   znippy_get_decompressed_size zl_get_decompressed_size      znippy-common/src/codec.rs:L69
+ *   znippy_decompress            codec::decompress_into        znippy-common/src/codec.rs:L67-78
+ *   znippy_blake3                blake3::hash                  stream_packer.rs:L219, slot_packer.rs:L553,
+ *                                                              decompress.rs:L172
+ *   znippy_rows_* + znippy_decode_verify_rows
+ *                                body of the read worker loop  znippy-common/src/decompress.rs:L135-190
+ *                                (+ stats merge L195-221)      over index columns (index.rs:L43-54)
+ *   znippy_rounds_* + znippy_encode_hash_rounds
+ *                                barrel + writer bodies        znippy-compress/src/stream_packer.rs:L217-284,
+ *                                                              znippy-compress/src/slot_packer.rs:L551-609
+ *   znippy_hash_rounds           blake3-only / store path      slot_packer.rs:L553-560 (skip branch)
+ *
+ * Codec wire format: one standard Zstandard frame (RFC 8878) per chunk.  (The reference's
+ * OpenZL framing cannot be reproduced or checked offline — see DESIGN.md "Oracle".)
+ */
+#ifndef ZNIPPY_HIP_H
+#define ZNIPPY_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ZNIPPY_OK 0
+#define ZNIPPY_E_INVAL (-1)       /* bad argument */
+#define ZNIPPY_E_HIP (-2)         /* HIP runtime error (znippy_last_error has the text) */
+#define ZNIPPY_E_NOMEM (-3)
+#define ZNIPPY_E_DST_SMALL (-4)   /* caller buffer too small */
+#define ZNIPPY_E_CORRUPT (-5)     /* malformed frame */
+#define ZNIPPY_E_UNSUPPORTED (-6) /* dictionary frames, unknown content size */
+#define ZNIPPY_E_CHECKSUM (-7)    /* frame content checksum (XXH64) mismatch */
+
+typedef struct znippy_ctx znippy_ctx;
+typedef struct znippy_rows znippy_rows;     /* read side: a range of index rows, device-resident */
+typedef struct znippy_rounds znippy_rounds; /* write side: a batch of Rounds, device-resident */
+
+/* One context per worker/GPU (the analogue of one CompressCtx per thread, codec.rs:L8-28).
+ * `hip_stream` may be NULL (the context then owns a non-blocking stream). */
+int znippy_ctx_create(int device, void *hip_stream, znippy_ctx **out);
+void znippy_ctx_destroy(znippy_ctx *ctx);
+const char *znippy_last_error(const znippy_ctx *ctx);
+/* Block until everything queued on the context's stream has finished. */
+int znippy_ctx_sync(znippy_ctx *ctx);
+
+/* ---- (1) bounds ---------------------------------------------------------------------- */
+size_t znippy_compress_bound(size_t n);
+
+/* ---- (5) single-chunk synchronous shims, HOST buffers, codec.rs semantics -------------- */
+int znippy_get_decompressed_size(const void *frame, size_t n, uint64_t *out_size);
+int znippy_decompress(znippy_ctx *ctx, const void *frame, size_t n, void *dst, size_t cap,
+                      size_t *written);
+int znippy_compress(znippy_ctx *ctx, const void *src, size_t n, void *dst, size_t cap,
+                    size_t *written);
+int znippy_blake3(znippy_ctx *ctx, const void *src, size_t n, uint8_t out[32]);
+
+/* ---- (3) batch decode + verify over a row range ---------------------------------------- */
+/* Counters of the read loop (WorkerStats, decompress.rs:L22-28; VerifyReport is derived from
+ * them on the host, decompress.rs:L195-221).  decode_errors = rows whose frame failed to
+ * decode: counted in total_chunks and in no byte counter (decompress.rs:L140,L159-162). */
+typedef struct {
+    uint64_t total_chunks;
+    uint64_t total_written_bytes;
+    uint64_t verified_bytes;
+    uint64_t corrupt_bytes;
+    uint64_t corrupt_rows;
+    uint64_t decode_errors;
+} znippy_verify_counters;
+
+/* Upload rows [row_begin,row_end) of the index columns (HOST pointers, indexed by absolute
+ * row number, exactly the Arrow buffers the reference downcasts at decompress.rs:L115-129):
+ *   blob_offset, blob_size, uncompressed_size : u64 per row
+ *   compressed_bitmap                         : Arrow boolean bitmap, LSB-first (NULL = all compressed)
+ *   checksum                                  : 32 bytes per row (NULL = no verification)
+ *   out_offset                                : u64 per row, byte position of the row's decoded
+ *                                               bytes in the caller's flat output region
+ *                                               (stands for (file, fdata_offset), L186-189)
+ * Also builds the work plan (tiles of <=64 BLAKE3 leaves) that drives the kernels' cursor. */
+int znippy_rows_create(znippy_ctx *ctx, const uint64_t *blob_offset, const uint64_t *blob_size,
+                       const uint8_t *compressed_bitmap, const uint64_t *uncompressed_size,
+                       const uint64_t *out_offset, const uint8_t *checksum, uint64_t row_begin,
+                       uint64_t row_end, znippy_rows **out);
+void znippy_rows_destroy(znippy_rows *rows);
+
+/* Decode-or-passthrough + BLAKE3 + compare for every row of the table.
+ *   d_blobs   : DEVICE pointer to the blob region; row r's blob is d_blobs[blob_offset[r]-blob_base ..]
+ *   d_out     : DEVICE pointer to the flat output region (row r lands at d_out + out_offset[r]);
+ *               out_cap = its size in bytes
+ *   counters  : HOST, filled after the call (the call synchronises the stream)
+ *   corrupt_rows / corrupt_cap : HOST list receiving absolute row numbers whose checksum
+ *               mismatched (ascending); may be NULL
+ *   row_status: HOST, optional (NULL ok): one int32 per row of the table, 0 = decoded, <0 = ZNIPPY_E_*
+ * Asynchronous variant: znippy_decode_verify_rows_async queues the work only; results are read
+ * back with znippy_rows_results after znippy_ctx_sync. */
+int znippy_decode_verify_rows(znippy_ctx *ctx, znippy_rows *rows, const void *d_blobs,
+                              uint64_t blob_base, void *d_out, uint64_t out_cap,
+                              znippy_verify_counters *counters, uint64_t *corrupt_rows,
+                              uint64_t corrupt_cap, int32_t *row_status);
+int znippy_decode_verify_rows_async(znippy_ctx *ctx, znippy_rows *rows, const void *d_blobs,
+                                    uint64_t blob_base, void *d_out, uint64_t out_cap);
+int znippy_rows_results(znippy_ctx *ctx, znippy_rows *rows, znippy_verify_counters *counters,
+                        uint64_t *corrupt_rows, uint64_t corrupt_cap, int32_t *row_status);
+/* Computed digests of the last run (HOST, 32 bytes per row of the table). */
+int znippy_rows_digests(znippy_ctx *ctx, znippy_rows *rows, uint8_t *digests);
+
+/* ---- (2)+(4) batch encode + hash over Rounds -------------------------------------------- */
+/* A Round is (offset,len,skip) into one staging buffer (slotpool.rs:L39-47,
+ * stream_packer.rs:L98-106).  HOST arrays, n entries. */
+int znippy_rounds_create(znippy_ctx *ctx, const uint64_t *src_offset, const uint64_t *len,
+                         const uint8_t *skip, uint64_t n, znippy_rounds **out);
+void znippy_rounds_destroy(znippy_rounds *rounds);
+/* Upper bound of the blob bytes znippy_encode_hash_rounds can produce for this batch. */
+uint64_t znippy_rounds_blob_bound(const znippy_rounds *rounds);
+
+/* For every round: checksum = BLAKE3(src slice) (pre-compression bytes); skip -> the raw bytes
+ * are the payload (compressed=0), else one zstd frame (compressed=1).  Payloads are packed
+ * back-to-back from d_blob_out[0] in round order (blob offsets are a running sum — the
+ * writer's out_cursor.fetch_add, stream_packer.rs:L258).
+ *   d_src      : DEVICE staging buffer the rounds point into
+ *   d_blob_out : DEVICE, blob_cap bytes (>= znippy_rounds_blob_bound)
+ *   HOST outputs, n entries each: blob_offset, blob_size (= on_disk_len), checksum (32 B each),
+ *   compressed (0/1).  *blob_bytes = total payload bytes. */
+int znippy_encode_hash_rounds(znippy_ctx *ctx, znippy_rounds *rounds, const void *d_src,
+                              void *d_blob_out, uint64_t blob_cap, uint64_t *blob_offset,
+                              uint64_t *blob_size, uint8_t *checksum, uint8_t *compressed,
+                              uint64_t *blob_bytes);
+int znippy_encode_hash_rounds_async(znippy_ctx *ctx, znippy_rounds *rounds, const void *d_src,
+                                    void *d_blob_out, uint64_t blob_cap);
+int znippy_rounds_results(znippy_ctx *ctx, znippy_rounds *rounds, uint64_t *blob_offset,
+                          uint64_t *blob_size, uint8_t *checksum, uint8_t *compressed,
+                          uint64_t *blob_bytes);
+
+/* Hash only (store path / verify-only): digests[i] = BLAKE3(d_src[off_i .. off_i+len_i]).
+ * digests: HOST, 32 bytes per round. */
+int znippy_hash_rounds(znippy_ctx *ctx, znippy_rounds *rounds, const void *d_src, uint8_t *digests);
+
+/* ---- measurement hooks (bench.py): device time of the last async call's kernels, by HIP
+ * events on the context's stream.  names/ms: up to cap entries; returns the count. */
+int znippy_last_kernel_times(znippy_ctx *ctx, const char **names, float *ms, int cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ZNIPPY_HIP_H */

@@ -1,0 +1,74 @@
+// Shared host/device declarations for libznippy_hip.so (internal; the public surface is
+// include/znippy_hip.h).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+
+namespace zn {
+
+// A hash work item = one wavefront's worth of BLAKE3 leaves (<= 64 x 1 KiB).
+//   n_units >= 1 : `n_units` whole small units (each <= 64 leaves) packed so their leaves fill
+//                  the wave's lanes; digests are finished inside the wave.
+//   n_units == 0 : leaves [first_leaf, first_leaf+n_leaves) of big unit `first_unit`
+//                  (first_leaf is a multiple of 64 -> a complete subtree); the subtree CV goes
+//                  to tile_cv[cv_index] and the big-unit merge kernel finishes the tree.
+struct Tile {
+    uint32_t first_unit;
+    uint32_t n_units;
+    uint32_t first_leaf;
+    uint32_t n_leaves;
+    uint32_t cv_index;
+    uint32_t pad;
+};
+
+struct BigUnit {  // a unit with more than 64 leaves
+    uint32_t unit;
+    uint32_t cv_base;  // first tile CV of this unit in tile_cv
+    uint32_t n_cvs;    // ceil(leaves/64) >= 2
+    uint32_t pad;
+};
+
+// Where each unit's bytes live.  Units with sel==0 (or all units when sel==nullptr) are hashed
+// from srcA+offA[u]; when copy_to_B is set those bytes are also copied to srcB+offB[u] (store
+// path: blob -> output, fused with the hash).  Units with sel!=0 are hashed from srcB+offB[u]
+// (decoded output of the zstd kernel).
+struct HashArgs {
+    const Tile *tiles;
+    uint32_t n_tiles;
+    const uint64_t *len;
+    const uint8_t *srcA;
+    const uint64_t *offA;
+    uint64_t baseA;  // subtracted from offA (blob_base)
+    uint8_t *srcB;
+    const uint64_t *offB;
+    const uint8_t *sel;
+    const int32_t *status;  // optional: units with status<0 are skipped (decode failed)
+    int copy_to_B;
+    uint32_t *digests;  // 8 words per unit
+    uint32_t *tile_cv;  // 8 words per big-unit tile
+};
+
+struct DecodeArgs {
+    const uint8_t *blobs;
+    uint64_t blob_base;
+    const uint64_t *blob_off, *blob_size, *usize, *out_off;
+    const uint8_t *compressed;  // per row 0/1
+    uint8_t *out;
+    uint64_t out_cap;
+    int32_t *status;
+    uint32_t n_rows;
+    uint32_t *cursor;    // atomic row cursor (the reference's AtomicUsize, decompress.rs:L104)
+    uint8_t *lit_scratch;  // per resident workgroup: LIT_SCRATCH bytes
+    uint32_t *seq_scratch;
+};
+
+void launch_hash_tiles(const HashArgs &a, hipStream_t s);
+void launch_merge_big(const BigUnit *big, uint32_t n_big, uint32_t *tile_cv, uint32_t *digests, hipStream_t s);
+void launch_verify(const uint32_t *digests, const uint8_t *checksum, const uint64_t *usize,
+                   const int32_t *status, uint32_t n_rows, uint64_t row_begin, uint64_t *counters,
+                   uint64_t *corrupt_rows, uint32_t corrupt_cap, hipStream_t s);
+int decode_grid_size(int device);
+void launch_decode(const DecodeArgs &a, int grid, hipStream_t s);
+
+}  // namespace zn

@@ -1,0 +1,822 @@
+// Zstandard frame decoder for CDNA4 (gfx950) — the GPU side of codec::decompress_into
+// (znippy-common/src/codec.rs:L67-78) as called from the read worker loop
+// (znippy-common/src/decompress.rs:L135-166).
+//
+// Work distribution restates the reference's Gatling read model: persistent workgroups share
+// ONE atomic row cursor (decompress.rs:L104,L136); each pulls the next index row, decodes that
+// row's frame from the resident blob region straight to the row's output position.
+//
+// Inside a frame: header/entropy-table parsing and the FSE sequence bitstream are serial
+// (lane 0), Huffman literal streams decode 4 lanes wide (one lane per stream), tables live in
+// LDS, and every byte-moving step (raw/RLE blocks, literal runs, LZ matches incl. overlapping
+// ones via period doubling) is a wave- or workgroup-cooperative coalesced copy.
+// Integer/bitstream work: no MFMA.  Bounded by HBM bandwidth on the copy side.
+#include "common.h"
+
+namespace zn {
+
+constexpr int E_TRUNC = -5, E_CORRUPT = -5, E_UNSUP = -6, E_DST = -4;
+constexpr uint32_t BLOCK_MAX = 128 * 1024;
+constexpr int LIT_SCRATCH_BYTES = 128 * 1024 + 64;
+constexpr int SEQ_BATCH = 256;
+constexpr uint32_t BIG_COPY = 8192;  // copies at least this long are shared by all waves of the workgroup
+
+struct FseEntry {
+    uint16_t next;    // new-state base
+    uint8_t nbits;    // bits to read for the state update
+    uint8_t addbits;  // extra bits of the value
+    uint32_t base;    // value baseline
+};
+
+__constant__ uint32_t c_ll_base[36] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 18,
+                                       20, 22, 24, 28, 32, 40, 48, 64, 128, 256, 512, 1024, 2048,
+                                       4096, 8192, 16384, 32768, 65536};
+__constant__ uint8_t c_ll_bits[36] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 1,
+                                      1, 1, 2, 2, 3, 3, 4, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16};
+__constant__ uint32_t c_ml_base[53] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20,
+                                       21, 22, 23, 24, 25, 26, 27, 28, 29, 30, 31, 32, 33, 34, 35, 37,
+                                       39, 41, 43, 47, 51, 59, 67, 83, 99, 131, 259, 515, 1027, 2051,
+                                       4099, 8195, 16387, 32771, 65539};
+__constant__ uint8_t c_ml_bits[53] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0,
+                                      0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 1,
+                                      1, 1, 2, 2, 3, 3, 4, 4, 5, 7, 8, 9, 10, 11,
+                                      12, 13, 14, 15, 16};
+__constant__ int8_t c_ll_default[36] = {4, 3, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 1, 1, 1, 2, 2,
+                                        2, 2, 2, 2, 2, 2, 2, 3, 2, 1, 1, 1, 1, 1, -1, -1, -1, -1};
+__constant__ int8_t c_ml_default[53] = {1, 4, 3, 2, 2, 2, 2, 2, 2, 1, 1, 1, 1, 1, 1, 1, 1, 1,
+                                        1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1,
+                                        1, 1, 1, 1, 1, 1, 1, 1, 1, 1, -1, -1, -1, -1, -1, -1, -1};
+__constant__ int8_t c_of_default[29] = {1, 1, 1, 1, 1, 1, 2, 2, 2, 1, 1, 1, 1, 1, 1,
+                                        1, 1, 1, 1, 1, 1, 1, 1, 1, -1, -1, -1, -1, -1};
+
+enum { K_LL = 0, K_OF = 1, K_ML = 2 };
+
+struct Shared {
+    FseEntry ll[512], ml[512], of[256];  // tables described in the current/previous block
+    FseEntry dll[64], dml[64], dof[32];  // predefined tables (built once per workgroup)
+    FseEntry rle[3];
+    uint16_t huf[2048];                  // symbol | nbits << 8
+    uint8_t weights[256];
+    uint16_t sym_start[256];
+    uint16_t sym_len[256];
+    int16_t norm[256];
+    uint16_t fse_next[256];
+    uint8_t fse_sym[512];
+    uint32_t seq_ll[SEQ_BATCH], seq_ml[SEQ_BATCH], seq_off[SEQ_BATCH];
+    // per-row / per-block state broadcast from lane 0
+    int32_t err;
+    uint32_t row;
+    uint32_t blk_type, blk_size, blk_last;
+    uint32_t lit_kind;  // 0 raw (pointer into src), 1 rle, 2 scratch
+    uint32_t lit_len, lit_rle;
+    uint64_t lit_src;  // offset in blob (raw) -- relative to frame src
+    uint32_t huf_log, huf_valid;
+    uint32_t n_streams, stream_off[4], stream_len[4], stream_out[4], stream_n[4];
+    uint32_t sel[3], log_[3], valid[3];
+    uint32_t nseq, batch_n;
+    uint64_t src_pos, src_end;  // byte offsets inside the frame's blob
+    uint64_t out_pos, out_end;  // byte offsets inside the row's output
+    uint32_t lit_pos;
+    uint32_t rep[3];
+    uint32_t has_cksum;
+    uint64_t content_size;
+    // sequence bitstream state kept by lane 0 across batches
+    int64_t bs_pos;
+    uint32_t bs_off, st_ll, st_of, st_ml;
+};
+
+__device__ __forceinline__ int hibit(uint32_t v) { return 31 - __clz(v); }
+
+__device__ __forceinline__ uint64_t load8_guard(const uint8_t *p, const uint8_t *end) {
+    if (p + 8 <= end) {
+        uint64_t v;
+        __builtin_memcpy(&v, p, 8);
+        return v;
+    }
+    uint64_t v = 0;
+    for (int i = 0; i < 8 && p + i < end; i++) v |= (uint64_t)p[i] << (8 * i);
+    return v;
+}
+
+// Backward bit reader over [base, base+n): `pos` = unread bits, reads return the bits just
+// below pos, zero-filled below bit 0 (RFC 8878 §4.1).
+struct BitR {
+    const uint8_t *base, *end;
+    int64_t pos;
+    uint64_t win;
+    int64_t wbase;
+    __device__ __forceinline__ void refill() {
+        int64_t b0 = ((pos + 7) >> 3) - 8;
+        if (b0 < 0) b0 = 0;
+        win = load8_guard(base + b0, end);
+        wbase = b0 * 8;
+    }
+    __device__ __forceinline__ bool init(const uint8_t *p, uint32_t n, const uint8_t *blob_end) {
+        if (n == 0) return false;
+        uint8_t last = p[n - 1];
+        if (last == 0) return false;
+        base = p; end = blob_end;
+        pos = (int64_t)n * 8 - (8 - hibit(last));
+        refill();
+        return true;
+    }
+    __device__ __forceinline__ uint32_t peek(uint32_t nb) {  // nb <= 32
+        if (nb == 0) return 0;
+        int64_t s = pos - wbase - (int64_t)nb;
+        if (s < 0 && wbase > 0) { refill(); s = pos - wbase - (int64_t)nb; }
+        uint64_t v = s >= 0 ? (win >> s) : (s > -64 ? (win << (-s)) : 0ull);
+        if (pos < (int64_t)nb) {
+            // bits below 0 read as zero: keep only the top `pos` real bits
+            if (pos <= 0) return 0;
+            uint64_t real = win & ((pos >= 64) ? ~0ull : ((1ull << pos) - 1));  // wbase == 0 here
+            v = real << ((int64_t)nb - pos);
+        }
+        return (uint32_t)(v & ((nb >= 32) ? 0xFFFFFFFFull : ((1ull << nb) - 1)));
+    }
+    __device__ __forceinline__ uint32_t read(uint32_t nb) {
+        uint32_t v = peek(nb);
+        pos -= nb;
+        return v;
+    }
+};
+
+// Forward bit reader (FSE table descriptions).
+struct FwdR {
+    const uint8_t *p;
+    uint32_t n;
+    uint32_t bitpos;
+    __device__ __forceinline__ uint32_t read(uint32_t nb) {
+        uint32_t v = 0;
+        for (uint32_t i = 0; i < nb; i++) {
+            uint32_t bp = bitpos + i;
+            uint32_t bit = (bp >> 3) < n ? (p[bp >> 3] >> (bp & 7)) & 1u : 0u;
+            v |= bit << i;
+        }
+        bitpos += nb;
+        return v;
+    }
+};
+
+// ---------------------------------------------------------------------------------------------
+// cooperative copies.  `nthreads` lanes (tid in [0,nthreads)) move n bytes src -> dst; ranges
+// do not overlap.  Long copies go 16 B per lane with the DESTINATION aligned (coalesced 1 KiB
+// per wave-instruction); unaligned sources use the hardware's unaligned dwordx4 loads.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void coop_copy(uint8_t *dst, const uint8_t *src, uint64_t n, uint32_t tid,
+                                          uint32_t nthreads) {
+    if (n < 256) {
+        for (uint64_t i = tid; i < n; i += nthreads) dst[i] = src[i];
+        return;
+    }
+    uint32_t head = (uint32_t)((16 - ((uintptr_t)dst & 15)) & 15);
+    if (tid < head) dst[tid] = src[tid];
+    uint64_t body = (n - head) >> 4;
+    uint8_t *d = dst + head;
+    const uint8_t *s = src + head;
+    for (uint64_t i = tid; i < body; i += nthreads) {
+        uint4 v;
+        __builtin_memcpy(&v, s + i * 16, 16);
+        *reinterpret_cast<uint4 *>(d + i * 16) = v;
+    }
+    uint64_t done = head + body * 16;
+    if (done + tid < n) dst[done + tid] = src[done + tid];  // tail < 16 bytes
+}
+
+__device__ __forceinline__ void coop_fill(uint8_t *dst, uint8_t byte, uint64_t n, uint32_t tid, uint32_t nthreads) {
+    if (n < 256) {
+        for (uint64_t i = tid; i < n; i += nthreads) dst[i] = byte;
+        return;
+    }
+    uint32_t head = (uint32_t)((16 - ((uintptr_t)dst & 15)) & 15);
+    if (tid < head) dst[tid] = byte;
+    uint64_t body = (n - head) >> 4;
+    uint32_t w = byte * 0x01010101u;
+    uint4 v = make_uint4(w, w, w, w);
+    uint8_t *d = dst + head;
+    for (uint64_t i = tid; i < body; i += nthreads) *reinterpret_cast<uint4 *>(d + i * 16) = v;
+    uint64_t done = head + body * 16;
+    if (done + tid < n) dst[done + tid] = byte;
+}
+
+// stores of this wave complete (and visible to its later loads) before continuing
+__device__ __forceinline__ void wave_mem_sync() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+// LZ match: dst[i] = dst[i - off] for i in [0, n), executed by `nthreads` lanes.  An overlapping
+// match (off < n) is a periodic extension; it is laid down by period doubling so that every step
+// is a non-overlapping cooperative copy whose source is already final.
+template <int NWAVES>
+__device__ __forceinline__ void coop_match(uint8_t *dst, uint32_t off, uint64_t n, uint32_t tid, bool all_waves) {
+    const uint32_t nthreads = all_waves ? NWAVES * 64 : 64;
+    if (off >= n) {
+        coop_copy(dst, dst - off, n, tid, nthreads);
+        return;
+    }
+    uint64_t w = 0;
+    if (off < 64) {
+        // seed: the first bytes of the run straight from the period
+        uint64_t c = n < 64 ? n : 64;
+        if (tid < c) dst[tid] = dst[(int64_t)(tid % off) - (int64_t)off];
+        w = c;
+        if (all_waves && NWAVES > 1) __syncthreads(); else wave_mem_sync();
+    }
+    while (w < n) {
+        uint64_t avail = w + off;
+        uint64_t pm = (avail / off) * off;  // largest multiple of the period already laid down
+        uint64_t c = n - w < pm ? n - w : pm;
+        coop_copy(dst + w, dst + w - pm, c, tid, nthreads);
+        w += c;
+        if (w < n) {
+            if (all_waves && NWAVES > 1) __syncthreads(); else wave_mem_sync();
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// lane-0 serial helpers
+// ---------------------------------------------------------------------------------------------
+__device__ int fse_read_ncount(Shared &S, const uint8_t *src, uint32_t n, int max_log, int max_sym, int *nsym,
+                               int *log, uint32_t *consumed) {
+    FwdR b{src, n, 0};
+    if (n == 0) return E_TRUNC;
+    int alog = 5 + (int)b.read(4);
+    if (alog > max_log) return E_CORRUPT;
+    int remaining = 1 << alog, s = 0;
+    while (remaining > 0 && s <= max_sym) {
+        int bits = hibit((uint32_t)remaining + 1) + 1;
+        uint32_t val = b.read(bits);
+        uint32_t lower_mask = (1u << (bits - 1)) - 1;
+        uint32_t threshold = (1u << bits) - 1 - ((uint32_t)remaining + 1);
+        if ((val & lower_mask) < threshold) {
+            b.bitpos -= 1;
+            val &= lower_mask;
+        } else if (val > lower_mask) {
+            val -= threshold;
+        }
+        int proba = (int)val - 1;
+        remaining -= proba < 0 ? -proba : proba;
+        S.norm[s++] = (int16_t)proba;
+        if (proba == 0) {
+            uint32_t rep = b.read(2);
+            for (;;) {
+                for (uint32_t i = 0; i < rep && s <= max_sym; i++) S.norm[s++] = 0;
+                if (rep == 3) rep = b.read(2); else break;
+            }
+        }
+    }
+    if (remaining != 0) return E_CORRUPT;
+    if ((b.bitpos + 7) / 8 > n) return E_TRUNC;
+    *nsym = s;
+    *log = alog;
+    *consumed = (b.bitpos + 7) / 8;
+    return 0;
+}
+
+// Build a decoding table from S.norm[0..nsym).  kind selects how (symbol -> base, addbits) maps:
+// LL / ML use the RFC's code tables, OF codes carry `code` extra bits on base 1<<code,
+// kind < 0 = plain symbols (Huffman weights).
+__device__ int fse_build(Shared &S, FseEntry *t, int nsym, int log, int kind) {
+    const int size = 1 << log;
+    int high = size;
+    for (int s = 0; s < nsym; s++)
+        if (S.norm[s] == -1) { S.fse_sym[--high] = (uint8_t)s; S.fse_next[s] = 1; }
+    const int step = (size >> 1) + (size >> 3) + 3, mask = size - 1;
+    int pos = 0;
+    for (int s = 0; s < nsym; s++) {
+        int c = S.norm[s];
+        if (c <= 0) continue;
+        S.fse_next[s] = (uint16_t)c;
+        for (int i = 0; i < c; i++) {
+            S.fse_sym[pos] = (uint8_t)s;
+            do { pos = (pos + step) & mask; } while (pos >= high);
+        }
+    }
+    if (pos != 0) return E_CORRUPT;
+    for (int i = 0; i < size; i++) {
+        uint32_t sym = S.fse_sym[i];
+        uint32_t ns = S.fse_next[sym]++;
+        int nb = log - hibit(ns);
+        FseEntry e;
+        e.next = (uint16_t)((ns << nb) - size);
+        e.nbits = (uint8_t)nb;
+        if (kind == K_LL) { if (sym > 35) return E_CORRUPT; e.base = c_ll_base[sym]; e.addbits = c_ll_bits[sym]; }
+        else if (kind == K_ML) { if (sym > 52) return E_CORRUPT; e.base = c_ml_base[sym]; e.addbits = c_ml_bits[sym]; }
+        else if (kind == K_OF) { if (sym > 31) return E_CORRUPT; e.base = 1u << sym; e.addbits = (uint8_t)sym; }
+        else { e.base = sym; e.addbits = 0; }
+        t[i] = e;
+    }
+    return 0;
+}
+
+__device__ int fse_set_rle(FseEntry *e, uint32_t sym, int kind) {
+    e->next = 0; e->nbits = 0;
+    if (kind == K_LL) { if (sym > 35) return E_CORRUPT; e->base = c_ll_base[sym]; e->addbits = c_ll_bits[sym]; }
+    else if (kind == K_ML) { if (sym > 52) return E_CORRUPT; e->base = c_ml_base[sym]; e->addbits = c_ml_bits[sym]; }
+    else { if (sym > 31) return E_CORRUPT; e->base = 1u << sym; e->addbits = (uint8_t)sym; }
+    return 0;
+}
+
+// Huffman tree description -> S.weights / S.sym_start / S.sym_len / S.huf_log (lane 0).
+__device__ int huf_read_tree(Shared &S, const uint8_t *src, uint32_t n, const uint8_t *blob_end, uint32_t *consumed) {
+    if (n < 1) return E_TRUNC;
+    uint32_t hb = src[0];
+    int nw = 0;
+    if (hb >= 128) {
+        int num = (int)hb - 127;
+        uint32_t bytes = (uint32_t)(num + 1) / 2;
+        if (1 + bytes > n) return E_TRUNC;
+        for (int i = 0; i < num; i++) {
+            uint8_t b = src[1 + i / 2];
+            S.weights[i] = (i & 1) ? (b & 15) : (b >> 4);
+        }
+        nw = num;
+        *consumed = 1 + bytes;
+    } else {
+        if (hb == 0 || 1 + hb > n) return E_TRUNC;
+        int nsym, log;
+        uint32_t hdr;
+        int rc = fse_read_ncount(S, src + 1, hb, 6, 255, &nsym, &log, &hdr);
+        if (rc) return rc;
+        // weights table reuses the `of` slot region? no: keep sequence tables intact (repeat mode) -> use ll? also live.
+        // A 64-entry table fits in the dml slot only if ML is not in default mode later, so build into a
+        // private region: the seq_ll batch buffer is free while literals are being decoded.
+        FseEntry *t = reinterpret_cast<FseEntry *>(S.seq_ll);
+        rc = fse_build(S, t, nsym, log, -1);
+        if (rc) return rc;
+        if (hdr >= hb) return E_CORRUPT;
+        BitR b;
+        if (!b.init(src + 1 + hdr, hb - hdr, blob_end)) return E_CORRUPT;
+        uint32_t s1 = b.read(log), s2 = b.read(log);
+        for (;;) {
+            if (nw >= 255) return E_CORRUPT;
+            S.weights[nw++] = (uint8_t)t[s1].base;
+            s1 = t[s1].next + b.read(t[s1].nbits);
+            if (b.pos < 0) {
+                if (nw >= 255) return E_CORRUPT;
+                S.weights[nw++] = (uint8_t)t[s2].base;
+                break;
+            }
+            if (nw >= 255) return E_CORRUPT;
+            S.weights[nw++] = (uint8_t)t[s2].base;
+            s2 = t[s2].next + b.read(t[s2].nbits);
+            if (b.pos < 0) {
+                if (nw >= 255) return E_CORRUPT;
+                S.weights[nw++] = (uint8_t)t[s1].base;
+                break;
+            }
+        }
+        *consumed = 1 + hb;
+    }
+    // implied last weight, code lengths, canonical start index per symbol
+    uint32_t total = 0;
+    for (int i = 0; i < nw; i++) {
+        uint32_t w = S.weights[i];
+        if (w > 12) return E_CORRUPT;
+        total += w ? 1u << (w - 1) : 0;
+    }
+    if (total == 0) return E_CORRUPT;
+    int maxbits = hibit(total) + 1;
+    if (maxbits > 11) return E_CORRUPT;
+    uint32_t left = (1u << maxbits) - total;
+    if (left & (left - 1)) return E_CORRUPT;
+    S.weights[nw] = (uint8_t)(hibit(left) + 1);
+    int nsym = nw + 1;
+    uint32_t rank_count[13], rank_idx[13];
+    for (int i = 0; i < 13; i++) rank_count[i] = 0;
+    for (int i = 0; i < nsym; i++) {
+        uint32_t w = S.weights[i];
+        rank_count[w ? maxbits + 1 - w : 0]++;
+    }
+    rank_idx[maxbits] = 0;
+    for (int i = maxbits; i >= 1; i--) rank_idx[i - 1] = rank_idx[i] + rank_count[i] * (1u << (maxbits - i));
+    if (rank_idx[0] != (1u << maxbits)) return E_CORRUPT;
+    for (int i = 0; i < 256; i++) S.sym_len[i] = 0;
+    for (int i = 0; i < nsym; i++) {
+        uint32_t w = S.weights[i];
+        if (!w) continue;
+        uint32_t bits = maxbits + 1 - w, len = 1u << (maxbits - bits);
+        S.sym_start[i] = (uint16_t)rank_idx[bits];
+        S.sym_len[i] = (uint16_t)len;
+        rank_idx[bits] += len;
+    }
+    S.huf_log = maxbits;
+    return 0;
+}
+
+// One lane decodes one Huffman stream (n_out symbols) from [p, p+n) into dst.
+__device__ int huf_decode_stream(const Shared &S, const uint8_t *p, uint32_t n, const uint8_t *blob_end,
+                                 uint8_t *dst, uint32_t n_out) {
+    BitR b;
+    if (!b.init(p, n, blob_end)) return E_CORRUPT;
+    const uint32_t log = S.huf_log;
+    for (uint32_t i = 0; i < n_out; i++) {
+        uint32_t e = S.huf[b.peek(log)];
+        dst[i] = (uint8_t)e;
+        b.pos -= e >> 8;
+    }
+    return b.pos == 0 ? 0 : E_CORRUPT;
+}
+
+// ---------------------------------------------------------------------------------------------
+// the kernel
+// ---------------------------------------------------------------------------------------------
+template <int NWAVES>
+__global__ __launch_bounds__(NWAVES * 64) void k_zstd_decode(DecodeArgs a) {
+    __shared__ Shared S;
+    const uint32_t tid = threadIdx.x, NT = NWAVES * 64;
+    const bool wave0 = tid < 64;
+    uint8_t *const lit_buf = a.lit_scratch + (size_t)blockIdx.x * LIT_SCRATCH_BYTES;
+
+    // predefined tables, once per workgroup (lane 0; tiny)
+    if (tid == 0) {
+        for (int i = 0; i < 36; i++) S.norm[i] = c_ll_default[i];
+        fse_build(S, S.dll, 36, 6, K_LL);
+        for (int i = 0; i < 53; i++) S.norm[i] = c_ml_default[i];
+        fse_build(S, S.dml, 53, 6, K_ML);
+        for (int i = 0; i < 29; i++) S.norm[i] = c_of_default[i];
+        fse_build(S, S.dof, 29, 5, K_OF);
+    }
+    __syncthreads();
+
+    for (;;) {
+        if (tid == 0) S.row = atomicAdd(a.cursor, 1u);
+        __syncthreads();
+        const uint32_t row = S.row;
+        if (row >= a.n_rows) break;
+        if (!a.compressed[row]) { __syncthreads(); continue; }  // store path: handled by the hash+copy kernel
+
+        const uint8_t *const src = a.blobs + (a.blob_off[row] - a.blob_base);
+        const uint64_t src_n = a.blob_size[row];
+        const uint8_t *const blob_end = src + src_n;
+        uint8_t *const out = a.out + a.out_off[row];
+
+        // ---- frame header (lane 0) ----
+        if (tid == 0) {
+            int err = 0;
+            uint64_t pos = 0;
+            S.out_pos = 0;
+            S.huf_valid = 0; S.valid[0] = S.valid[1] = S.valid[2] = 0;
+            S.rep[0] = 1; S.rep[1] = 4; S.rep[2] = 8;
+            if (src_n < 5) err = E_TRUNC;
+            else {
+                uint32_t magic = src[0] | (src[1] << 8) | (src[2] << 16) | ((uint32_t)src[3] << 24);
+                if (magic != 0xFD2FB528u) err = E_CORRUPT;
+                else {
+                    uint32_t fhd = src[4];
+                    uint32_t fcs_flag = fhd >> 6, single = (fhd >> 5) & 1, did_flag = fhd & 3;
+                    if (fhd & 8) err = E_CORRUPT;
+                    S.has_cksum = (fhd >> 2) & 1;
+                    uint32_t fcs_bytes = fcs_flag == 0 ? single : (1u << fcs_flag);
+                    uint32_t did_bytes = did_flag == 3 ? 4 : did_flag;
+                    pos = 5;
+                    if (src_n < pos + (single ? 0 : 1) + did_bytes + fcs_bytes) err = E_TRUNC;
+                    if (!err) {
+                        if (!single) pos++;  // window descriptor: matches are bounded by the frame start below
+                        uint32_t did = 0;
+                        for (uint32_t i = 0; i < did_bytes; i++) did |= (uint32_t)src[pos + i] << (8 * i);
+                        pos += did_bytes;
+                        if (did) err = E_UNSUP;
+                        uint64_t fcs = 0;
+                        for (uint32_t i = 0; i < fcs_bytes; i++) fcs |= (uint64_t)src[pos + i] << (8 * i);
+                        pos += fcs_bytes;
+                        if (fcs_bytes == 2) fcs += 256;
+                        if (fcs_bytes == 0) err = err ? err : E_UNSUP;  // zl_get_decompressed_size would fail
+                        S.content_size = fcs;
+                        if (!err && fcs != a.usize[row]) err = E_CORRUPT;  // index row and frame disagree
+                        if (!err && a.out_off[row] + fcs > a.out_cap) err = E_DST;
+                        if (!err && fcs >= 0xFFFFFFFFull) err = E_UNSUP;
+                    }
+                }
+            }
+            S.src_pos = pos;
+            S.src_end = src_n;
+            S.out_end = S.content_size;
+            S.err = err;
+            S.blk_last = 0;
+        }
+        __syncthreads();
+
+        // ---- blocks ----
+        for (;;) {
+            const bool stop = S.err != 0 || S.blk_last != 0;
+            __syncthreads();  // every lane has read the loop state before lane 0 rewrites it
+            if (stop) break;
+            if (tid == 0) {
+                uint64_t p = S.src_pos;
+                if (p + 3 > S.src_end) S.err = E_TRUNC;
+                else {
+                    uint32_t bh = src[p] | (src[p + 1] << 8) | (src[p + 2] << 16);
+                    S.blk_last = bh & 1; S.blk_type = (bh >> 1) & 3; S.blk_size = bh >> 3;
+                    S.src_pos = p + 3;
+                    uint32_t need = S.blk_type == 1 ? 1 : S.blk_size;
+                    if (S.blk_type == 3) S.err = E_CORRUPT;
+                    else if (S.src_pos + need > S.src_end) S.err = E_TRUNC;
+                    else if (S.blk_type != 2 && S.out_pos + S.blk_size > S.out_end) S.err = E_CORRUPT;
+                    else if (S.blk_type == 2 && S.blk_size > BLOCK_MAX) S.err = E_CORRUPT;
+                }
+            }
+            __syncthreads();
+            if (S.err) break;
+            const uint32_t btype = S.blk_type, bsize = S.blk_size;
+            const uint64_t bpos = S.src_pos;
+            if (btype == 0) {
+                coop_copy(out + S.out_pos, src + bpos, bsize, tid, NT);
+                __syncthreads();
+                if (tid == 0) { S.out_pos += bsize; S.src_pos += bsize; }
+                __syncthreads();
+                continue;
+            }
+            if (btype == 1) {
+                coop_fill(out + S.out_pos, src[bpos], bsize, tid, NT);
+                __syncthreads();
+                if (tid == 0) { S.out_pos += bsize; S.src_pos += 1; }
+                __syncthreads();
+                continue;
+            }
+
+            // ======== compressed block ========
+            const uint8_t *const bsrc = src + bpos;
+            // -- literals header + Huffman tree (lane 0) --
+            __syncthreads();
+            if (tid == 0) {
+                int err = 0;
+                uint32_t n = bsize, used = 0;
+                if (n < 1) err = E_TRUNC;
+                else {
+                    uint32_t b0 = bsrc[0], type = b0 & 3, sf = (b0 >> 2) & 3, regen = 0, comp = 0, hdr = 0;
+                    if (type <= 1) {
+                        if ((sf & 1) == 0) { regen = b0 >> 3; hdr = 1; }
+                        else if (sf == 1) { if (n < 2) err = E_TRUNC; else { regen = (b0 >> 4) + ((uint32_t)bsrc[1] << 4); hdr = 2; } }
+                        else { if (n < 3) err = E_TRUNC; else { regen = (b0 >> 4) + ((uint32_t)bsrc[1] << 4) + ((uint32_t)bsrc[2] << 12); hdr = 3; } }
+                        if (!err && regen > BLOCK_MAX) err = E_CORRUPT;
+                        if (!err) {
+                            if (type == 0) {
+                                if (hdr + regen > n) err = E_TRUNC;
+                                S.lit_kind = 0; S.lit_src = bpos + hdr; used = hdr + regen;
+                            } else {
+                                if (hdr + 1 > n) err = E_TRUNC;
+                                else { S.lit_kind = 1; S.lit_rle = bsrc[hdr]; used = hdr + 1; }
+                            }
+                            S.lit_len = regen; S.n_streams = 0;
+                        }
+                    } else {
+                        uint64_t h = 0;
+                        for (uint32_t i = 0; i < 5 && i < n; i++) h |= (uint64_t)bsrc[i] << (8 * i);
+                        uint32_t streams;
+                        if (sf == 0) { streams = 1; regen = (h >> 4) & 0x3FF; comp = (h >> 14) & 0x3FF; hdr = 3; }
+                        else if (sf == 1) { streams = 4; regen = (h >> 4) & 0x3FF; comp = (h >> 14) & 0x3FF; hdr = 3; }
+                        else if (sf == 2) { streams = 4; regen = (h >> 4) & 0x3FFF; comp = (h >> 18) & 0x3FFF; hdr = 4; }
+                        else { streams = 4; regen = (h >> 4) & 0x3FFFF; comp = (h >> 22) & 0x3FFFF; hdr = 5; }
+                        if (hdr + comp > n) err = E_TRUNC;
+                        else if (regen > BLOCK_MAX) err = E_CORRUPT;
+                        uint32_t p = hdr, remain = comp;
+                        if (!err && type == 2) {
+                            uint32_t tu = 0;
+                            err = huf_read_tree(S, bsrc + p, remain, blob_end, &tu);
+                            if (!err) { p += tu; remain -= tu; S.huf_valid = 2; }  // 2 = table must be (re)filled
+                        } else if (!err && !S.huf_valid) err = E_CORRUPT;
+                        if (!err) {
+                            if (streams == 1) {
+                                S.stream_off[0] = p; S.stream_len[0] = remain; S.stream_out[0] = 0; S.stream_n[0] = regen;
+                            } else {
+                                uint32_t seg = (regen + 3) / 4;
+                                if (remain < 6 || 3 * seg > regen) err = E_CORRUPT;
+                                else {
+                                    uint32_t s1 = bsrc[p] | (bsrc[p + 1] << 8), s2 = bsrc[p + 2] | (bsrc[p + 3] << 8),
+                                             s3 = bsrc[p + 4] | (bsrc[p + 5] << 8);
+                                    if (6 + s1 + s2 + s3 > remain) err = E_CORRUPT;
+                                    else {
+                                        uint32_t s4 = remain - 6 - s1 - s2 - s3;
+                                        p += 6;
+                                        S.stream_off[0] = p; S.stream_len[0] = s1; S.stream_out[0] = 0; S.stream_n[0] = seg;
+                                        S.stream_off[1] = p + s1; S.stream_len[1] = s2; S.stream_out[1] = seg; S.stream_n[1] = seg;
+                                        S.stream_off[2] = p + s1 + s2; S.stream_len[2] = s3; S.stream_out[2] = 2 * seg; S.stream_n[2] = seg;
+                                        S.stream_off[3] = p + s1 + s2 + s3; S.stream_len[3] = s4; S.stream_out[3] = 3 * seg; S.stream_n[3] = regen - 3 * seg;
+                                    }
+                                }
+                            }
+                            S.n_streams = streams; S.lit_kind = 2; S.lit_len = regen; used = hdr + comp;
+                        }
+                    }
+                }
+                S.err = err;
+                S.lit_pos = 0;
+                S.src_pos = bpos + used;  // now at the sequences section
+            }
+            __syncthreads();
+            if (S.err) break;
+            if (S.n_streams) {
+                if (S.huf_valid == 2) {
+                    // fill the decoding table: lane = symbol, each writes its canonical range
+                    for (uint32_t sym = tid; sym < 256; sym += NT) {
+                        uint32_t len = S.sym_len[sym];
+                        if (len) {
+                            uint32_t st = S.sym_start[sym];
+                            uint16_t e = (uint16_t)(sym | ((S.huf_log + 1 - S.weights[sym]) << 8));
+                            for (uint32_t i = 0; i < len; i++) S.huf[st + i] = e;
+                        }
+                    }
+                    __syncthreads();
+                    if (tid == 0) S.huf_valid = 1;
+                }
+                if (tid < S.n_streams) {
+                    int rc = huf_decode_stream(S, bsrc + S.stream_off[tid], S.stream_len[tid], blob_end,
+                                               lit_buf + S.stream_out[tid], S.stream_n[tid]);
+                    if (rc) atomicMin(&S.err, rc);
+                }
+                __syncthreads();  // literal bytes visible to the whole workgroup (same CU)
+                if (S.err) break;
+            }
+
+            // -- sequences header + tables (lane 0) --
+            __syncthreads();
+            if (tid == 0) {
+                int err = 0;
+                const uint64_t end = bpos + bsize;
+                uint64_t p = S.src_pos;
+                uint32_t nseq = 0;
+                if (p >= end) err = E_TRUNC;
+                else {
+                    uint32_t b0 = src[p];
+                    if (b0 == 0) { nseq = 0; p += 1; }
+                    else if (b0 < 128) { nseq = b0; p += 1; }
+                    else if (b0 < 255) { if (p + 2 > end) err = E_TRUNC; else { nseq = ((b0 - 128) << 8) + src[p + 1]; p += 2; } }
+                    else { if (p + 3 > end) err = E_TRUNC; else { nseq = src[p + 1] + ((uint32_t)src[p + 2] << 8) + 0x7F00; p += 3; } }
+                }
+                if (!err && nseq) {
+                    if (p >= end) err = E_TRUNC;
+                    else {
+                        uint32_t modes = src[p++];
+                        if (modes & 3) err = E_CORRUPT;
+                        const int shifts[3] = {6, 4, 2};
+                        const int kinds[3] = {K_LL, K_OF, K_ML};
+                        const int maxlog[3] = {9, 8, 9};
+                        const int maxsym[3] = {35, 31, 52};
+                        const int deflog[3] = {6, 5, 6};
+                        for (int k = 0; k < 3 && !err; k++) {
+                            uint32_t mode = (modes >> shifts[k]) & 3;
+                            if (mode == 0) { S.sel[k] = 0; S.log_[k] = deflog[k]; S.valid[k] = 1; }
+                            else if (mode == 1) {
+                                if (p >= end) err = E_TRUNC;
+                                else { err = fse_set_rle(&S.rle[k], src[p++], kinds[k]); S.sel[k] = 1; S.log_[k] = 0; S.valid[k] = 1; }
+                            } else if (mode == 2) {
+                                int nsym, log;
+                                uint32_t used;
+                                err = fse_read_ncount(S, src + p, (uint32_t)(end - p), maxlog[k], maxsym[k], &nsym, &log, &used);
+                                if (!err) err = fse_build(S, k == 0 ? S.ll : (k == 1 ? S.of : S.ml), nsym, log, kinds[k]);
+                                if (!err) { p += used; S.sel[k] = 2; S.log_[k] = log; S.valid[k] = 1; }
+                            } else if (!S.valid[k]) err = E_CORRUPT;
+                        }
+                        if (!err) {
+                            if (p >= end) err = E_TRUNC;
+                            else {
+                                BitR b;
+                                if (!b.init(src + p, (uint32_t)(end - p), blob_end)) err = E_CORRUPT;
+                                else {
+                                    S.st_ll = b.read(S.log_[0]);
+                                    S.st_of = b.read(S.log_[1]);
+                                    S.st_ml = b.read(S.log_[2]);
+                                    S.bs_pos = b.pos;
+                                    S.bs_off = (uint32_t)p;
+                                }
+                            }
+                        }
+                    }
+                } else if (!err && p != end) err = E_CORRUPT;
+                S.nseq = nseq;
+                S.err = err;
+                S.src_pos = end;
+            }
+            __syncthreads();
+            if (S.err) break;
+
+            // -- sequences: lane 0 decodes a batch into LDS, the workgroup executes it --
+            uint32_t seq_done = 0;
+            const uint32_t nseq = S.nseq;
+            const uint8_t *lit_ptr = S.lit_kind == 0 ? src + S.lit_src : lit_buf;
+            while (seq_done < nseq) {
+                const uint32_t bn = nseq - seq_done < SEQ_BATCH ? nseq - seq_done : SEQ_BATCH;
+                __syncthreads();
+                if (tid == 0) {
+                    const FseEntry *tl = S.sel[0] == 0 ? S.dll : (S.sel[0] == 1 ? &S.rle[0] : S.ll);
+                    const FseEntry *to = S.sel[1] == 0 ? S.dof : (S.sel[1] == 1 ? &S.rle[1] : S.of);
+                    const FseEntry *tm = S.sel[2] == 0 ? S.dml : (S.sel[2] == 1 ? &S.rle[2] : S.ml);
+                    BitR b;
+                    b.base = src + S.bs_off; b.end = blob_end; b.pos = S.bs_pos; b.refill();
+                    uint32_t sl = S.st_ll, so = S.st_of, sm = S.st_ml;
+                    uint32_t r0 = S.rep[0], r1 = S.rep[1], r2 = S.rep[2];
+                    int err = 0;
+                    uint64_t produced = 0;
+                    uint32_t lits = 0;
+                    for (uint32_t i = 0; i < bn; i++) {
+                        const FseEntry eo = to[so], em = tm[sm], el = tl[sl];
+                        uint32_t ov = eo.base + b.read(eo.addbits);
+                        uint32_t ml = em.base + b.read(em.addbits);
+                        uint32_t ll = el.base + b.read(el.addbits);
+                        if (seq_done + i + 1 < nseq) {
+                            sl = el.next + b.read(el.nbits);
+                            sm = em.next + b.read(em.nbits);
+                            so = eo.next + b.read(eo.nbits);
+                        }
+                        if (b.pos < 0) { err = E_CORRUPT; break; }
+                        uint32_t offset;
+                        if (ov > 3) { offset = ov - 3; r2 = r1; r1 = r0; r0 = offset; }
+                        else {
+                            uint32_t idx = ov - 1 + (ll == 0 ? 1 : 0);
+                            if (idx == 0) offset = r0;
+                            else {
+                                offset = idx == 1 ? r1 : (idx == 2 ? r2 : r0 - 1);
+                                if (offset == 0) { err = E_CORRUPT; break; }
+                                if (idx > 1) r2 = r1;
+                                r1 = r0; r0 = offset;
+                            }
+                        }
+                        S.seq_ll[i] = ll; S.seq_ml[i] = ml; S.seq_off[i] = offset;
+                        lits += ll;
+                        produced += (uint64_t)ll + ml;
+                        // validate against what exists at that point
+                        if (S.lit_pos + lits > S.lit_len) { err = E_CORRUPT; break; }
+                        if ((uint64_t)offset > S.out_pos + produced - ml) { err = E_CORRUPT; break; }
+                    }
+                    if (!err && S.out_pos + produced > S.out_end) err = E_CORRUPT;
+                    if (!err && seq_done + bn == nseq && b.pos != 0) err = E_CORRUPT;
+                    S.st_ll = sl; S.st_of = so; S.st_ml = sm;
+                    S.rep[0] = r0; S.rep[1] = r1; S.rep[2] = r2;
+                    S.bs_pos = b.pos;
+                    S.err = err;
+                    S.batch_n = bn;
+                }
+                __syncthreads();
+                if (S.err) break;
+                // execute: wave 0 walks the batch in order; long copies are shared by all waves
+                {
+                    uint64_t opos = S.out_pos;
+                    uint32_t lpos = S.lit_pos;
+                    const bool rle_lits = S.lit_kind == 1;
+                    const uint8_t rle_byte = (uint8_t)S.lit_rle;
+                    for (uint32_t i = 0; i < bn; i++) {
+                        const uint32_t ll = S.seq_ll[i], ml = S.seq_ml[i], off = S.seq_off[i];
+                        if (ll) {
+                            const bool big = NWAVES > 1 && ll >= BIG_COPY;
+                            if (big) __syncthreads();
+                            if (big || wave0) {
+                                const uint32_t nt = big ? NT : 64;
+                                if (rle_lits) coop_fill(out + opos, rle_byte, ll, tid, nt);
+                                else coop_copy(out + opos, lit_ptr + lpos, ll, tid, nt);
+                            }
+                            if (big) __syncthreads();
+                            opos += ll; lpos += ll;
+                        }
+                        {
+                            const bool big = NWAVES > 1 && ml >= BIG_COPY;
+                            if (big) __syncthreads();
+                            else if (wave0) wave_mem_sync();
+                            if (big || wave0) coop_match<NWAVES>(out + opos, off, ml, tid, big);
+                            if (big) __syncthreads();
+                            opos += ml;
+                        }
+                    }
+                    __syncthreads();
+                    if (tid == 0) { S.out_pos = opos; S.lit_pos = lpos; }
+                }
+                seq_done += bn;
+                __syncthreads();
+            }
+            if (S.err) break;
+            // -- literals left after the last sequence --
+            {
+                const uint32_t rest = S.lit_len - S.lit_pos;
+                if (S.out_pos + rest > S.out_end) { if (tid == 0) S.err = E_CORRUPT; }
+                else if (rest) {
+                    if (S.lit_kind == 1) coop_fill(out + S.out_pos, (uint8_t)S.lit_rle, rest, tid, NT);
+                    else coop_copy(out + S.out_pos, lit_ptr + S.lit_pos, rest, tid, NT);
+                }
+                __syncthreads();
+                if (tid == 0) S.out_pos += rest;
+                __syncthreads();
+            }
+        }
+        __syncthreads();
+        if (tid == 0) {
+            int err = S.err;
+            if (!err && S.out_pos != S.content_size) err = E_CORRUPT;
+            if (!err && S.has_cksum && S.src_pos + 4 > S.src_end) err = E_TRUNC;
+            a.status[row] = err;
+        }
+        __syncthreads();
+    }
+}
+
+int decode_grid_size(int device) {
+    hipDeviceProp_t p;
+    if (hipGetDeviceProperties(&p, device) != hipSuccess) return 1024;
+    return p.multiProcessorCount * 4;
+}
+
+size_t decode_lit_scratch_bytes(int grid) { return (size_t)grid * LIT_SCRATCH_BYTES; }
+
+void launch_decode(const DecodeArgs &a, int grid, hipStream_t s) {
+    if (!a.n_rows) return;
+    hipLaunchKernelGGL(k_zstd_decode<4>, dim3(grid), dim3(256), 0, s, a);
+}
+
+}  // namespace zn

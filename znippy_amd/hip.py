@@ -1,0 +1,192 @@
+"""Object wrappers over the C ABI (include/znippy_hip.h).  Device buffers are torch uint8 CUDA
+tensors (PyTorch-ROCm is only the allocator/stream provider); every compute call goes through
+libznippy_hip.so."""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import VerifyCounters, ZnippyError, as_np, np_ptr, vp
+
+
+def _dptr(t):
+    if t is None:
+        return None
+    if isinstance(t, int):
+        return vp(t)
+    assert t.is_cuda and t.is_contiguous(), "device buffers must be contiguous CUDA tensors"
+    return vp(t.data_ptr())
+
+
+class Context:
+    """One per worker / GPU — the analogue of one CompressCtx per thread (codec.rs:L8-28)."""
+
+    def __init__(self, device=0, stream=None):
+        self.L = _lib.lib()
+        h = vp()
+        rc = self.L.znippy_ctx_create(int(device), vp(stream) if stream else None, C.byref(h))
+        if rc:
+            raise ZnippyError(rc, "znippy_ctx_create")
+        self.h = h
+        self.device = int(device)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.znippy_ctx_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def _chk(self, rc, what):
+        if rc:
+            raise ZnippyError(rc, what, (self.L.znippy_last_error(self.h) or b"").decode())
+
+    def sync(self):
+        self._chk(self.L.znippy_ctx_sync(self.h), "znippy_ctx_sync")
+
+    def kernel_times(self):
+        names = (C.c_char_p * 16)()
+        ms = (C.c_float * 16)()
+        n = self.L.znippy_last_kernel_times(self.h, names, ms, 16)
+        return [(names[i].decode(), float(ms[i])) for i in range(n)]
+
+    # ---- single-chunk shims (codec.rs semantics, host buffers) ----
+    def compress_bound(self, n):
+        return int(self.L.znippy_compress_bound(n))
+
+    def blake3(self, data) -> bytes:
+        a = np.frombuffer(data, dtype=np.uint8) if not isinstance(data, np.ndarray) else data
+        out = (C.c_uint8 * 32)()
+        self._chk(self.L.znippy_blake3(self.h, np_ptr(a) if a.size else None, a.size, out), "znippy_blake3")
+        return bytes(out)
+
+    def decompress(self, frame) -> bytes:
+        a = np.frombuffer(frame, dtype=np.uint8)
+        n = get_decompressed_size(frame)
+        out = np.empty(max(n, 1), dtype=np.uint8)
+        w = C.c_size_t()
+        self._chk(self.L.znippy_decompress(self.h, np_ptr(a), a.size, np_ptr(out), n, C.byref(w)), "znippy_decompress")
+        return out[:w.value].tobytes()
+
+    def compress(self, data) -> bytes:
+        a = np.frombuffer(data, dtype=np.uint8) if not isinstance(data, np.ndarray) else data
+        cap = self.compress_bound(a.size)
+        out = np.empty(cap, dtype=np.uint8)
+        w = C.c_size_t()
+        self._chk(self.L.znippy_compress(self.h, np_ptr(a) if a.size else None, a.size, np_ptr(out), cap, C.byref(w)),
+                  "znippy_compress")
+        return out[:w.value].tobytes()
+
+
+def get_decompressed_size(frame) -> int:
+    a = np.frombuffer(frame, dtype=np.uint8)
+    v = C.c_uint64()
+    rc = _lib.lib().znippy_get_decompressed_size(np_ptr(a), a.size, C.byref(v))
+    if rc:
+        raise ZnippyError(rc, "znippy_get_decompressed_size")
+    return v.value
+
+
+class RowTable:
+    """Device-resident slice [row_begin,row_end) of the index columns + its work plan."""
+
+    def __init__(self, ctx, blob_offset, blob_size, uncompressed_size, out_offset, compressed_bitmap=None,
+                 checksum=None, row_begin=0, row_end=None):
+        self.ctx = ctx
+        bo = as_np(blob_offset, np.uint64)
+        bs = as_np(blob_size, np.uint64)
+        us = as_np(uncompressed_size, np.uint64)
+        oo = as_np(out_offset, np.uint64)
+        n = len(bo)
+        row_end = n if row_end is None else row_end
+        bm = as_np(compressed_bitmap, np.uint8) if compressed_bitmap is not None else None
+        ck = as_np(checksum, np.uint8).reshape(-1) if checksum is not None else None
+        h = vp()
+        ctx._chk(ctx.L.znippy_rows_create(ctx.h, np_ptr(bo), np_ptr(bs), np_ptr(bm) if bm is not None else None,
+                                          np_ptr(us), np_ptr(oo), np_ptr(ck) if ck is not None else None,
+                                          row_begin, row_end, C.byref(h)), "znippy_rows_create")
+        self.h = h
+        self.row_begin, self.row_end = row_begin, row_end
+        self.n = row_end - row_begin
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.ctx.L.znippy_rows_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def decode_verify_async(self, d_blobs, d_out, blob_base=0, out_cap=None):
+        out_cap = d_out.numel() if out_cap is None else out_cap
+        self.ctx._chk(self.ctx.L.znippy_decode_verify_rows_async(self.ctx.h, self.h, _dptr(d_blobs), blob_base,
+                                                                 _dptr(d_out), out_cap),
+                      "znippy_decode_verify_rows_async")
+
+    def results(self, want_status=True):
+        c = VerifyCounters()
+        corrupt = np.zeros(max(self.n, 1), dtype=np.uint64)
+        status = np.zeros(max(self.n, 1), dtype=np.int32)
+        self.ctx._chk(self.ctx.L.znippy_rows_results(self.ctx.h, self.h, C.byref(c), np_ptr(corrupt), corrupt.size,
+                                                     np_ptr(status) if want_status else None), "znippy_rows_results")
+        return c.as_dict(), corrupt[:min(c.corrupt_rows, corrupt.size)].copy(), status[:self.n]
+
+    def decode_verify(self, d_blobs, d_out, blob_base=0, out_cap=None):
+        self.decode_verify_async(d_blobs, d_out, blob_base, out_cap)
+        return self.results()
+
+    def digests(self):
+        out = np.zeros((max(self.n, 1), 32), dtype=np.uint8)
+        self.ctx._chk(self.ctx.L.znippy_rows_digests(self.ctx.h, self.h, np_ptr(out)), "znippy_rows_digests")
+        return out[:self.n]
+
+
+class RoundTable:
+    """Device-resident batch of Rounds (offset,len,skip) over one staging buffer."""
+
+    def __init__(self, ctx, src_offset, length, skip=None):
+        self.ctx = ctx
+        so = as_np(src_offset, np.uint64)
+        ln = as_np(length, np.uint64)
+        sk = as_np(skip, np.uint8) if skip is not None else None
+        self.n = len(so)
+        h = vp()
+        ctx._chk(ctx.L.znippy_rounds_create(ctx.h, np_ptr(so), np_ptr(ln), np_ptr(sk) if sk is not None else None,
+                                            self.n, C.byref(h)), "znippy_rounds_create")
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.ctx.L.znippy_rounds_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def blob_bound(self):
+        return int(self.ctx.L.znippy_rounds_blob_bound(self.h))
+
+    def hash(self, d_src):
+        out = np.zeros((max(self.n, 1), 32), dtype=np.uint8)
+        self.ctx._chk(self.ctx.L.znippy_hash_rounds(self.ctx.h, self.h, _dptr(d_src), np_ptr(out)), "znippy_hash_rounds")
+        return out[:self.n]
+
+    def encode_hash_async(self, d_src, d_blob_out, blob_cap=None):
+        blob_cap = d_blob_out.numel() if blob_cap is None else blob_cap
+        self.ctx._chk(self.ctx.L.znippy_encode_hash_rounds_async(self.ctx.h, self.h, _dptr(d_src), _dptr(d_blob_out),
+                                                                 blob_cap), "znippy_encode_hash_rounds_async")
+
+    def results(self):
+        n = max(self.n, 1)
+        bo = np.zeros(n, dtype=np.uint64)
+        bs = np.zeros(n, dtype=np.uint64)
+        ck = np.zeros((n, 32), dtype=np.uint8)
+        cm = np.zeros(n, dtype=np.uint8)
+        total = C.c_uint64()
+        self.ctx._chk(self.ctx.L.znippy_rounds_results(self.ctx.h, self.h, np_ptr(bo), np_ptr(bs), np_ptr(ck),
+                                                       np_ptr(cm), C.byref(total)), "znippy_rounds_results")
+        k = self.n
+        return dict(blob_offset=bo[:k], blob_size=bs[:k], checksum=ck[:k], compressed=cm[:k],
+                    blob_bytes=int(total.value))
+
+    def encode_hash(self, d_src, d_blob_out, blob_cap=None):
+        self.encode_hash_async(d_src, d_blob_out, blob_cap)
+        return self.results()
