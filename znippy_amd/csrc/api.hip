@@ -483,14 +483,14 @@ int znippy_hash_rounds(znippy_ctx *ctx, znippy_rounds *r, const void *d_src, uin
 
 // ---- single-chunk shims -------------------------------------------------------------------------
 static int shim_reserve(znippy_ctx *ctx, size_t in_need, size_t out_need) {
-    if (in_need > ctx->shim_in_cap) {
+    if (in_need > ctx->shim_in_cap || !ctx->shim_in) {
         if (ctx->shim_in) (void)hipFree(ctx->shim_in);
         ctx->shim_in = nullptr; ctx->shim_in_cap = 0;
         size_t cap = std::max<size_t>(in_need + 64, 1 << 16);
         HIPCHK(ctx, hipMalloc(&ctx->shim_in, cap));
         ctx->shim_in_cap = cap;
     }
-    if (out_need > ctx->shim_out_cap) {
+    if (out_need > ctx->shim_out_cap || !ctx->shim_out) {
         if (ctx->shim_out) (void)hipFree(ctx->shim_out);
         ctx->shim_out = nullptr; ctx->shim_out_cap = 0;
         size_t cap = std::max<size_t>(out_need + 64, 1 << 16);
