@@ -1,0 +1,133 @@
+"""GPU parity for the write side: BLAKE3 + zstd encode of Rounds through the C ABI.
+
+Replaces the barrel/writer bodies (stream_packer.rs:L217-284, slot_packer.rs:L551-609) and
+CompressCtx::compress_into (codec.rs:L43-55).  Compressed BYTES cannot equal the reference's
+(OpenZL framing is unpinned); what is bit-exact is everything the format pins:
+decoded bytes (checked with three independent decoders: libzstd, the oracle, the GPU decoder),
+per-chunk BLAKE3, the compressed flag, uncompressed_size, and blob packing (offsets are the
+running sum of on_disk_len from 0 with no gaps, stream_packer.rs:L258).
+"""
+import numpy as np
+import pytest
+
+import gen
+
+pytestmark = pytest.mark.gpu
+
+
+CASES = [("text", 10240), ("binary", 10240), ("random_lcg", 10240), ("pseudo_text", 5000), ("pseudo_text", 300000),
+         ("text", 1), ("text", 0), ("text", 7), ("text", 8), ("zeros", 200000), ("text", 1 << 20),
+         ("pseudo_text", (1 << 20) + 12345), ("binary", 3 << 20), ("random_lcg", 300000), ("text", 131072),
+         ("text", 131073), ("zeros", 131072 * 2)]
+
+
+def _gen(name, n):
+    return bytes(n) if name == "zeros" else getattr(gen, name)(n)
+
+
+@pytest.mark.parametrize("gname,n", CASES)
+def test_shim_roundtrip_three_decoders(gpu_ctx, oracle, gname, n):
+    data = _gen(gname, n)
+    frame = gpu_ctx.compress(data)
+    assert len(frame) <= gpu_ctx.compress_bound(n)
+    assert oracle.zstd_decompressed_size(frame) == n
+    assert oracle.libzstd_decompress(frame, n) == data      # independent RFC 8878 decoder
+    assert oracle.zstd_decompress(frame) == data            # oracle restatement
+    assert gpu_ctx.decompress(frame) == data                # GPU decoder
+
+
+def test_compressible_inputs_actually_shrink(gpu_ctx):
+    assert len(gpu_ctx.compress(gen.text(10240))) < 200
+    assert len(gpu_ctx.compress(gen.binary(10240))) < 400
+    assert len(gpu_ctx.compress(bytes(1 << 20))) < 1000
+    assert len(gpu_ctx.compress(gen.pseudo_text(300000))) < 300000 * 0.9  # raw literals, greedy parse
+    n = len(gpu_ctx.compress(gen.random_lcg(300000)))
+    assert 300000 < n <= 300000 + 3 * 3 + 16    # incompressible -> raw blocks, tiny overhead
+
+
+def test_rounds_batch_matches_write_loop_metadata(gpu_ctx, oracle):
+    """A mixed batch of Rounds incl. skip (store) rounds, an empty round and a multi-block round."""
+    import torch
+    from znippy_amd import hip
+    rng = np.random.default_rng(3)
+    entries, skip = [], []
+    for i in range(200):
+        kind = i % 5
+        n = int(rng.integers(0, 50000))
+        e = [gen.text(n), gen.binary(n), gen.pseudo_text(n, seed=i), gen.incompressible(i, n), b""][kind]
+        entries.append(e)
+        skip.append(1 if kind == 3 else 0)
+    entries += [gen.pseudo_text(700000, seed=5), gen.incompressible(9, 2_500_000), gen.text(400000)]
+    skip += [0, 1, 0]
+    lens = np.array([len(e) for e in entries], dtype=np.uint64)
+    # ragged, unaligned placement inside the staging buffer
+    offs, pos = [], 1
+    for L in lens:
+        offs.append(pos)
+        pos += int(L) + int(rng.integers(0, 5))
+    buf = np.zeros(pos + 64, dtype=np.uint8)
+    for o, e in zip(offs, entries):
+        buf[o:o + len(e)] = np.frombuffer(e, dtype=np.uint8)
+    d_src = torch.from_numpy(buf).cuda()
+    rt = hip.RoundTable(gpu_ctx, offs, lens, skip)
+    d_blob = torch.zeros(rt.blob_bound() + 64, dtype=torch.uint8, device="cuda")
+    res = rt.encode_hash(d_src, d_blob)
+    want = oracle.compress_rounds(buf, np.array(offs, dtype=np.uint64), lens, np.array(skip, dtype=np.uint8),
+                                  level=3, n_threads=1)
+    assert np.array_equal(res["checksum"], want["checksum"])          # BLAKE3 of the ORIGINAL bytes
+    assert np.array_equal(res["compressed"], want["compressed"])      # skip -> compressed=false
+    # blobs packed back-to-back from 0 in round order
+    assert int(res["blob_offset"][0]) == 0
+    assert np.array_equal(res["blob_offset"][1:], np.cumsum(res["blob_size"])[:-1])
+    assert res["blob_bytes"] == int(res["blob_size"].sum())
+    blob = d_blob[:res["blob_bytes"]].cpu().numpy()
+    for i, e in enumerate(entries):
+        b = blob[int(res["blob_offset"][i]):int(res["blob_offset"][i] + res["blob_size"][i])].tobytes()
+        if skip[i]:
+            assert b == e
+        else:
+            assert oracle.libzstd_decompress(b, len(e)) == e, i
+    # and the GPU read path consumes the GPU-written archive: counters equal the oracle loop's
+    out_off = np.concatenate([[0], np.cumsum(lens)[:-1]]).astype(np.uint64)
+    bitmap = np.packbits(res["compressed"].astype(bool), bitorder="little")
+    rows = hip.RowTable(gpu_ctx, res["blob_offset"], res["blob_size"], lens, out_off, bitmap, res["checksum"])
+    d_out = torch.zeros(int(lens.sum()) + 64, dtype=torch.uint8, device="cuda")
+    counters, corrupt, status = rows.decode_verify(d_blob, d_out)
+    wantc, _ = oracle.decompress_rows(blob, res["blob_offset"], res["blob_size"], lens, out_off, bitmap,
+                                      res["checksum"], 0, len(entries))
+    assert counters == wantc and (status == 0).all() and len(corrupt) == 0
+    assert d_out[:int(lens.sum())].cpu().numpy().tobytes() == b"".join(entries)
+
+
+def test_blob_cap_too_small_is_reported(gpu_ctx):
+    import torch
+    from znippy_amd import hip
+    from znippy_amd._lib import ZnippyError, E_DST_SMALL
+    data = np.frombuffer(gen.random_lcg(100000), dtype=np.uint8)
+    d_src = torch.from_numpy(data.copy()).cuda()
+    rt = hip.RoundTable(gpu_ctx, [0], [100000])
+    d_blob = torch.zeros(50000, dtype=torch.uint8, device="cuda")
+    with pytest.raises(ZnippyError) as ei:
+        rt.encode_hash(d_src, d_blob)
+    assert ei.value.code == E_DST_SMALL
+
+
+def test_c2_shape_100k_rounds(gpu_ctx, oracle):
+    """BASELINE C2 at full size on the write side: 100k identical 10 KiB text chunks."""
+    import torch
+    from znippy_amd import hip
+    n, sz = 100_000, 10240
+    chunk = gen.text(sz)
+    d_src = torch.from_numpy(np.tile(np.frombuffer(chunk, dtype=np.uint8), n)).cuda()
+    rt = hip.RoundTable(gpu_ctx, np.arange(n, dtype=np.uint64) * sz, np.full(n, sz, np.uint64))
+    d_blob = torch.zeros(rt.blob_bound() + 64, dtype=torch.uint8, device="cuda")
+    res = rt.encode_hash(d_src, d_blob)
+    want = np.frombuffer(oracle.blake3(chunk), dtype=np.uint8)
+    assert (res["checksum"] == want[None, :]).all()
+    assert (res["blob_size"] == res["blob_size"][0]).all() and int(res["blob_size"][0]) < 200
+    assert np.array_equal(res["blob_offset"], np.arange(n, dtype=np.uint64) * res["blob_size"][0])
+    blob = d_blob[:res["blob_bytes"]].cpu().numpy()
+    fl = int(res["blob_size"][0])
+    frames = blob.reshape(n, fl)
+    assert (frames == frames[0][None, :]).all()            # identical inputs -> identical frames
+    assert oracle.libzstd_decompress(frames[0].tobytes(), sz) == chunk

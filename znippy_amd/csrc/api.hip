@@ -2,6 +2,7 @@
 // index columns / Round tables, the tile plan that drives the kernels' work cursor, kernel
 // launches on the context's HIP stream, and result read-back.
 #include "common.h"
+#include "encode.h"
 #include "../../include/znippy_hip.h"
 
 #include <algorithm>
@@ -12,9 +13,6 @@
 
 namespace zn {
 size_t decode_lit_scratch_bytes(int grid);
-// encoder (zstd_encode.hip)
-struct EncodeArgs;
-size_t encode_bound(size_t n);
 }  // namespace zn
 
 using namespace zn;
@@ -45,6 +43,12 @@ struct znippy_ctx {
     // shim scratch (grow-only)
     uint8_t *shim_in = nullptr, *shim_out = nullptr;
     size_t shim_in_cap = 0, shim_out_cap = 0;
+    // encoder scratch (grow-only) + tables
+    int encode_grid = 0;
+    uint8_t *enc_prov = nullptr;
+    size_t enc_prov_cap = 0;
+    uint32_t *enc_seq = nullptr;
+    EncTables *enc_tabs = nullptr;
     // kernel timing
     std::vector<KTime> ktimes;
     int n_ktimes = 0;
@@ -142,8 +146,14 @@ struct znippy_rounds {
     std::vector<uint8_t> h_skip;
     uint64_t blob_bound = 0;
     DevPlan plan;
-    // encoder state (filled by zstd_encode.hip helpers)
-    void *enc = nullptr;
+    // encoder plan: one item per output piece
+    EncItem *items = nullptr;
+    uint32_t n_items = 0;
+    uint64_t prov_bytes = 0;
+    uint32_t *piece_len = nullptr, *piece_len_init = nullptr;
+    uint64_t *piece_start = nullptr, *local_excl = nullptr, *block_tot = nullptr;
+    uint64_t *blob_offset = nullptr, *blob_size = nullptr, *total = nullptr;
+    uint32_t *overflow = nullptr;
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -187,6 +197,19 @@ int znippy_ctx_create(int device, void *hip_stream, znippy_ctx **out) {
         delete ctx;
         return ZNIPPY_E_NOMEM;
     }
+    {
+        hipDeviceProp_t p;
+        int cus = hipGetDeviceProperties(&p, device) == hipSuccess ? p.multiProcessorCount : 256;
+        ctx->encode_grid = cus * 12;
+        EncTables t;
+        build_encode_tables(&t);
+        if (hipMalloc(&ctx->enc_seq, (size_t)ctx->encode_grid * MAX_SEQ * 3 * 4) != hipSuccess ||
+            hipMalloc(&ctx->enc_tabs, sizeof(EncTables)) != hipSuccess ||
+            hipMemcpy(ctx->enc_tabs, &t, sizeof t, hipMemcpyHostToDevice) != hipSuccess) {
+            delete ctx;
+            return ZNIPPY_E_NOMEM;
+        }
+    }
     *out = ctx;
     return ZNIPPY_OK;
 }
@@ -200,6 +223,9 @@ void znippy_ctx_destroy(znippy_ctx *ctx) {
     if (ctx->cursor) (void)hipFree(ctx->cursor);
     if (ctx->shim_in) (void)hipFree(ctx->shim_in);
     if (ctx->shim_out) (void)hipFree(ctx->shim_out);
+    if (ctx->enc_prov) (void)hipFree(ctx->enc_prov);
+    if (ctx->enc_seq) (void)hipFree(ctx->enc_seq);
+    if (ctx->enc_tabs) (void)hipFree(ctx->enc_tabs);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -410,7 +436,8 @@ int znippy_rows_digests(znippy_ctx *ctx, znippy_rows *r, uint8_t *digests) {
 void znippy_rounds_destroy(znippy_rounds *r) {
     if (!r) return;
     (void)hipSetDevice(r->ctx->device);
-    void *ptrs[] = {r->src_off, r->len, r->skip, r->digests};
+    void *ptrs[] = {r->src_off, r->len, r->skip, r->digests, r->items, r->piece_len, r->piece_len_init,
+                    r->piece_start, r->local_excl, r->block_tot, r->blob_offset, r->blob_size, r->total, r->overflow};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     free_plan(r->plan);
@@ -444,6 +471,45 @@ int znippy_rounds_create(znippy_ctx *ctx, const uint64_t *src_offset, const uint
     if ((rc = upload_plan(ctx, p, r->plan))) {
         znippy_rounds_destroy(r);
         return rc;
+    }
+    // encoder plan: one item per output piece, in round order
+    std::vector<EncItem> items;
+    std::vector<uint32_t> plen;
+    for (uint64_t i = 0; i < n; i++) {
+        if (r->h_skip[i]) {
+            uint64_t L = len[i];
+            uint32_t np = (uint32_t)std::max<uint64_t>(1, (L + SKIP_PIECE - 1) / SKIP_PIECE);
+            for (uint32_t k = 0; k < np; k++) {
+                uint64_t o = (uint64_t)k * SKIP_PIECE;
+                items.push_back(EncItem{(uint32_t)i, k, np, ITEM_SKIP | (k == 0 ? ITEM_FIRST : 0), o});
+                plen.push_back((uint32_t)std::min<uint64_t>(SKIP_PIECE, L - o));
+            }
+        } else {
+            uint64_t L = len[i];
+            uint32_t nb = (uint32_t)std::max<uint64_t>(1, (L + BLOCK_BYTES - 1) / BLOCK_BYTES);
+            for (uint32_t k = 0; k < nb; k++) {
+                uint32_t bl = (uint32_t)std::min<uint64_t>(BLOCK_BYTES, L - (uint64_t)k * BLOCK_BYTES);
+                items.push_back(EncItem{(uint32_t)i, k, nb, k == 0 ? ITEM_FIRST : 0u, r->prov_bytes});
+                plen.push_back(0);
+                r->prov_bytes += enc_slot_bytes(bl);
+            }
+        }
+    }
+    if (items.size() >= 0xFFFFFFF0ull) { znippy_rounds_destroy(r); return ZNIPPY_E_INVAL; }
+    r->n_items = (uint32_t)items.size();
+    const size_t ni = std::max<size_t>(r->n_items, 1), nsb = (ni + 1023) / 1024;
+    if ((rc = dev_upload(ctx, &r->items, items.data(), items.size())) ||
+        (rc = dev_upload(ctx, &r->piece_len_init, plen.data(), plen.size()))) {
+        znippy_rounds_destroy(r);
+        return rc;
+    }
+    if (hipMalloc(&r->piece_len, 4 * ni) != hipSuccess || hipMalloc(&r->piece_start, 8 * ni) != hipSuccess ||
+        hipMalloc(&r->local_excl, 8 * ni) != hipSuccess || hipMalloc(&r->block_tot, 8 * nsb) != hipSuccess ||
+        hipMalloc(&r->blob_offset, std::max<size_t>(8 * n, 16)) != hipSuccess ||
+        hipMalloc(&r->blob_size, std::max<size_t>(8 * n, 16)) != hipSuccess ||
+        hipMalloc(&r->total, 16) != hipSuccess || hipMalloc(&r->overflow, 16) != hipSuccess) {
+        znippy_rounds_destroy(r);
+        return ZNIPPY_E_NOMEM;
     }
     *out = r;
     return ZNIPPY_OK;
@@ -541,14 +607,104 @@ int znippy_decompress(znippy_ctx *ctx, const void *frame, size_t n, void *dst, s
 
 }  // extern "C"
 
-extern "C" size_t znippy_compress_bound(size_t n) {
-    // every 128 KiB block can fall back to a raw block (3-byte header) + frame header/epilogue
-    return n + (n >> 8) + 64;
+
+// ---- write side ------------------------------------------------------------------------------------
+extern "C" int znippy_encode_hash_rounds_async(znippy_ctx *ctx, znippy_rounds *r, const void *d_src, void *d_blob_out,
+                                               uint64_t blob_cap) {
+    if (!ctx || !r || r->ctx != ctx || (r->n && (!d_src || !d_blob_out))) return ZNIPPY_E_INVAL;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    ctx->n_ktimes = 0;
+    if (!r->n) return ZNIPPY_OK;
+    if (r->prov_bytes + 64 > ctx->enc_prov_cap) {
+        HIPCHK(ctx, hipStreamSynchronize(s));
+        if (ctx->enc_prov) (void)hipFree(ctx->enc_prov);
+        ctx->enc_prov = nullptr; ctx->enc_prov_cap = 0;
+        HIPCHK(ctx, hipMalloc(&ctx->enc_prov, r->prov_bytes + 64));
+        ctx->enc_prov_cap = r->prov_bytes + 64;
+    }
+    int rc = hash_rounds_async(ctx, r, d_src);  // checksum over the ORIGINAL bytes (stream_packer.rs:L219)
+    if (rc) return rc;
+    HIPCHK(ctx, hipMemcpyAsync(r->piece_len, r->piece_len_init, 4 * (size_t)r->n_items, hipMemcpyDeviceToDevice, s));
+    HIPCHK(ctx, hipMemsetAsync(r->blob_size, 0, 8 * (size_t)r->n, s));
+    HIPCHK(ctx, hipMemsetAsync(r->overflow, 0, 16, s));
+    HIPCHK(ctx, hipMemsetAsync(r->total, 0, 16, s));
+    HIPCHK(ctx, hipMemsetAsync(ctx->cursor, 0, 64, s));
+    EncodeArgs a{};
+    a.items = r->items; a.n_items = r->n_items; a.cursor = ctx->cursor;
+    a.src = (const uint8_t *)d_src; a.src_off = r->src_off; a.len = r->len;
+    a.prov = ctx->enc_prov; a.seq_scratch = ctx->enc_seq;
+    a.piece_len = r->piece_len; a.piece_start = r->piece_start; a.tabs = ctx->enc_tabs;
+    ktime_begin(ctx, "zstd_encode");
+    launch_encode(a, std::min<int>(ctx->encode_grid, (int)r->n_items), s);
+    ktime_end(ctx);
+    ktime_begin(ctx, "piece_scan");
+    launch_piece_scan(r->piece_len, r->n_items, r->local_excl, r->block_tot, s);
+    ktime_end(ctx);
+    GatherArgs g{};
+    g.items = r->items; g.n_pieces = r->n_items; g.piece_len = r->piece_len; g.piece_start = r->piece_start;
+    g.local_excl = r->local_excl; g.block_tot = r->block_tot; g.prov = ctx->enc_prov;
+    g.src = (const uint8_t *)d_src; g.src_off = r->src_off;
+    g.blob_out = (uint8_t *)d_blob_out; g.blob_cap = blob_cap;
+    g.blob_offset = r->blob_offset; g.blob_size = r->blob_size; g.total = r->total; g.overflow = r->overflow;
+    ktime_begin(ctx, "gather");
+    launch_gather(g, s);
+    ktime_end(ctx);
+    HIPCHK(ctx, hipGetLastError());
+    return ZNIPPY_OK;
 }
 
-// ---- encoder entry points: TEMPORARY stubs until zstd_encode.hip lands -------------------------
-extern "C" int znippy_compress(znippy_ctx *, const void *, size_t, void *, size_t, size_t *) { return ZNIPPY_E_UNSUPPORTED; }
-extern "C" int znippy_encode_hash_rounds(znippy_ctx *, znippy_rounds *, const void *, void *, uint64_t, uint64_t *,
-                                         uint64_t *, uint8_t *, uint8_t *, uint64_t *) { return ZNIPPY_E_UNSUPPORTED; }
-extern "C" int znippy_encode_hash_rounds_async(znippy_ctx *, znippy_rounds *, const void *, void *, uint64_t) { return ZNIPPY_E_UNSUPPORTED; }
-extern "C" int znippy_rounds_results(znippy_ctx *, znippy_rounds *, uint64_t *, uint64_t *, uint8_t *, uint8_t *, uint64_t *) { return ZNIPPY_E_UNSUPPORTED; }
+extern "C" int znippy_rounds_results(znippy_ctx *ctx, znippy_rounds *r, uint64_t *blob_offset, uint64_t *blob_size,
+                                     uint8_t *checksum, uint8_t *compressed, uint64_t *blob_bytes) {
+    if (!ctx || !r || r->ctx != ctx) return ZNIPPY_E_INVAL;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (blob_bytes) *blob_bytes = 0;
+    if (!r->n) return ZNIPPY_OK;
+    uint32_t ovf = 0;
+    uint64_t total = 0;
+    HIPCHK(ctx, hipMemcpy(&ovf, r->overflow, 4, hipMemcpyDeviceToHost));
+    HIPCHK(ctx, hipMemcpy(&total, r->total, 8, hipMemcpyDeviceToHost));
+    if (ovf) return ZNIPPY_E_DST_SMALL;
+    if (blob_offset) HIPCHK(ctx, hipMemcpy(blob_offset, r->blob_offset, 8 * (size_t)r->n, hipMemcpyDeviceToHost));
+    if (blob_size) HIPCHK(ctx, hipMemcpy(blob_size, r->blob_size, 8 * (size_t)r->n, hipMemcpyDeviceToHost));
+    if (checksum) HIPCHK(ctx, hipMemcpy(checksum, r->digests, 32 * (size_t)r->n, hipMemcpyDeviceToHost));
+    if (compressed)
+        for (uint32_t i = 0; i < r->n; i++) compressed[i] = r->h_skip[i] ? 0 : 1;
+    if (blob_bytes) *blob_bytes = total;
+    return ZNIPPY_OK;
+}
+
+extern "C" int znippy_encode_hash_rounds(znippy_ctx *ctx, znippy_rounds *rounds, const void *d_src, void *d_blob_out,
+                                         uint64_t blob_cap, uint64_t *blob_offset, uint64_t *blob_size,
+                                         uint8_t *checksum, uint8_t *compressed, uint64_t *blob_bytes) {
+    int rc = znippy_encode_hash_rounds_async(ctx, rounds, d_src, d_blob_out, blob_cap);
+    if (rc) return rc;
+    return znippy_rounds_results(ctx, rounds, blob_offset, blob_size, checksum, compressed, blob_bytes);
+}
+
+extern "C" int znippy_compress(znippy_ctx *ctx, const void *src, size_t n, void *dst, size_t cap, size_t *written) {
+    if (!ctx || !written || !dst || (n && !src)) return ZNIPPY_E_INVAL;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const size_t bound = znippy_compress_bound(n);
+    int rc = shim_reserve(ctx, n, bound);
+    if (rc) return rc;
+    if (n) HIPCHK(ctx, hipMemcpyAsync(ctx->shim_in, src, n, hipMemcpyHostToDevice, ctx->stream));
+    uint64_t off = 0, len = n, bsz = 0, total = 0;
+    znippy_rounds *r = nullptr;
+    rc = znippy_rounds_create(ctx, &off, &len, nullptr, 1, &r);
+    if (rc) return rc;
+    rc = znippy_encode_hash_rounds(ctx, r, ctx->shim_in, ctx->shim_out, ctx->shim_out_cap, nullptr, &bsz, nullptr, nullptr,
+                                   &total);
+    znippy_rounds_destroy(r);
+    if (rc) return rc;
+    if (total > cap) return ZNIPPY_E_DST_SMALL;
+    HIPCHK(ctx, hipMemcpy(dst, ctx->shim_out, total, hipMemcpyDeviceToHost));
+    *written = total;
+    return ZNIPPY_OK;
+}
+
+extern "C" size_t znippy_compress_bound(size_t n) {
+    // every 128 KiB block can fall back to a raw block (3-byte header) + frame header
+    return n + 3 * (n / BLOCK_BYTES + 1) + 16;
+}

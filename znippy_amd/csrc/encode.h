@@ -1,0 +1,71 @@
+// Internal declarations shared by zstd_encode.hip and api.hip.
+#pragma once
+#include "common.h"
+#include <cstring>
+#include <vector>
+
+namespace zn {
+
+constexpr uint32_t BLOCK_BYTES = 128 * 1024;  // zstd Block_Maximum_Size
+constexpr uint32_t HDR_ROOM = 16;             // space in front of block 0 for the frame header
+constexpr uint32_t MAX_SEQ = 4096;            // sequences per block (block_len/40 at most)
+constexpr uint32_t SKIP_PIECE = 1u << 20;     // store-path rounds are gathered in 1 MiB pieces
+
+struct FseSymTT {
+    int32_t delta_find_state;
+    uint32_t delta_nb_bits;
+};
+
+struct EncTables {  // FSE encoding tables of the predefined LL / ML / OF distributions
+    uint16_t ll_state[64], ml_state[64], of_state[32];
+    FseSymTT ll_tt[36], ml_tt[53], of_tt[29];
+};
+
+constexpr uint32_t ITEM_SKIP = 1, ITEM_FIRST = 2;
+
+// One output piece.  Encoded rounds: one item per <=128 KiB block (prov = offset of the item's
+// provisional slot).  Store-path rounds: one item per <=1 MiB slice (prov = byte offset of the
+// slice inside the round; the gather pass copies it straight from the staging buffer).
+struct EncItem {
+    uint32_t round;
+    uint32_t block;
+    uint32_t n_blocks;
+    uint32_t flags;
+    uint64_t prov;
+};
+
+inline uint64_t enc_slot_bytes(uint32_t n) { return ((HDR_ROOM + 16 + (uint64_t)n + (n >> 2) + 64) + 15) & ~15ull; }
+
+struct EncodeArgs {
+    const EncItem *items;
+    uint32_t n_items;
+    uint32_t *cursor;
+    const uint8_t *src;
+    const uint64_t *src_off, *len;
+    uint8_t *prov;
+    uint32_t *seq_scratch;  // per resident wave: 3 * MAX_SEQ words
+    uint32_t *piece_len;
+    uint64_t *piece_start;  // offset in prov where the finished piece begins
+    const EncTables *tabs;
+};
+
+struct GatherArgs {
+    const EncItem *items;
+    uint32_t n_pieces;
+    const uint32_t *piece_len;
+    const uint64_t *piece_start;
+    const uint64_t *local_excl, *block_tot;
+    const uint8_t *prov, *src;
+    const uint64_t *src_off;
+    uint8_t *blob_out;
+    uint64_t blob_cap;
+    uint64_t *blob_offset, *blob_size, *total;
+    uint32_t *overflow;
+};
+
+void launch_encode(const EncodeArgs &a, int grid, hipStream_t s);
+void launch_piece_scan(const uint32_t *piece_len, uint32_t n, uint64_t *local_excl, uint64_t *block_tot, hipStream_t s);
+void launch_gather(const GatherArgs &g, hipStream_t s);
+void build_encode_tables(EncTables *t);
+
+}  // namespace zn

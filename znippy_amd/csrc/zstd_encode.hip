@@ -1,0 +1,411 @@
+// Zstandard frame encoder for CDNA4 (gfx950) — the GPU side of CompressCtx::compress_into
+// (znippy-common/src/codec.rs:L43-55) as called from the write worker loops
+// (znippy-compress/src/stream_packer.rs:L217-246, slot_packer.rs:L551-580).
+//
+// Not a port of libzstd: the unit of work is one <=128 KiB zstd block of one Round, handled by
+// one wavefront that pulls blocks from an atomic cursor.  Match finding is a greedy LZ over a
+// per-wave LDS hash table probed 64 positions at a time (lane = position); a found match is
+// extended 1 KiB per step by the whole wave.  Literals go out raw, sequences are FSE-coded
+// with the RFC 8878 predefined distributions (no table description, no repeat offsets), so every
+// block is self-contained and blocks of one frame are encoded in parallel.  A block that does
+// not shrink is emitted as a raw block.  Output pieces land in a provisional area; a scan +
+// gather pass packs them back-to-back in Round order (the writer's running out_cursor,
+// stream_packer.rs:L258, made deterministic).
+#include "common.h"
+#include "encode.h"
+
+namespace zn {
+
+constexpr uint32_t HASH_LOG = 12;
+constexpr uint32_t HASH_SIZE = 1u << HASH_LOG;
+constexpr uint32_t MIN_MATCH = 4;
+
+__device__ __forceinline__ uint32_t ld32(const uint8_t *p) {
+    uint32_t v;
+    __builtin_memcpy(&v, p, 4);
+    return v;
+}
+__device__ __forceinline__ uint4 ld128(const uint8_t *p) {
+    uint4 v;
+    __builtin_memcpy(&v, p, 16);
+    return v;
+}
+__device__ __forceinline__ uint32_t hash4(uint32_t v) { return (v * 2654435761u) >> (32 - HASH_LOG); }
+__device__ __forceinline__ int hib(uint32_t v) { return 31 - __clz(v); }
+
+__constant__ uint8_t c_ll_code[64] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15,
+                                      16, 16, 17, 17, 18, 18, 19, 19, 20, 20, 20, 20, 21, 21, 21, 21,
+                                      22, 22, 22, 22, 22, 22, 22, 22, 23, 23, 23, 23, 23, 23, 23, 23,
+                                      24, 24, 24, 24, 24, 24, 24, 24, 24, 24, 24, 24, 24, 24, 24, 24};
+__constant__ uint8_t c_ml_code[128] = {
+    0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 30, 31,
+    32, 32, 33, 33, 34, 34, 35, 35, 36, 36, 36, 36, 37, 37, 37, 37, 38, 38, 38, 38, 38, 38, 38, 38, 39, 39, 39, 39, 39, 39, 39, 39,
+    40, 40, 40, 40, 40, 40, 40, 40, 40, 40, 40, 40, 40, 40, 40, 40, 41, 41, 41, 41, 41, 41, 41, 41, 41, 41, 41, 41, 41, 41, 41, 41,
+    42, 42, 42, 42, 42, 42, 42, 42, 42, 42, 42, 42, 42, 42, 42, 42, 42, 42, 42, 42, 42, 42, 42, 42, 42, 42, 42, 42, 42, 42, 42, 42};
+__constant__ uint32_t c_ll_base_e[36] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 18,
+                                         20, 22, 24, 28, 32, 40, 48, 64, 128, 256, 512, 1024, 2048,
+                                         4096, 8192, 16384, 32768, 65536};
+__constant__ uint8_t c_ll_bits_e[36] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 1,
+                                        1, 1, 2, 2, 3, 3, 4, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16};
+__constant__ uint32_t c_ml_base_e[53] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20,
+                                         21, 22, 23, 24, 25, 26, 27, 28, 29, 30, 31, 32, 33, 34, 35, 37,
+                                         39, 41, 43, 47, 51, 59, 67, 83, 99, 131, 259, 515, 1027, 2051,
+                                         4099, 8195, 16387, 32771, 65539};
+__constant__ uint8_t c_ml_bits_e[53] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0,
+                                        0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 1,
+                                        1, 1, 2, 2, 3, 3, 4, 4, 5, 7, 8, 9, 10, 11,
+                                        12, 13, 14, 15, 16};
+
+// forward bit writer (lane 0): LSB-first accumulate, flushed 4 bytes at a time
+struct BitW {
+    uint8_t *p;
+    uint64_t acc;
+    uint32_t n;
+    __device__ __forceinline__ void add(uint32_t v, uint32_t nb) {
+        acc |= (uint64_t)(v & ((nb >= 32) ? 0xFFFFFFFFu : ((1u << nb) - 1))) << n;
+        n += nb;
+        if (n >= 32) {
+            uint32_t w = (uint32_t)acc;
+            __builtin_memcpy(p, &w, 4);
+            p += 4;
+            acc >>= 32;
+            n -= 32;
+        }
+    }
+    __device__ __forceinline__ uint8_t *close() {
+        add(1, 1);
+        while (n > 0) {
+            *p++ = (uint8_t)acc;
+            acc >>= 8;
+            n = n > 8 ? n - 8 : 0;
+        }
+        return p;
+    }
+};
+
+struct CState {
+    uint32_t v;
+    const uint16_t *st;
+    const FseSymTT *tt;
+    uint32_t log;
+    __device__ __forceinline__ void init(const uint16_t *st_, const FseSymTT *tt_, uint32_t log_, uint32_t sym) {
+        st = st_; tt = tt_; log = log_;
+        const FseSymTT t = tt[sym];
+        uint32_t nb = (t.delta_nb_bits + (1u << 15)) >> 16;
+        uint32_t val = (nb << 16) - t.delta_nb_bits;
+        v = st[(int32_t)(val >> nb) + t.delta_find_state];
+    }
+    __device__ __forceinline__ void encode(BitW &b, uint32_t sym) {
+        const FseSymTT t = tt[sym];
+        uint32_t nb = (v + t.delta_nb_bits) >> 16;
+        b.add(v, nb);
+        v = st[(int32_t)(v >> nb) + t.delta_find_state];
+    }
+    __device__ __forceinline__ void flush(BitW &b) { b.add(v, log); }
+};
+
+struct EncShared {
+    uint16_t table[HASH_SIZE];
+};
+
+// n bytes src -> dst by one wave (ranges do not overlap)
+__device__ __forceinline__ void wave_copy(uint8_t *dst, const uint8_t *src, uint32_t n, uint32_t lane) {
+    if (n < 128) {
+        for (uint32_t i = lane; i < n; i += 64) dst[i] = src[i];
+        return;
+    }
+    const uint32_t head = (uint32_t)((16 - ((uintptr_t)dst & 15)) & 15);
+    if (lane < head) dst[lane] = src[lane];
+    const uint32_t body = (n - head) >> 4;
+    for (uint32_t i = lane; i < body; i += 64) {
+        uint4 v = ld128(src + head + (size_t)i * 16);
+        *reinterpret_cast<uint4 *>(dst + head + (size_t)i * 16) = v;
+    }
+    const uint32_t done = head + body * 16;
+    if (done + lane < n) dst[done + lane] = src[done + lane];
+}
+
+// One wave encodes one block item pulled from the atomic cursor.
+__global__ __launch_bounds__(64) void k_zstd_encode(EncodeArgs a) {
+    __shared__ EncShared S;
+    __shared__ uint32_t s_item, s_raw;
+    const uint32_t lane = threadIdx.x;
+    uint32_t *const seqs = a.seq_scratch + (size_t)blockIdx.x * MAX_SEQ * 3;  // {ll, ml-3, offset} per sequence
+
+    for (;;) {
+        __syncthreads();
+        if (lane == 0) s_item = atomicAdd(a.cursor, 1u);
+        __syncthreads();
+        const uint32_t item = s_item;
+        if (item >= a.n_items) break;
+        const EncItem it = a.items[item];
+        if (it.flags & ITEM_SKIP) continue;  // store path: the gather pass copies it from the staging buffer
+        const uint64_t rlen = a.len[it.round];
+        const uint8_t *const rsrc = a.src + a.src_off[it.round];
+        const uint64_t boff = (uint64_t)it.block * BLOCK_BYTES;
+        const uint32_t n = (uint32_t)((rlen - boff) < BLOCK_BYTES ? (rlen - boff) : BLOCK_BYTES);
+        const uint8_t *const in = rsrc + boff;
+        const bool last = it.block + 1 == it.n_blocks;
+        uint8_t *const blk = a.prov + it.prov + HDR_ROOM;  // block header goes here
+        uint8_t *const lits = blk + 3 + 3;                 // literals after a 3-byte literals header
+        const uint32_t max_seq = (n / 40) < MAX_SEQ ? (n / 40) : MAX_SEQ;
+
+        // ---- match finding ----
+        for (uint32_t i = lane; i < HASH_SIZE; i += 64) S.table[i] = 0xFFFF;
+        __syncthreads();
+        uint32_t nseq = 0, lit_total = 0;
+        uint32_t anchor = 0;  // first byte not yet emitted
+        uint32_t base = 0, misses = 0;
+        const uint32_t scan_end = n >= 8 ? n - 7 : 0;  // positions with >= 8 bytes ahead
+        while (base < scan_end && nseq < max_seq) {
+            const uint32_t pos = base + lane;
+            uint32_t cand = 0, hitf = 0;
+            if (pos < scan_end) {
+                const uint32_t v = ld32(in + pos);
+                const uint32_t h = hash4(v);
+                const uint32_t e = S.table[h];
+                S.table[h] = (uint16_t)pos;  // low 16 bits; candidates are within 64 KiB
+                if (e != 0xFFFF) {
+                    uint32_t c = (pos & ~0xFFFFu) | e;
+                    if (c >= pos) c -= 0x10000u;  // wraps to a huge value when there is no earlier half
+                    if (c < pos && ld32(in + c) == v) { cand = c; hitf = 1; }
+                }
+            }
+            const uint64_t hit = __ballot(hitf != 0);
+            if (!hit) {
+                misses++;
+                base += 64 * (1 + (misses >> 4 > 7 ? 7 : misses >> 4));  // accelerate through incompressible data
+                continue;
+            }
+            misses = 0;
+            const uint32_t win = __ffsll((unsigned long long)hit) - 1;
+            const uint32_t mpos = __shfl(pos, win), mcand = __shfl(cand, win);
+            // cooperative extension: 16 bytes per lane, 1 KiB per step
+            uint32_t ml = 4;
+            for (;;) {
+                const uint32_t o = ml + lane * 16;
+                uint32_t good = 0;  // matching bytes in my 16-byte piece
+                if (mpos + o + 16 <= n) {
+                    uint4 x = ld128(in + mpos + o), y = ld128(in + mcand + o);
+                    uint32_t d0 = x.x ^ y.x, d1 = x.y ^ y.y, d2 = x.z ^ y.z, d3 = x.w ^ y.w;
+                    if (d0) good = (__ffs(d0) - 1) >> 3;
+                    else if (d1) good = 4 + ((__ffs(d1) - 1) >> 3);
+                    else if (d2) good = 8 + ((__ffs(d2) - 1) >> 3);
+                    else if (d3) good = 12 + ((__ffs(d3) - 1) >> 3);
+                    else good = 16;
+                } else {
+                    while (good < 16 && mpos + o + good < n && in[mpos + o + good] == in[mcand + o + good]) good++;
+                }
+                const uint64_t partial = __ballot(good != 16);
+                if (partial) {
+                    const uint32_t fl = __ffsll((unsigned long long)partial) - 1;
+                    ml += fl * 16 + __shfl(good, fl);
+                    break;
+                }
+                ml += 1024;
+            }
+            // emit: literals [anchor, mpos) then the match
+            const uint32_t ll = mpos - anchor;
+            wave_copy(lits + lit_total, in + anchor, ll, lane);
+            if (lane == 0) {
+                seqs[3 * nseq] = ll;
+                seqs[3 * nseq + 1] = ml - 3;
+                seqs[3 * nseq + 2] = mpos - mcand;
+            }
+            lit_total += ll;
+            nseq++;
+            anchor = mpos + ml;
+            base = anchor;
+        }
+        // trailing literals
+        wave_copy(lits + lit_total, in + anchor, n - anchor, lane);
+        lit_total += n - anchor;
+        __syncthreads();  // sequences + literal bytes of all lanes are visible to lane 0
+
+        // ---- entropy stage (lane 0) ----
+        if (lane == 0) {
+            uint32_t piece_len = 0, hdr_len = 0;
+            uint8_t *p = lits + lit_total;
+            bool raw = nseq == 0;
+            if (!raw) {
+                // literals header: Raw_Literals_Block, size_format 3 (20-bit size, 3 bytes)
+                blk[3] = (uint8_t)(0 | (3 << 2) | ((lit_total & 15) << 4));
+                blk[4] = (uint8_t)(lit_total >> 4);
+                blk[5] = (uint8_t)(lit_total >> 12);
+                if (nseq < 128) *p++ = (uint8_t)nseq;
+                else if (nseq < 0x7F00) { *p++ = (uint8_t)((nseq >> 8) + 128); *p++ = (uint8_t)nseq; }
+                else { *p++ = 255; *p++ = (uint8_t)(nseq - 0x7F00); *p++ = (uint8_t)((nseq - 0x7F00) >> 8); }
+                *p++ = 0;  // LL, OF, ML all Predefined_Mode
+                BitW b{p, 0, 0};
+                CState sl, so, sm;
+                for (int32_t i = (int32_t)nseq - 1; i >= 0; i--) {
+                    const uint32_t ll = seqs[3 * i], mlb = seqs[3 * i + 1], ov = seqs[3 * i + 2] + 3;
+                    const uint32_t lc = ll < 64 ? c_ll_code[ll] : (uint32_t)hib(ll) + 19;
+                    const uint32_t mc = mlb < 128 ? c_ml_code[mlb] : (uint32_t)hib(mlb) + 36;
+                    const uint32_t oc = (uint32_t)hib(ov);
+                    if (i == (int32_t)nseq - 1) {
+                        sm.init(a.tabs->ml_state, a.tabs->ml_tt, 6, mc);
+                        so.init(a.tabs->of_state, a.tabs->of_tt, 5, oc);
+                        sl.init(a.tabs->ll_state, a.tabs->ll_tt, 6, lc);
+                    } else {
+                        so.encode(b, oc);
+                        sm.encode(b, mc);
+                        sl.encode(b, lc);
+                    }
+                    b.add(ll - c_ll_base_e[lc], c_ll_bits_e[lc]);
+                    b.add(mlb + 3 - c_ml_base_e[mc], c_ml_bits_e[mc]);
+                    b.add(ov - (1u << oc), oc);
+                }
+                sm.flush(b);
+                so.flush(b);
+                sl.flush(b);
+                p = b.close();
+                const uint32_t csize = (uint32_t)(p - (blk + 3));
+                if (csize >= n) raw = true;
+                else {
+                    const uint32_t bh = (last ? 1u : 0u) | (2u << 1) | (csize << 3);
+                    blk[0] = (uint8_t)bh; blk[1] = (uint8_t)(bh >> 8); blk[2] = (uint8_t)(bh >> 16);
+                    piece_len = 3 + csize;
+                }
+            }
+            if (raw) {
+                const uint32_t bh = (last ? 1u : 0u) | (0u << 1) | (n << 3);
+                blk[0] = (uint8_t)bh; blk[1] = (uint8_t)(bh >> 8); blk[2] = (uint8_t)(bh >> 16);
+                piece_len = 3 + n;
+            }
+            if (it.block == 0) {  // frame header in front of block 0: magic, FHD (single segment), FCS
+                uint8_t h[16];
+                uint32_t k = 0;
+                h[k++] = 0x28; h[k++] = 0xB5; h[k++] = 0x2F; h[k++] = 0xFD;
+                if (rlen < 256) { h[k++] = 0x20; h[k++] = (uint8_t)rlen; }
+                else if (rlen < 65792) { h[k++] = 0x60; uint32_t v = (uint32_t)rlen - 256; h[k++] = (uint8_t)v; h[k++] = (uint8_t)(v >> 8); }
+                else if (rlen <= 0xFFFFFFFFull) { h[k++] = 0xA0; for (int i = 0; i < 4; i++) h[k++] = (uint8_t)(rlen >> (8 * i)); }
+                else { h[k++] = 0xE0; for (int i = 0; i < 8; i++) h[k++] = (uint8_t)(rlen >> (8 * i)); }
+                hdr_len = k;
+                for (uint32_t i = 0; i < k; i++) blk[(int32_t)i - (int32_t)k] = h[i];
+            }
+            s_raw = raw ? 1u : 0u;
+            a.piece_len[item] = piece_len + hdr_len;
+            a.piece_start[item] = it.prov + HDR_ROOM - hdr_len;
+        }
+        __syncthreads();
+        if (s_raw) wave_copy(blk + 3, in, n, lane);  // raw block: the input bytes after the header
+    }
+}
+
+// ---- piece scan + gather ---------------------------------------------------------------------
+// local exclusive scan of piece lengths inside blocks of 1024 pieces + block totals
+__global__ __launch_bounds__(1024) void k_piece_scan(const uint32_t *piece_len, uint32_t n, uint64_t *local_excl,
+                                                     uint64_t *block_tot) {
+    __shared__ uint64_t wsum[16];
+    const uint32_t i = blockIdx.x * 1024 + threadIdx.x, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    uint64_t v = i < n ? piece_len[i] : 0, inc = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        uint64_t y = __shfl_up(inc, d);
+        if (lane >= (uint32_t)d) inc += y;
+    }
+    if (lane == 63) wsum[w] = inc;
+    __syncthreads();
+    uint64_t wbase = 0;
+    for (uint32_t k = 0; k < w; k++) wbase += wsum[k];
+    if (i < n) local_excl[i] = wbase + inc - v;
+    if (threadIdx.x == 1023) block_tot[blockIdx.x] = wbase + inc;
+}
+
+// one wave per piece: copy it to its packed position; fill the per-round outputs
+__global__ __launch_bounds__(256) void k_gather(GatherArgs g) {
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t piece = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (piece >= g.n_pieces) return;
+    // base of my scan block = sum of the totals of the blocks before it
+    const uint32_t sb = piece >> 10;
+    uint64_t part = 0;
+    for (uint32_t k = lane; k < sb; k += 64) part += g.block_tot[k];
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) part += __shfl_xor(part, d);
+    const uint64_t off = part + g.local_excl[piece];
+    const uint32_t len = g.piece_len[piece];
+    const EncItem it = g.items[piece];
+    const uint8_t *s = (it.flags & ITEM_SKIP) ? g.src + g.src_off[it.round] + it.prov : g.prov + g.piece_start[piece];
+    uint8_t *d = g.blob_out + off;
+    if (off + len <= g.blob_cap) wave_copy(d, s, len, lane);
+    else if (lane == 0) atomicOr(g.overflow, 1u);
+    if (lane == 0) {
+        if (it.flags & ITEM_FIRST) g.blob_offset[it.round] = off;
+        atomicAdd(reinterpret_cast<unsigned long long *>(&g.blob_size[it.round]), (unsigned long long)len);
+        if (piece == g.n_pieces - 1) *g.total = off + len;
+    }
+}
+
+void launch_encode(const EncodeArgs &a, int grid, hipStream_t s) {
+    if (!a.n_items) return;
+    hipLaunchKernelGGL(k_zstd_encode, dim3(grid), dim3(64), 0, s, a);
+}
+
+void launch_piece_scan(const uint32_t *piece_len, uint32_t n, uint64_t *local_excl, uint64_t *block_tot, hipStream_t s) {
+    if (!n) return;
+    hipLaunchKernelGGL(k_piece_scan, dim3((n + 1023) / 1024), dim3(1024), 0, s, piece_len, n, local_excl, block_tot);
+}
+
+void launch_gather(const GatherArgs &g, hipStream_t s) {
+    if (!g.n_pieces) return;
+    hipLaunchKernelGGL(k_gather, dim3((g.n_pieces + 3) / 4), dim3(256), 0, s, g);
+}
+
+// ---- host: FSE encoding tables for the predefined distributions (RFC 8878 §3.1.1.3.2.2) ------
+static void build_ctable(const int8_t *norm, int nsym, int log, uint16_t *state_table, FseSymTT *tt) {
+    const int size = 1 << log;
+    std::vector<int> cumul(nsym + 2, 0);
+    std::vector<uint8_t> sym(size);
+    int high = size - 1;
+    for (int s = 0; s < nsym; s++) {
+        int c = norm[s] == -1 ? 1 : norm[s];
+        cumul[s + 1] = cumul[s] + c;
+        if (norm[s] == -1) sym[high--] = (uint8_t)s;
+    }
+    const int step = (size >> 1) + (size >> 3) + 3, mask = size - 1;
+    int pos = 0;
+    for (int s = 0; s < nsym; s++)
+        for (int i = 0; i < norm[s]; i++) {
+            sym[pos] = (uint8_t)s;
+            do { pos = (pos + step) & mask; } while (pos > high);
+        }
+    std::vector<int> cur(cumul.begin(), cumul.end());
+    for (int u = 0; u < size; u++) state_table[cur[sym[u]]++] = (uint16_t)(size + u);
+    int total = 0;
+    for (int s = 0; s < nsym; s++) {
+        int c = norm[s];
+        if (c == 0) {
+            tt[s].delta_nb_bits = ((uint32_t)(log + 1) << 16) - (1u << log);
+            tt[s].delta_find_state = 0;
+        } else if (c == -1 || c == 1) {
+            tt[s].delta_nb_bits = ((uint32_t)log << 16) - (1u << log);
+            tt[s].delta_find_state = total - 1;
+            total++;
+        } else {
+            int hb = 31 - __builtin_clz((unsigned)(c - 1));
+            uint32_t max_bits_out = (uint32_t)(log - hb);
+            uint32_t min_state_plus = (uint32_t)c << max_bits_out;
+            tt[s].delta_nb_bits = (max_bits_out << 16) - min_state_plus;
+            tt[s].delta_find_state = total - c;
+            total += c;
+        }
+    }
+}
+
+void build_encode_tables(EncTables *t) {
+    static const int8_t ll[36] = {4, 3, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 1, 1, 1, 2, 2,
+                                  2, 2, 2, 2, 2, 2, 2, 3, 2, 1, 1, 1, 1, 1, -1, -1, -1, -1};
+    static const int8_t ml[53] = {1, 4, 3, 2, 2, 2, 2, 2, 2, 1, 1, 1, 1, 1, 1, 1, 1, 1,
+                                  1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1,
+                                  1, 1, 1, 1, 1, 1, 1, 1, 1, 1, -1, -1, -1, -1, -1, -1, -1};
+    static const int8_t of[29] = {1, 1, 1, 1, 1, 1, 2, 2, 2, 1, 1, 1, 1, 1, 1,
+                                  1, 1, 1, 1, 1, 1, 1, 1, 1, -1, -1, -1, -1, -1};
+    memset(t, 0, sizeof *t);
+    build_ctable(ll, 36, 6, t->ll_state, t->ll_tt);
+    build_ctable(ml, 53, 6, t->ml_state, t->ml_tt);
+    build_ctable(of, 29, 5, t->of_state, t->of_tt);
+}
+
+}  // namespace zn
