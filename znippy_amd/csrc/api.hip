@@ -133,6 +133,10 @@ struct znippy_rows {
     uint64_t *counters = nullptr;  // 8 x u64
     uint64_t *corrupt = nullptr;
     uint32_t corrupt_cap = 0;
+    uint32_t *list_a = nullptr;   // compressed rows with > 64 leaves: general decoder
+    uint32_t n_list_a = 0;
+    uint32_t *pending = nullptr;  // rows the fused kernel hands over (+ its counter)
+    uint32_t *pending_count = nullptr;
     DevPlan plan;
 };
 
@@ -191,6 +195,7 @@ int znippy_ctx_create(int device, void *hip_stream, znippy_ctx **out) {
         if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return ZNIPPY_E_HIP; }
         ctx->own_stream = true;
     }
+    init_fused_tables();
     ctx->decode_grid = decode_grid_size(device);
     if (hipMalloc(&ctx->lit_scratch, decode_lit_scratch_bytes(ctx->decode_grid)) != hipSuccess ||
         hipMalloc(&ctx->cursor, 64) != hipSuccess) {
@@ -288,7 +293,7 @@ void znippy_rows_destroy(znippy_rows *r) {
     if (!r) return;
     (void)hipSetDevice(r->ctx->device);
     void *ptrs[] = {r->blob_off, r->blob_size, r->usize, r->out_off, r->compressed, r->checksum,
-                    r->status, r->digests, r->counters, r->corrupt};
+                    r->status, r->digests, r->counters, r->corrupt, r->list_a, r->pending, r->pending_count};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     free_plan(r->plan);
@@ -341,6 +346,19 @@ int znippy_rows_create(znippy_ctx *ctx, const uint64_t *blob_offset, const uint6
         znippy_rows_destroy(r);
         return rc;
     }
+    std::vector<uint32_t> la;
+    for (uint32_t i = 0; i < n; i++)
+        if (comp[i] && uncompressed_size[row_begin + i] > 64 * 1024) la.push_back(i);
+    r->n_list_a = (uint32_t)la.size();
+    if ((rc = dev_upload(ctx, &r->list_a, la.data(), la.size()))) {
+        znippy_rows_destroy(r);
+        return rc;
+    }
+    if (hipMalloc(&r->pending, std::max<size_t>(4 * (size_t)n, 16)) != hipSuccess ||
+        hipMalloc(&r->pending_count, 64) != hipSuccess) {
+        znippy_rows_destroy(r);
+        return ZNIPPY_E_NOMEM;
+    }
     *out = r;
     return ZNIPPY_OK;
 }
@@ -356,8 +374,31 @@ int znippy_decode_verify_rows_async(znippy_ctx *ctx, znippy_rows *r, const void 
     HIPCHK(ctx, hipMemsetAsync(r->counters, 0, 64, s));
     HIPCHK(ctx, hipMemsetAsync(ctx->cursor, 0, 64, s));
     if (!r->n) return ZNIPPY_OK;
+    HIPCHK(ctx, hipMemsetAsync(r->pending_count, 0, 64, s));
+    // 1) fused small-row kernel: decode simple frames + hash (+ copy stored rows), one wave per tile
+    HashArgs h{};
+    h.tiles = r->plan.tiles; h.n_tiles = r->plan.n_tiles;
+    h.len = r->usize;
+    h.srcA = (const uint8_t *)d_blobs; h.offA = r->blob_off; h.baseA = blob_base;
+    h.srcB = (uint8_t *)d_out; h.offB = r->out_off;
+    h.sel = r->compressed; h.status = r->status; h.pending_count = r->pending_count;
+    h.copy_to_B = 1;
+    h.digests = r->digests; h.tile_cv = r->plan.tile_cv;
+    {
+        FusedArgs f{};
+        f.h = h;
+        f.h.pass = 1;  // PASS_FUSED
+        f.blob_size = r->blob_size; f.out_cap = out_cap; f.status = r->status;
+        f.pending = r->pending; f.pending_count = r->pending_count;
+        ktime_begin(ctx, "decode_verify_fused");
+        launch_fused_small(f, s);
+        ktime_end(ctx);
+    }
+    // 2) general decoder: big compressed rows + whatever the fused kernel handed over
     if (r->n_compressed) {
         DecodeArgs a{};
+        a.list_a = r->list_a; a.n_list_a = r->n_list_a;
+        a.pending = r->pending; a.pending_count = r->pending_count;
         a.blobs = (const uint8_t *)d_blobs;
         a.blob_base = blob_base;
         a.blob_off = r->blob_off; a.blob_size = r->blob_size; a.usize = r->usize; a.out_off = r->out_off;
@@ -365,19 +406,13 @@ int znippy_decode_verify_rows_async(znippy_ctx *ctx, znippy_rows *r, const void 
         a.out = (uint8_t *)d_out; a.out_cap = out_cap;
         a.status = r->status; a.n_rows = r->n; a.cursor = ctx->cursor;
         a.lit_scratch = ctx->lit_scratch;
-        ktime_begin(ctx, "zstd_decode");
-        launch_decode(a, std::min<int>(ctx->decode_grid, (int)r->n), s);
+        ktime_begin(ctx, "zstd_decode_general");
+        launch_decode(a, std::min<int>(ctx->decode_grid, (int)r->n_compressed), s);
         ktime_end(ctx);
     }
-    HashArgs h{};
-    h.tiles = r->plan.tiles; h.n_tiles = r->plan.n_tiles;
-    h.len = r->usize;
-    h.srcA = (const uint8_t *)d_blobs; h.offA = r->blob_off; h.baseA = blob_base;
-    h.srcB = (uint8_t *)d_out; h.offB = r->out_off;
-    h.sel = r->compressed; h.status = r->status;
-    h.copy_to_B = 1;
-    h.digests = r->digests; h.tile_cv = r->plan.tile_cv;
-    ktime_begin(ctx, "blake3_tiles");
+    // 3) second hash pass: slices of big rows + rows the general decoder finished
+    h.pass = 2;  // PASS_SECOND
+    ktime_begin(ctx, "blake3_second_pass");
     launch_hash_tiles(h, s);
     ktime_end(ctx);
     if (r->plan.n_big) {
@@ -411,7 +446,11 @@ int znippy_rows_results(znippy_ctx *ctx, znippy_rows *r, znippy_verify_counters 
         std::sort(tmp.begin(), tmp.end());
         memcpy(corrupt_rows, tmp.data(), 8 * std::min<uint64_t>(k, corrupt_cap));
     }
-    if (row_status && r->n) HIPCHK(ctx, hipMemcpy(row_status, r->status, 4 * (size_t)r->n, hipMemcpyDeviceToHost));
+    if (row_status && r->n) {
+        HIPCHK(ctx, hipMemcpy(row_status, r->status, 4 * (size_t)r->n, hipMemcpyDeviceToHost));
+        for (uint32_t i = 0; i < r->n; i++)
+            if (row_status[i] > 0) row_status[i] = 0;  // internal routing states (1, 2) are successes
+    }
     return ZNIPPY_OK;
 }
 

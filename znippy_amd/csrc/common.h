@@ -43,13 +43,22 @@ struct HashArgs {
     uint8_t *srcB;
     const uint64_t *offB;
     const uint8_t *sel;
-    const int32_t *status;  // optional: units with status<0 are skipped (decode failed)
+    const int32_t *status;          // per-unit decode status (read side), see hash_dev.h PASS_*
+    const uint32_t *pending_count;  // rows handed to the general decoder (PASS_SECOND early-out)
+    int pass;
     int copy_to_B;
     uint32_t *digests;  // 8 words per unit
     uint32_t *tile_cv;  // 8 words per big-unit tile
 };
 
+// Row status values on the read side: 0 = done (stored row, or decoded+hashed by the fused
+// small-row kernel), 1 = handed to the general decoder, 2 = decoded by the general decoder
+// (still to be hashed by the second pass), < 0 = ZNIPPY_E_* (frame failed to decode).
 struct DecodeArgs {
+    const uint32_t *list_a;         // rows the host routes to the general decoder (big compressed rows)
+    uint32_t n_list_a;
+    const uint32_t *pending;        // rows the fused kernel could not handle
+    const uint32_t *pending_count;
     const uint8_t *blobs;
     uint64_t blob_base;
     const uint64_t *blob_off, *blob_size, *usize, *out_off;
@@ -63,7 +72,18 @@ struct DecodeArgs {
     uint32_t *seq_scratch;
 };
 
+struct FusedArgs {
+    HashArgs h;  // tiles, len (= usize), srcA = blobs, srcB = out, sel = compressed, status, digests
+    const uint64_t *blob_size;
+    uint64_t out_cap;
+    int32_t *status;
+    uint32_t *pending;
+    uint32_t *pending_count;
+};
+
 void launch_hash_tiles(const HashArgs &a, hipStream_t s);
+void launch_fused_small(const FusedArgs &a, hipStream_t s);
+void init_fused_tables();
 void launch_merge_big(const BigUnit *big, uint32_t n_big, uint32_t *tile_cv, uint32_t *digests, hipStream_t s);
 void launch_verify(const uint32_t *digests, const uint8_t *checksum, const uint64_t *usize,
                    const int32_t *status, uint32_t n_rows, uint64_t row_begin, uint64_t *counters,

@@ -1,0 +1,459 @@
+// Fused small-row read path for CDNA4 (gfx950): one wavefront takes one Tile (several whole
+// index rows, <= 64 BLAKE3 leaves in total), decodes every compressed row of the tile and then
+// hashes all the tile's leaves at once (lane = leaf) while the decoded bytes are still in the
+// XCD's L2 — the body of the reference's read worker loop (znippy-common/src/decompress.rs:L135-190)
+// for up to 64 KiB of output per wave, with no intermediate pass over HBM.
+//
+// The in-wave decoder handles "simple" zstd frames: raw/RLE blocks and compressed blocks whose
+// literals are raw/RLE and whose sequence tables are predefined/RLE (what this build's encoder
+// emits, and what libzstd emits for short or highly repetitive chunks).  Parsing is SCALAR:
+// the frame lives in one VGPR (lane = dword of a 256-byte window) and every header field /
+// bitstream read is a v_readlane + SALU shift, so no lane idles on a serial byte loop.
+// Overlapping LZ matches (offset < length, e.g. a 45-byte text period) are expanded once into
+// an LDS pattern buffer and streamed out 1 KiB per wave-instruction with aligned 16-byte stores.
+// Anything else (Huffman literals, FSE table descriptions) is handed to the general decoder
+// through the pending list and hashed by the second pass.
+#include "common.h"
+#include "hash_dev.h"
+
+#include <cstring>
+
+namespace zn {
+
+constexpr uint32_t EOFF_MAX = 2048;             // longest period expanded in LDS
+constexpr uint32_t EBUF = EOFF_MAX + 1024 + 64; // pattern buffer per wave
+constexpr int F_E_CORRUPT = -5, F_E_UNSUP = -6, F_E_DST = -4;
+constexpr int F_NOT_SIMPLE = 1;
+
+struct DTab {
+    uint16_t next;
+    uint8_t nbits, addbits;
+    uint32_t base;
+};
+__constant__ DTab c_dll[64], c_dml[64], c_dof[32];
+__constant__ uint32_t c_llb[36] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 18,
+                                   20, 22, 24, 28, 32, 40, 48, 64, 128, 256, 512, 1024, 2048,
+                                   4096, 8192, 16384, 32768, 65536};
+__constant__ uint8_t c_lla[36] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 1,
+                                  1, 1, 2, 2, 3, 3, 4, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16};
+__constant__ uint32_t c_mlb[53] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20,
+                                   21, 22, 23, 24, 25, 26, 27, 28, 29, 30, 31, 32, 33, 34, 35, 37,
+                                   39, 41, 43, 47, 51, 59, 67, 83, 99, 131, 259, 515, 1027, 2051,
+                                   4099, 8195, 16387, 32771, 65539};
+__constant__ uint8_t c_mla[53] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0,
+                                  0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 1,
+                                  1, 1, 2, 2, 3, 3, 4, 4, 5, 7, 8, 9, 10, 11,
+                                  12, 13, 14, 15, 16};
+
+// ---- host: decoding tables of the predefined distributions -> __constant__ -----------------------
+static void host_fse_build(const int8_t *norm, int nsym, int log, int kind, DTab *t) {
+    static const uint32_t llb[36] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 18,
+                                     20, 22, 24, 28, 32, 40, 48, 64, 128, 256, 512, 1024, 2048,
+                                     4096, 8192, 16384, 32768, 65536};
+    static const uint8_t lla[36] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 1,
+                                    1, 1, 2, 2, 3, 3, 4, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16};
+    static const uint32_t mlb[53] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20,
+                                     21, 22, 23, 24, 25, 26, 27, 28, 29, 30, 31, 32, 33, 34, 35, 37,
+                                     39, 41, 43, 47, 51, 59, 67, 83, 99, 131, 259, 515, 1027, 2051,
+                                     4099, 8195, 16387, 32771, 65539};
+    static const uint8_t mla[53] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0,
+                                    0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 1,
+                                    1, 1, 2, 2, 3, 3, 4, 4, 5, 7, 8, 9, 10, 11,
+                                    12, 13, 14, 15, 16};
+    const int size = 1 << log;
+    uint8_t sym[512];
+    uint16_t next[64];
+    int high = size;
+    for (int s = 0; s < nsym; s++)
+        if (norm[s] == -1) { sym[--high] = (uint8_t)s; next[s] = 1; }
+    const int step = (size >> 1) + (size >> 3) + 3, mask = size - 1;
+    int pos = 0;
+    for (int s = 0; s < nsym; s++) {
+        if (norm[s] <= 0) continue;
+        next[s] = (uint16_t)norm[s];
+        for (int i = 0; i < norm[s]; i++) {
+            sym[pos] = (uint8_t)s;
+            do { pos = (pos + step) & mask; } while (pos >= high);
+        }
+    }
+    for (int i = 0; i < size; i++) {
+        uint32_t s = sym[i], ns = next[s]++;
+        int nb = log - (31 - __builtin_clz(ns));
+        t[i].next = (uint16_t)((ns << nb) - size);
+        t[i].nbits = (uint8_t)nb;
+        if (kind == 0) { t[i].base = llb[s]; t[i].addbits = lla[s]; }
+        else if (kind == 2) { t[i].base = mlb[s]; t[i].addbits = mla[s]; }
+        else { t[i].base = 1u << s; t[i].addbits = (uint8_t)s; }
+    }
+}
+
+void init_fused_tables() {
+    static const int8_t ll[36] = {4, 3, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 1, 1, 1, 2, 2,
+                                  2, 2, 2, 2, 2, 2, 2, 3, 2, 1, 1, 1, 1, 1, -1, -1, -1, -1};
+    static const int8_t ml[53] = {1, 4, 3, 2, 2, 2, 2, 2, 2, 1, 1, 1, 1, 1, 1, 1, 1, 1,
+                                  1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1,
+                                  1, 1, 1, 1, 1, 1, 1, 1, 1, 1, -1, -1, -1, -1, -1, -1, -1};
+    static const int8_t of[29] = {1, 1, 1, 1, 1, 1, 2, 2, 2, 1, 1, 1, 1, 1, 1,
+                                  1, 1, 1, 1, 1, 1, 1, 1, 1, -1, -1, -1, -1, -1};
+    DTab tl[64], tm[64], to[32];
+    host_fse_build(ll, 36, 6, 0, tl);
+    host_fse_build(ml, 53, 6, 2, tm);
+    host_fse_build(of, 29, 5, 1, to);
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(c_dll), tl, sizeof tl);
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(c_dml), tm, sizeof tm);
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(c_dof), to, sizeof to);
+}
+
+// ---- device helpers ---------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t uni(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ int fhib(uint32_t v) { return 31 - __clz(v); }
+__device__ __forceinline__ void fwave_mem_sync() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+// 256-byte window of the frame held across the wave: lane l keeps bytes [wbase+4l, wbase+4l+4).
+struct FrameWin {
+    const uint8_t *src;
+    uint32_t n, wbase, w;
+    __device__ __forceinline__ void load(uint32_t base) {
+        const uint32_t lane = threadIdx.x & 63;
+        wbase = base;
+        const uint32_t o = base + 4 * lane;
+        uint32_t v = 0;
+        if (o + 4 <= n) __builtin_memcpy(&v, src + o, 4);
+        else
+            for (uint32_t k = 0; k < 4; k++)
+                if (o + k < n) v |= (uint32_t)src[o + k] << (8 * k);
+        w = v;
+    }
+    // 8 bytes at byte position pos (wave-uniform), zero past the end of the frame
+    __device__ __forceinline__ uint64_t u64(uint32_t pos) {
+        const uint32_t rel = pos - wbase, idx = rel >> 2, sh = (rel & 3) * 8;
+        const uint32_t d0 = __builtin_amdgcn_readlane(w, idx), d1 = __builtin_amdgcn_readlane(w, idx + 1),
+                       d2 = __builtin_amdgcn_readlane(w, idx + 2);
+        uint64_t lo = (uint64_t)d0 | ((uint64_t)d1 << 32);
+        return sh ? (lo >> sh) | ((uint64_t)d2 << (64 - sh)) : lo;
+    }
+    __device__ __forceinline__ uint64_t fwd(uint32_t pos) {
+        if (pos < wbase || pos + 12 > wbase + 256) load(pos);
+        return u64(pos);
+    }
+    __device__ __forceinline__ uint64_t bwd(uint32_t pos) {
+        if (pos < wbase || pos + 12 > wbase + 256) load(pos >= 240 ? pos - 240 : 0);
+        return u64(pos);
+    }
+};
+
+// backward bit reader over frame bytes [s_begin, ...): bp = unread bits
+struct SBits {
+    uint32_t s_begin;
+    int32_t bp;
+    __device__ __forceinline__ uint32_t read(FrameWin &W, uint32_t nb) {  // nb <= 32, scalar
+        if (nb == 0) return 0;
+        uint32_t v;
+        if (bp <= 0) v = 0;
+        else {
+            const uint32_t take = (uint32_t)bp < nb ? (uint32_t)bp : nb;  // real bits available
+            const uint32_t lo_bit = (uint32_t)bp - take;
+            const uint64_t x = W.bwd(s_begin + (lo_bit >> 3)) >> (lo_bit & 7);
+            v = (uint32_t)(x & ((1ull << take) - 1)) << (nb - take);
+        }
+        bp -= (int32_t)nb;
+        return v;
+    }
+};
+
+__device__ __forceinline__ void fwave_copy(uint8_t *dst, const uint8_t *src, uint32_t n, uint32_t lane) {
+    if (n < 128) {
+        for (uint32_t i = lane; i < n; i += 64) dst[i] = src[i];
+        return;
+    }
+    const uint32_t head = (uint32_t)((16 - ((uintptr_t)dst & 15)) & 15);
+    if (lane < head) dst[lane] = src[lane];
+    const uint32_t body = (n - head) >> 4;
+    for (uint32_t i = lane; i < body; i += 64) {
+        uint4 v = ld16(src + head + (size_t)i * 16);
+        *reinterpret_cast<uint4 *>(dst + head + (size_t)i * 16) = v;
+    }
+    const uint32_t done = head + body * 16;
+    if (done + lane < n) dst[done + lane] = src[done + lane];
+}
+
+__device__ __forceinline__ void fwave_fill(uint8_t *dst, uint8_t byte, uint32_t n, uint32_t lane) {
+    if (n < 128) {
+        for (uint32_t i = lane; i < n; i += 64) dst[i] = byte;
+        return;
+    }
+    const uint32_t head = (uint32_t)((16 - ((uintptr_t)dst & 15)) & 15);
+    if (lane < head) dst[lane] = byte;
+    const uint32_t body = (n - head) >> 4;
+    const uint32_t w = byte * 0x01010101u;
+    const uint4 v = make_uint4(w, w, w, w);
+    for (uint32_t i = lane; i < body; i += 64) *reinterpret_cast<uint4 *>(dst + head + (size_t)i * 16) = v;
+    const uint32_t done = head + body * 16;
+    if (done + lane < n) dst[done + lane] = byte;
+}
+
+// dst[i] = pat[i % off], i < ml.  `pat` points at `off` bytes that are final (read-only frame
+// literals, or output already drained with fwave_mem_sync).  E = this wave's LDS pattern buffer.
+__device__ __forceinline__ void fwave_match(uint8_t *dst, const uint8_t *pat, uint32_t off, uint32_t ml, uint8_t *E,
+                                            uint32_t lane) {
+    if (off >= ml) {
+        fwave_copy(dst, pat, ml, lane);
+        return;
+    }
+    if (ml <= 256 || off > EOFF_MAX) {
+        for (uint32_t i = lane; i < ml; i += 64) dst[i] = pat[i % off];
+        return;
+    }
+    // E[i] = pat[i % off] for i < off + 1024, by doubling inside LDS (ds ops of one wave are ordered)
+    for (uint32_t i = lane; i < off; i += 64) E[i] = pat[i];
+    const uint32_t need = off + 1024;
+    uint32_t w = off;
+    while (w < need) {
+        const uint32_t c = w < need - w ? w : need - w;
+        for (uint32_t i = lane * 16; i < c; i += 1024) {
+            if (i + 16 <= c) {
+                uint4 v;
+                __builtin_memcpy(&v, E + i, 16);
+                __builtin_memcpy(E + w + i, &v, 16);
+            } else {
+                for (uint32_t k = i; k < c; k++) E[w + k] = E[k];
+            }
+        }
+        w += c;
+    }
+    const uint32_t head = (uint32_t)((16 - ((uintptr_t)dst & 15)) & 15);
+    if (lane < head) dst[lane] = E[lane];
+    uint32_t x = head, s = head % off;
+    const uint32_t step = 1024 % off;
+    while (x + 1024 <= ml) {
+        uint4 v;
+        __builtin_memcpy(&v, E + s + 16 * lane, 16);
+        *reinterpret_cast<uint4 *>(dst + x + 16 * lane) = v;
+        x += 1024;
+        s += step;
+        if (s >= off) s -= off;
+    }
+    const uint32_t rem = ml - x;
+    if (16 * lane + 16 <= rem) {
+        uint4 v;
+        __builtin_memcpy(&v, E + s + 16 * lane, 16);
+        *reinterpret_cast<uint4 *>(dst + x + 16 * lane) = v;
+    } else if (16 * lane < rem) {
+        for (uint32_t k = 16 * lane; k < rem; k++) dst[x + k] = E[s + k];
+    }
+}
+
+// Decode one simple frame with the calling wave.  Returns 0, F_NOT_SIMPLE or a negative error.
+__device__ int decode_simple(const uint8_t *src, uint32_t n, uint8_t *out, uint64_t usize, uint8_t *E) {
+    const uint32_t lane = threadIdx.x & 63;
+    FrameWin W;
+    W.src = src; W.n = n;
+    W.load(0);
+    if (n < 5) return F_E_CORRUPT;
+    uint64_t h = W.fwd(0);
+    if ((uint32_t)h != 0xFD2FB528u) return F_E_CORRUPT;
+    const uint32_t fhd = (uint32_t)(h >> 32) & 0xFF;
+    const uint32_t fcs_flag = fhd >> 6, single = (fhd >> 5) & 1, did_flag = fhd & 3;
+    if (fhd & 8) return F_E_CORRUPT;
+    const uint32_t has_ck = (fhd >> 2) & 1;
+    const uint32_t fcs_bytes = fcs_flag == 0 ? single : (1u << fcs_flag);
+    const uint32_t did_bytes = did_flag == 3 ? 4 : did_flag;
+    uint32_t pos = 5 + (single ? 0 : 1);
+    if (n < pos + did_bytes + fcs_bytes) return F_E_CORRUPT;
+    if (did_bytes) {
+        uint32_t did = (uint32_t)(W.fwd(pos) & (did_bytes == 4 ? 0xFFFFFFFFull : ((1ull << (8 * did_bytes)) - 1)));
+        if (did) return F_E_UNSUP;
+        pos += did_bytes;
+    }
+    if (!fcs_bytes) return F_E_UNSUP;
+    uint64_t fcs = W.fwd(pos);
+    if (fcs_bytes < 8) fcs &= (1ull << (8 * fcs_bytes)) - 1;
+    if (fcs_bytes == 2) fcs += 256;
+    pos += fcs_bytes;
+    if (fcs != usize) return F_E_CORRUPT;
+
+    uint32_t opos = 0;
+    uint32_t r0 = 1, r1 = 4, r2 = 8;
+    const uint32_t osize = (uint32_t)usize;  // small rows only (<= 64 KiB)
+    for (;;) {
+        if (pos + 3 > n) return F_E_CORRUPT;
+        const uint32_t bh = (uint32_t)W.fwd(pos) & 0xFFFFFF;
+        pos += 3;
+        const uint32_t last = bh & 1, btype = (bh >> 1) & 3, bsize = bh >> 3;
+        if (btype == 3) return F_E_CORRUPT;
+        if (btype == 0) {
+            if (pos + bsize > n || opos + bsize > osize) return F_E_CORRUPT;
+            fwave_copy(out + opos, src + pos, bsize, lane);
+            opos += bsize; pos += bsize;
+        } else if (btype == 1) {
+            if (pos + 1 > n || opos + bsize > osize) return F_E_CORRUPT;
+            fwave_fill(out + opos, (uint8_t)(W.fwd(pos) & 0xFF), bsize, lane);
+            opos += bsize; pos += 1;
+        } else {
+            if (pos + bsize > n || bsize > 128 * 1024 || bsize < 2) return F_E_CORRUPT;
+            const uint32_t bend = pos + bsize;
+            // literals section: raw or RLE only
+            const uint32_t lh = (uint32_t)W.fwd(pos);
+            const uint32_t ltype = lh & 3, sf = (lh >> 2) & 3;
+            if (ltype >= 2) return F_NOT_SIMPLE;
+            uint32_t regen, lhdr;
+            if ((sf & 1) == 0) { regen = (lh & 0xFF) >> 3; lhdr = 1; }
+            else if (sf == 1) { regen = (lh & 0xFFFF) >> 4; lhdr = 2; }
+            else { regen = (lh & 0xFFFFFF) >> 4; lhdr = 3; }
+            uint32_t lit_at;   // frame position of raw literals
+            uint32_t rle_byte = 0;
+            pos += lhdr;
+            if (ltype == 0) {
+                if (pos + regen > bend) return F_E_CORRUPT;
+                lit_at = pos;
+                pos += regen;
+            } else {
+                if (pos + 1 > bend) return F_E_CORRUPT;
+                rle_byte = (uint32_t)W.fwd(pos) & 0xFF;
+                lit_at = 0;
+                pos += 1;
+            }
+            // sequences header
+            if (pos >= bend) return F_E_CORRUPT;
+            const uint32_t sh = (uint32_t)W.fwd(pos);
+            uint32_t nseq;
+            const uint32_t b0 = sh & 0xFF;
+            if (b0 == 0) { nseq = 0; pos += 1; }
+            else if (b0 < 128) { nseq = b0; pos += 1; }
+            else if (b0 < 255) { nseq = ((b0 - 128) << 8) + ((sh >> 8) & 0xFF); pos += 2; }
+            else { nseq = ((sh >> 8) & 0xFFFF) + 0x7F00; pos += 3; }
+            uint32_t lit_pos = 0;
+            if (nseq) {
+                if (pos >= bend) return F_E_CORRUPT;
+                const uint32_t modes = (uint32_t)W.fwd(pos) & 0xFF;
+                pos += 1;
+                if (modes & 3) return F_E_CORRUPT;
+                const uint32_t m_ll = (modes >> 6) & 3, m_of = (modes >> 4) & 3, m_ml = (modes >> 2) & 3;
+                if (m_ll > 1 || m_of > 1 || m_ml > 1) return F_NOT_SIMPLE;
+                uint32_t rl_base = 0, rl_add = 0, ro_base = 0, ro_add = 0, rm_base = 0, rm_add = 0;
+                if (m_ll) {
+                    if (pos >= bend) return F_E_CORRUPT;
+                    uint32_t s = (uint32_t)W.fwd(pos) & 0xFF; pos++;
+                    if (s > 35) return F_E_CORRUPT;
+                    rl_base = c_llb[s]; rl_add = c_lla[s];
+                }
+                if (m_of) {
+                    if (pos >= bend) return F_E_CORRUPT;
+                    uint32_t s = (uint32_t)W.fwd(pos) & 0xFF; pos++;
+                    if (s > 31) return F_E_CORRUPT;
+                    ro_base = 1u << s; ro_add = s;
+                }
+                if (m_ml) {
+                    if (pos >= bend) return F_E_CORRUPT;
+                    uint32_t s = (uint32_t)W.fwd(pos) & 0xFF; pos++;
+                    if (s > 52) return F_E_CORRUPT;
+                    rm_base = c_mlb[s]; rm_add = c_mla[s];
+                }
+                if (pos >= bend) return F_E_CORRUPT;
+                const uint32_t lastb = (uint32_t)W.bwd(bend - 1) & 0xFF;
+                if (!lastb) return F_E_CORRUPT;
+                SBits B;
+                B.s_begin = pos;
+                B.bp = (int32_t)((bend - pos) * 8 - (8 - fhib(lastb)));
+                uint32_t sl = m_ll ? 0 : B.read(W, 6);
+                uint32_t so = m_of ? 0 : B.read(W, 5);
+                uint32_t sm = m_ml ? 0 : B.read(W, 6);
+                for (uint32_t i = 0; i < nseq; i++) {
+                    uint32_t ob, oa, onx = 0, onb = 0, mb, ma, mnx = 0, mnb = 0, lb, la, lnx = 0, lnb = 0;
+                    if (m_of) { ob = ro_base; oa = ro_add; } else { const DTab e = c_dof[so]; ob = e.base; oa = e.addbits; onx = e.next; onb = e.nbits; }
+                    if (m_ml) { mb = rm_base; ma = rm_add; } else { const DTab e = c_dml[sm]; mb = e.base; ma = e.addbits; mnx = e.next; mnb = e.nbits; }
+                    if (m_ll) { lb = rl_base; la = rl_add; } else { const DTab e = c_dll[sl]; lb = e.base; la = e.addbits; lnx = e.next; lnb = e.nbits; }
+                    const uint32_t ov = ob + B.read(W, oa);
+                    const uint32_t ml = mb + B.read(W, ma);
+                    const uint32_t ll = lb + B.read(W, la);
+                    if (i + 1 < nseq) {
+                        sl = lnx + B.read(W, lnb);
+                        sm = mnx + B.read(W, mnb);
+                        so = onx + B.read(W, onb);
+                    }
+                    if (B.bp < 0) return F_E_CORRUPT;
+                    uint32_t offset;
+                    if (ov > 3) { offset = ov - 3; r2 = r1; r1 = r0; r0 = offset; }
+                    else {
+                        const uint32_t idx = ov - 1 + (ll == 0 ? 1 : 0);
+                        if (idx == 0) offset = r0;
+                        else {
+                            offset = idx == 1 ? r1 : (idx == 2 ? r2 : r0 - 1);
+                            if (offset == 0) return F_E_CORRUPT;
+                            if (idx > 1) r2 = r1;
+                            r1 = r0; r0 = offset;
+                        }
+                    }
+                    if (lit_pos + ll > regen) return F_E_CORRUPT;
+                    if ((uint64_t)opos + ll + ml > osize) return F_E_CORRUPT;
+                    // literals
+                    if (ll) {
+                        if (ltype == 0) fwave_copy(out + opos, src + lit_at + lit_pos, ll, lane);
+                        else fwave_fill(out + opos, (uint8_t)rle_byte, ll, lane);
+                    }
+                    opos += ll; lit_pos += ll;
+                    if (offset > opos) return F_E_CORRUPT;
+                    // match: the period is forwarded from the frame when it lies inside this literal run
+                    if (offset <= ll) {
+                        if (ltype == 0) fwave_match(out + opos, src + lit_at + lit_pos - offset, offset, ml, E, lane);
+                        else fwave_fill(out + opos, (uint8_t)rle_byte, ml, lane);
+                    } else {
+                        fwave_mem_sync();  // earlier output of this wave must have landed before it is re-read
+                        fwave_match(out + opos, out + opos - offset, offset, ml, E, lane);
+                    }
+                    opos += ml;
+                }
+                if (B.bp != 0) return F_E_CORRUPT;
+            } else if (pos != bend) {
+                return F_E_CORRUPT;
+            }
+            const uint32_t rest = regen - lit_pos;
+            if ((uint64_t)opos + rest > osize) return F_E_CORRUPT;
+            if (rest) {
+                if (ltype == 0) fwave_copy(out + opos, src + lit_at + lit_pos, rest, lane);
+                else fwave_fill(out + opos, (uint8_t)rle_byte, rest, lane);
+            }
+            opos += rest;
+            pos = bend;
+        }
+        if (last) break;
+    }
+    if (opos != osize) return F_E_CORRUPT;
+    if (has_ck && pos + 4 > n) return F_E_CORRUPT;
+    return 0;
+}
+
+__global__ __launch_bounds__(256) void k_fused_small(FusedArgs a) {
+    __shared__ __attribute__((aligned(16))) uint8_t s_E[4][EBUF];
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t wave = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (wave >= a.h.n_tiles) return;
+    const Tile t = a.h.tiles[wave];
+    if (t.n_units == 0) return;  // slices of big rows: general decoder + second hash pass
+    uint8_t *const E = s_E[threadIdx.x >> 6];
+
+    for (uint32_t u = 0; u < t.n_units; u++) {
+        const uint32_t row = t.first_unit + u;
+        if (!a.h.sel[row]) continue;  // stored row: copied while it is hashed below
+        const uint64_t usize = a.h.len[row];
+        const uint64_t ooff = a.h.offB[row];
+        int rc;
+        if (ooff + usize > a.out_cap) rc = F_E_DST;
+        else
+            rc = decode_simple(a.h.srcA + (a.h.offA[row] - a.h.baseA), (uint32_t)a.blob_size[row], a.h.srcB + ooff, usize, E);
+        rc = (int)uni((uint32_t)rc);
+        if (rc != 0 && lane == 0) {
+            a.status[row] = rc;
+            if (rc == F_NOT_SIMPLE) a.pending[atomicAdd(a.pending_count, 1u)] = row;
+        }
+    }
+    fwave_mem_sync();  // decoded bytes + status words have landed (same CU: visible to this wave's loads)
+    hash_tile<true>(a.h, t);
+}
+
+void launch_fused_small(const FusedArgs &a, hipStream_t s) {
+    if (!a.h.n_tiles) return;
+    hipLaunchKernelGGL(k_fused_small, dim3((a.h.n_tiles + 3) / 4), dim3(256), 0, s, a);
+}
+
+}  // namespace zn

@@ -1,0 +1,172 @@
+// Device-side body of the BLAKE3 tile hash (one wavefront = one Tile, lane = 1 KiB leaf),
+// shared by the standalone hash kernel (hash_kernels.hip) and the fused small-row
+// decode+hash kernel (fused_small.hip).
+#pragma once
+#include "common.h"
+#include "blake3_dev.h"
+
+namespace zn {
+
+__device__ __forceinline__ uint4 ld16(const uint8_t *p) {
+    uint4 v;
+    __builtin_memcpy(&v, p, 16);  // unaligned-access-mode: one global_load_dwordx4
+    return v;
+}
+__device__ __forceinline__ void st16(uint8_t *p, uint4 v) { __builtin_memcpy(p, &v, 16); }
+
+// Load one (possibly partial) 64-byte block into 16 little-endian words, zero padded.
+__device__ __forceinline__ void load_block(const uint8_t *p, uint32_t n, uint32_t m[16]) {
+    if (n == 64) {
+        uint4 a = ld16(p), b = ld16(p + 16), c = ld16(p + 32), d = ld16(p + 48);
+        m[0] = a.x; m[1] = a.y; m[2] = a.z; m[3] = a.w;
+        m[4] = b.x; m[5] = b.y; m[6] = b.z; m[7] = b.w;
+        m[8] = c.x; m[9] = c.y; m[10] = c.z; m[11] = c.w;
+        m[12] = d.x; m[13] = d.y; m[14] = d.z; m[15] = d.w;
+    } else {
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            uint32_t w = 0;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                uint32_t idx = 4 * i + k;
+                if (idx < n) w |= (uint32_t)p[idx] << (8 * k);
+            }
+            m[i] = w;
+        }
+    }
+}
+
+__device__ __forceinline__ void store_block(uint8_t *p, uint32_t n, const uint32_t m[16]) {
+    if (n == 64) {
+        st16(p, make_uint4(m[0], m[1], m[2], m[3]));
+        st16(p + 16, make_uint4(m[4], m[5], m[6], m[7]));
+        st16(p + 32, make_uint4(m[8], m[9], m[10], m[11]));
+        st16(p + 48, make_uint4(m[12], m[13], m[14], m[15]));
+    } else {
+        for (uint32_t i = 0; i < n; i++) p[i] = (uint8_t)(m[i >> 2] >> (8 * (i & 3)));
+    }
+}
+
+// Fold the CVs held by lanes [s, s+n) (one node per lane, node j in lane s+j) into lane s.
+// All 64 lanes call this together; lanes outside any segment pass n = 0.  `final_root`:
+// the fold ends at the unit's root (ROOT flag on the last parent).
+__device__ __forceinline__ void fold_segments(uint32_t cv[8], uint32_t s, uint32_t n, bool final_root) {
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t j = lane - s;
+    while (__ballot(n > 1) != 0ull) {
+        uint32_t li = (s + 2 * j) & 63, ri = (s + 2 * j + 1) & 63;
+        uint32_t L[8], R[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            L[i] = __shfl(cv[i], li);
+            R[i] = __shfl(cv[i], ri);
+        }
+        if (n > 1 && j < (n + 1) / 2) {
+            if (2 * j + 1 < n) b3::parent(cv, L, R, final_root && n == 2);
+            else {
+#pragma unroll
+                for (int i = 0; i < 8; i++) cv[i] = L[i];
+            }
+        }
+        if (n > 1) n = (n + 1) / 2;
+    }
+}
+
+// Which units of a tile a pass hashes (HashArgs::pass):
+//   PASS_ALL    no status array, hash everything (write side, hash-only)
+//   PASS_FUSED  small tiles only; a unit is hashed iff status == 0 (stored, or decoded by the fused path)
+//   PASS_SECOND big-unit slices (status >= 0) and small-tile units the general decoder finished (status == 2)
+enum { PASS_ALL = 0, PASS_FUSED = 1, PASS_SECOND = 2 };
+
+// Hash one tile with the calling wavefront.  Every lane of the wave must call it.
+template <bool COPY>
+__device__ __forceinline__ void hash_tile(const HashArgs &a, const Tile &t) {
+    const uint32_t lane = threadIdx.x & 63;
+    uint32_t unit, k, unit_leaves, seg_start;
+    bool active = lane < t.n_leaves;
+    if (t.n_units) {
+        uint32_t cnt = 0;
+        if (lane < t.n_units) {
+            uint64_t L = a.len[t.first_unit + lane];
+            cnt = L ? (uint32_t)((L + 1023) >> 10) : 1u;
+        }
+        uint32_t inc = cnt;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            uint32_t y = __shfl_up(inc, d);
+            if (lane >= (uint32_t)d) inc += y;
+        }
+        // smallest i with inc[i] > lane
+        uint32_t lo = 0, hi = t.n_units - 1;
+#pragma unroll
+        for (int it = 0; it < 6; it++) {
+            uint32_t mid = (lo + hi) >> 1;
+            uint32_t v = __shfl(inc, mid);
+            if (lo < hi) {
+                if (v > lane) hi = mid; else lo = mid + 1;
+            }
+        }
+        uint32_t i = lo;
+        unit_leaves = __shfl(cnt, i);
+        seg_start = __shfl(inc, i) - unit_leaves;
+        unit = t.first_unit + i;
+        k = lane - seg_start;
+    } else {
+        unit = t.first_unit;
+        k = t.first_leaf + lane;
+        unit_leaves = t.n_leaves;  // nodes of this slice
+        seg_start = 0;
+    }
+    if (!active) { unit = t.first_unit; k = 0; }
+    if (a.pass != PASS_ALL) {
+        const int32_t st = a.status[unit];
+        if (a.pass == PASS_FUSED) active = active && st == 0;
+        else active = active && (t.n_units ? st == 2 : st >= 0);
+    }
+
+    const uint64_t ulen = a.len[unit];
+    const bool from_b = a.sel && a.sel[unit];
+    const uint8_t *src = from_b ? a.srcB + a.offB[unit] : a.srcA + (a.offA[unit] - a.baseA);
+    uint8_t *dst = (COPY && !from_b && a.srcB) ? a.srcB + a.offB[unit] : nullptr;
+    const uint64_t leaf_off = (uint64_t)k << 10;
+    uint32_t leaf_len = 0;
+    if (active && ulen > leaf_off) leaf_len = (uint32_t)((ulen - leaf_off) < 1024 ? (ulen - leaf_off) : 1024);
+    const uint32_t nblk = leaf_len ? (leaf_len + 63) >> 6 : 1u;
+    const uint64_t total_leaves = ulen ? (ulen + 1023) >> 10 : 1;
+    const bool single = total_leaves == 1;  // the leaf itself is the root
+
+    uint32_t cv[8];
+    b3::set_iv(cv);
+    src += leaf_off;
+    if (COPY && dst) dst += leaf_off;
+    // wave-uniform trip count (16 for every full leaf)
+    uint32_t maxblk = active ? nblk : 0;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        uint32_t o = __shfl_xor(maxblk, d);
+        maxblk = o > maxblk ? o : maxblk;
+    }
+    maxblk = __builtin_amdgcn_readfirstlane(maxblk);
+    for (uint32_t b = 0; b < maxblk; b++) {
+        if (active && b < nblk) {
+            uint32_t m[16];
+            uint32_t rem = leaf_len - b * 64;
+            uint32_t bl = leaf_len == 0 ? 0 : (rem < 64 ? rem : 64);
+            load_block(src + b * 64, bl, m);
+            if (COPY && dst) store_block(dst + b * 64, bl, m);
+            uint32_t flags = (b == 0 ? b3::CHUNK_START : 0u) |
+                             (b == nblk - 1 ? (b3::CHUNK_END | (single ? b3::ROOT : 0u)) : 0u);
+            b3::compress(cv, m, k, 0, bl, flags);
+        }
+    }
+
+    fold_segments(cv, seg_start, active ? unit_leaves : 0, t.n_units != 0);
+
+    if (active && lane == seg_start) {
+        uint32_t *o = t.n_units ? a.digests + (size_t)unit * 8 : a.tile_cv + (size_t)t.cv_index * 8;
+#pragma unroll
+        for (int i = 0; i < 8; i++) o[i] = cv[i];
+    }
+}
+
+}  // namespace zn

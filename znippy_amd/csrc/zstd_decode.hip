@@ -426,6 +426,10 @@ __global__ __launch_bounds__(NWAVES * 64) void k_zstd_decode(DecodeArgs a) {
     const bool wave0 = tid < 64;
     uint8_t *const lit_buf = a.lit_scratch + (size_t)blockIdx.x * LIT_SCRATCH_BYTES;
 
+    // nothing routed here (every row was handled by the fused small-row kernel): leave at once
+    if (a.n_list_a == 0 && *a.pending_count == 0) return;
+    const uint32_t n_work = a.n_list_a + *a.pending_count;
+
     // predefined tables, once per workgroup (lane 0; tiny)
     if (tid == 0) {
         for (int i = 0; i < 36; i++) S.norm[i] = c_ll_default[i];
@@ -440,9 +444,9 @@ __global__ __launch_bounds__(NWAVES * 64) void k_zstd_decode(DecodeArgs a) {
     for (;;) {
         if (tid == 0) S.row = atomicAdd(a.cursor, 1u);
         __syncthreads();
-        const uint32_t row = S.row;
-        if (row >= a.n_rows) break;
-        if (!a.compressed[row]) { __syncthreads(); continue; }  // store path: handled by the hash+copy kernel
+        const uint32_t widx = S.row;
+        if (widx >= n_work) break;
+        const uint32_t row = widx < a.n_list_a ? a.list_a[widx] : a.pending[widx - a.n_list_a];
 
         const uint8_t *const src = a.blobs + (a.blob_off[row] - a.blob_base);
         const uint64_t src_n = a.blob_size[row];
@@ -800,7 +804,7 @@ __global__ __launch_bounds__(NWAVES * 64) void k_zstd_decode(DecodeArgs a) {
             int err = S.err;
             if (!err && S.out_pos != S.content_size) err = E_CORRUPT;
             if (!err && S.has_cksum && S.src_pos + 4 > S.src_end) err = E_TRUNC;
-            a.status[row] = err;
+            a.status[row] = err ? err : 2;  // 2 = decoded here, to be hashed by the second pass
         }
         __syncthreads();
     }
