@@ -7,6 +7,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -390,6 +391,7 @@ int znippy_decode_verify_rows_async(znippy_ctx *ctx, znippy_rows *r, const void 
         f.h.pass = 1;  // PASS_FUSED
         f.blob_size = r->blob_size; f.out_cap = out_cap; f.status = r->status;
         f.pending = r->pending; f.pending_count = r->pending_count;
+        { const char *e = getenv("ZNIPPY_DBG"); f.dbg = e ? atoi(e) : 0; }
         ktime_begin(ctx, "decode_verify_fused");
         launch_fused_small(f, s);
         ktime_end(ctx);

@@ -79,6 +79,7 @@ struct FusedArgs {
     int32_t *status;
     uint32_t *pending;
     uint32_t *pending_count;
+    int dbg;  // diagnostic builds only (ZNIPPY_DBG): 1 = skip hash, 2 = skip decode
 };
 
 void launch_hash_tiles(const HashArgs &a, hipStream_t s);

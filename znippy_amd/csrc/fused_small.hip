@@ -204,20 +204,25 @@ __device__ __forceinline__ void fwave_match(uint8_t *dst, const uint8_t *pat, ui
         for (uint32_t i = lane; i < ml; i += 64) dst[i] = pat[i % off];
         return;
     }
-    // E[i] = pat[i % off] for i < off + 1024, by doubling inside LDS (ds ops of one wave are ordered)
-    for (uint32_t i = lane; i < off; i += 64) E[i] = pat[i];
+    // E[i] = pat[i % off] for i < off + 1024, by doubling inside LDS (ds ops of one wave are ordered).
+    // Chunks are whole 16-byte pieces: a step may copy up to 15 bytes past its end; that spill is
+    // rewritten by the next step (or lands in the buffer's slack), so no byte loop is needed.
+    {
+        const uint32_t full = off & ~15u;
+        for (uint32_t i = lane * 16; i < full; i += 1024) {
+            uint4 v = ld16(pat + i);
+            __builtin_memcpy(E + i, &v, 16);
+        }
+        if (lane < (off & 15)) E[full + lane] = pat[full + lane];
+    }
     const uint32_t need = off + 1024;
     uint32_t w = off;
     while (w < need) {
         const uint32_t c = w < need - w ? w : need - w;
         for (uint32_t i = lane * 16; i < c; i += 1024) {
-            if (i + 16 <= c) {
-                uint4 v;
-                __builtin_memcpy(&v, E + i, 16);
-                __builtin_memcpy(E + w + i, &v, 16);
-            } else {
-                for (uint32_t k = i; k < c; k++) E[w + k] = E[k];
-            }
+            uint4 v;
+            __builtin_memcpy(&v, E + i, 16);
+            __builtin_memcpy(E + w + i, &v, 16);
         }
         w += c;
     }
@@ -432,7 +437,7 @@ __global__ __launch_bounds__(256) void k_fused_small(FusedArgs a) {
     if (t.n_units == 0) return;  // slices of big rows: general decoder + second hash pass
     uint8_t *const E = s_E[threadIdx.x >> 6];
 
-    for (uint32_t u = 0; u < t.n_units; u++) {
+    for (uint32_t u = 0; u < t.n_units && !(a.dbg & 2); u++) {
         const uint32_t row = t.first_unit + u;
         if (!a.h.sel[row]) continue;  // stored row: copied while it is hashed below
         const uint64_t usize = a.h.len[row];
@@ -448,7 +453,7 @@ __global__ __launch_bounds__(256) void k_fused_small(FusedArgs a) {
         }
     }
     fwave_mem_sync();  // decoded bytes + status words have landed (same CU: visible to this wave's loads)
-    hash_tile<true>(a.h, t);
+    if (!(a.dbg & 1)) hash_tile<true>(a.h, t);
 }
 
 void launch_fused_small(const FusedArgs &a, hipStream_t s) {

@@ -139,24 +139,51 @@ __device__ __forceinline__ void hash_tile(const HashArgs &a, const Tile &t) {
     b3::set_iv(cv);
     src += leaf_off;
     if (COPY && dst) dst += leaf_off;
-    // wave-uniform trip count (16 for every full leaf)
-    uint32_t maxblk = active ? nblk : 0;
+    if (__ballot(active && leaf_len != 1024) == 0ull) {
+        // fast path (wave-uniform): every active lane owns a full 1 KiB leaf -> 16 full blocks,
+        // next block's 64 bytes are in flight while the current one is compressed
+        if (active) {
+            uint4 n0 = ld16(src), n1 = ld16(src + 16), n2 = ld16(src + 32), n3 = ld16(src + 48);
+#pragma unroll 1
+            for (uint32_t b = 0; b < 16; b++) {
+                uint32_t m[16] = {n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, n1.z, n1.w,
+                                  n2.x, n2.y, n2.z, n2.w, n3.x, n3.y, n3.z, n3.w};
+                if (b < 15) {
+                    const uint8_t *q = src + (b + 1) * 64;
+                    n0 = ld16(q); n1 = ld16(q + 16); n2 = ld16(q + 32); n3 = ld16(q + 48);
+                }
+                if (COPY && dst) {
+                    uint8_t *d = dst + b * 64;
+                    st16(d, make_uint4(m[0], m[1], m[2], m[3]));
+                    st16(d + 16, make_uint4(m[4], m[5], m[6], m[7]));
+                    st16(d + 32, make_uint4(m[8], m[9], m[10], m[11]));
+                    st16(d + 48, make_uint4(m[12], m[13], m[14], m[15]));
+                }
+                const uint32_t flags = (b == 0 ? b3::CHUNK_START : 0u) |
+                                       (b == 15 ? (b3::CHUNK_END | (single ? b3::ROOT : 0u)) : 0u);
+                b3::compress(cv, m, k, 0, 64, flags);
+            }
+        }
+    } else {
+        // generic path: ragged / partial / empty leaves
+        uint32_t maxblk = active ? nblk : 0;
 #pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) {
-        uint32_t o = __shfl_xor(maxblk, d);
-        maxblk = o > maxblk ? o : maxblk;
-    }
-    maxblk = __builtin_amdgcn_readfirstlane(maxblk);
-    for (uint32_t b = 0; b < maxblk; b++) {
-        if (active && b < nblk) {
-            uint32_t m[16];
-            uint32_t rem = leaf_len - b * 64;
-            uint32_t bl = leaf_len == 0 ? 0 : (rem < 64 ? rem : 64);
-            load_block(src + b * 64, bl, m);
-            if (COPY && dst) store_block(dst + b * 64, bl, m);
-            uint32_t flags = (b == 0 ? b3::CHUNK_START : 0u) |
-                             (b == nblk - 1 ? (b3::CHUNK_END | (single ? b3::ROOT : 0u)) : 0u);
-            b3::compress(cv, m, k, 0, bl, flags);
+        for (int d = 32; d >= 1; d >>= 1) {
+            uint32_t o = __shfl_xor(maxblk, d);
+            maxblk = o > maxblk ? o : maxblk;
+        }
+        maxblk = __builtin_amdgcn_readfirstlane(maxblk);
+        for (uint32_t b = 0; b < maxblk; b++) {
+            if (active && b < nblk) {
+                uint32_t m[16];
+                uint32_t rem = leaf_len - b * 64;
+                uint32_t bl = leaf_len == 0 ? 0 : (rem < 64 ? rem : 64);
+                load_block(src + b * 64, bl, m);
+                if (COPY && dst) store_block(dst + b * 64, bl, m);
+                uint32_t flags = (b == 0 ? b3::CHUNK_START : 0u) |
+                                 (b == nblk - 1 ? (b3::CHUNK_END | (single ? b3::ROOT : 0u)) : 0u);
+                b3::compress(cv, m, k, 0, bl, flags);
+            }
         }
     }
 
