@@ -1,0 +1,80 @@
+"""N>1 path on CPU: world_size-2 gloo group, per-rank row ranges, counters reduced with one
+all-reduce.  Same host code as the GPU path (backend nccl = RCCL there)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import gen
+from znippy_amd.decompress import decompress_archive
+from znippy_amd.sharding import split_rows
+from znippy_amd.stream_packer import ArchiveEntry, compress_stream
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def test_split_rows_is_a_partition_balanced_by_bytes():
+    rng = np.random.default_rng(0)
+    for world in (1, 2, 3, 8):
+        for w in ([], [5], [0, 0, 0], list(rng.integers(0, 10**6, 1000)), [10**9] + [1] * 100, [1] * 7):
+            parts = split_rows(w, world)
+            assert len(parts) == world
+            assert parts[0][0] == 0 and parts[-1][1] == len(w)
+            for (a, b), (c, d) in zip(parts, parts[1:]):
+                assert b == c and a <= b and c <= d
+    # skewed archive (C5 shape): ranges are balanced by bytes, not by row count
+    w = [2000] * 3500 + [10**6] * 1400 + [4 * 10**7] * 100
+    parts = split_rows(w, 8)
+    loads = [sum(w[a:b]) for a, b in parts]
+    assert max(loads) <= 1.35 * (sum(w) / 8) + 4 * 10**7
+    rows = [b - a for a, b in parts]
+    assert max(rows) > 10 * max(min(rows), 1)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def test_world2_gloo_matches_single_process(tmp_path, oracle):
+    from oracle_backend import OracleBackend
+    entries = [ArchiveEntry(f"d{i % 3}/f{i:03}.txt", gen.pseudo_text(3000 + 977 * i, seed=i)) for i in range(24)]
+    entries += [ArchiveEntry("big.bin", gen.binary(20 * 1024 * 1024)),            # 3 chunks, may straddle ranks
+                ArchiveEntry("stored.jar", gen.incompressible(1, 300000)), ArchiveEntry("empty.txt", b"")]
+    c = compress_stream(tmp_path / "a.znippy", False, backend=OracleBackend())
+    for e in entries:
+        c.sender().send(e)
+    c.finish()
+    archive = tmp_path / "a.znippy"
+    # corrupt one stored payload byte so the reduced report has something to carry
+    raw = bytearray(archive.read_bytes())
+    idx = raw.find(gen.incompressible(1, 300000)[:64])
+    raw[idx + 5] ^= 1
+    archive.write_bytes(bytes(raw))
+
+    single = decompress_archive(archive, True, tmp_path / "single", backend=OracleBackend())
+    port = _free_port()
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE="2")
+    procs = []
+    for r in range(2):
+        e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "_mr_worker.py"), str(archive),
+                                       str(tmp_path / "multi"), str(tmp_path / "rep.json")], env=e))
+    for p in procs:
+        assert p.wait(timeout=300) == 0
+    multi = json.load(open(tmp_path / "rep.json"))
+    assert multi == single.__dict__
+    assert single.corrupt_files == 1 and single.total_files == len(entries)
+    for e in entries:
+        a = (tmp_path / "single" / e.relative_path).read_bytes()
+        b = (tmp_path / "multi" / e.relative_path).read_bytes()
+        assert a == b
+        if e.relative_path != "stored.jar":
+            assert a == e.data
