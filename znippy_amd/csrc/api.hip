@@ -50,6 +50,9 @@ struct znippy_ctx {
     size_t enc_prov_cap = 0;
     uint32_t *enc_seq = nullptr;
     EncTables *enc_tabs = nullptr;
+    // auxiliary stream: the write side hashes on it while the main stream encodes
+    hipStream_t aux = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     // kernel timing
     std::vector<KTime> ktimes;
     int n_ktimes = 0;
@@ -162,7 +165,7 @@ struct znippy_rounds {
 };
 
 // ------------------------------------------------------------------------------------------------
-static void ktime_begin(znippy_ctx *ctx, const char *name) {
+static void ktime_begin(znippy_ctx *ctx, const char *name, hipStream_t on = nullptr) {
     if ((int)ctx->ktimes.size() <= ctx->n_ktimes) {
         KTime k{name, nullptr, nullptr};
         (void)hipEventCreate(&k.t0);
@@ -170,10 +173,10 @@ static void ktime_begin(znippy_ctx *ctx, const char *name) {
         ctx->ktimes.push_back(k);
     }
     ctx->ktimes[ctx->n_ktimes].name = name;
-    (void)hipEventRecord(ctx->ktimes[ctx->n_ktimes].t0, ctx->stream);
+    (void)hipEventRecord(ctx->ktimes[ctx->n_ktimes].t0, on ? on : ctx->stream);
 }
-static void ktime_end(znippy_ctx *ctx) {
-    (void)hipEventRecord(ctx->ktimes[ctx->n_ktimes].t1, ctx->stream);
+static void ktime_end(znippy_ctx *ctx, hipStream_t on = nullptr) {
+    (void)hipEventRecord(ctx->ktimes[ctx->n_ktimes].t1, on ? on : ctx->stream);
     ctx->n_ktimes++;
 }
 
@@ -197,6 +200,12 @@ int znippy_ctx_create(int device, void *hip_stream, znippy_ctx **out) {
         ctx->own_stream = true;
     }
     init_fused_tables();
+    if (hipStreamCreateWithFlags(&ctx->aux, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming) != hipSuccess) {
+        delete ctx;
+        return ZNIPPY_E_HIP;
+    }
     ctx->decode_grid = decode_grid_size(device);
     if (hipMalloc(&ctx->lit_scratch, decode_lit_scratch_bytes(ctx->decode_grid)) != hipSuccess ||
         hipMalloc(&ctx->cursor, 64) != hipSuccess) {
@@ -232,6 +241,9 @@ void znippy_ctx_destroy(znippy_ctx *ctx) {
     if (ctx->enc_prov) (void)hipFree(ctx->enc_prov);
     if (ctx->enc_seq) (void)hipFree(ctx->enc_seq);
     if (ctx->enc_tabs) (void)hipFree(ctx->enc_tabs);
+    if (ctx->aux) { (void)hipStreamSynchronize(ctx->aux); (void)hipStreamDestroy(ctx->aux); }
+    if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
+    if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -392,6 +404,8 @@ int znippy_decode_verify_rows_async(znippy_ctx *ctx, znippy_rows *r, const void 
         f.blob_size = r->blob_size; f.out_cap = out_cap; f.status = r->status;
         f.pending = r->pending; f.pending_count = r->pending_count;
         { const char *e = getenv("ZNIPPY_DBG"); f.dbg = e ? atoi(e) : 0; }
+        { const char *e = getenv("ZNIPPY_STAGGER"); f.stagger = e ? (uint32_t)atoi(e) : 0; }
+        { const char *e = getenv("ZNIPPY_LDS_PAD"); f.lds_pad = e ? (uint32_t)atoi(e) : 0; }
         ktime_begin(ctx, "decode_verify_fused");
         launch_fused_small(f, s);
         ktime_end(ctx);
@@ -558,20 +572,20 @@ int znippy_rounds_create(znippy_ctx *ctx, const uint64_t *src_offset, const uint
 
 uint64_t znippy_rounds_blob_bound(const znippy_rounds *r) { return r ? r->blob_bound : 0; }
 
-static int hash_rounds_async(znippy_ctx *ctx, znippy_rounds *r, const void *d_src) {
-    hipStream_t s = ctx->stream;
+static int hash_rounds_async(znippy_ctx *ctx, znippy_rounds *r, const void *d_src, hipStream_t on = nullptr) {
+    hipStream_t s = on ? on : ctx->stream;
     HashArgs h{};
     h.tiles = r->plan.tiles; h.n_tiles = r->plan.n_tiles;
     h.len = r->len;
     h.srcA = (const uint8_t *)d_src; h.offA = r->src_off; h.baseA = 0;
     h.digests = r->digests; h.tile_cv = r->plan.tile_cv;
-    ktime_begin(ctx, "blake3_tiles");
+    ktime_begin(ctx, "blake3_tiles", s);
     launch_hash_tiles(h, s);
-    ktime_end(ctx);
+    ktime_end(ctx, s);
     if (r->plan.n_big) {
-        ktime_begin(ctx, "blake3_merge_big");
+        ktime_begin(ctx, "blake3_merge_big", s);
         launch_merge_big(r->plan.big, r->plan.n_big, r->plan.tile_cv, r->digests, s);
-        ktime_end(ctx);
+        ktime_end(ctx, s);
     }
     HIPCHK(ctx, hipGetLastError());
     return ZNIPPY_OK;
@@ -664,8 +678,7 @@ extern "C" int znippy_encode_hash_rounds_async(znippy_ctx *ctx, znippy_rounds *r
         HIPCHK(ctx, hipMalloc(&ctx->enc_prov, r->prov_bytes + 64));
         ctx->enc_prov_cap = r->prov_bytes + 64;
     }
-    int rc = hash_rounds_async(ctx, r, d_src);  // checksum over the ORIGINAL bytes (stream_packer.rs:L219)
-    if (rc) return rc;
+    HIPCHK(ctx, hipEventRecord(ctx->ev_fork, s));
     HIPCHK(ctx, hipMemcpyAsync(r->piece_len, r->piece_len_init, 4 * (size_t)r->n_items, hipMemcpyDeviceToDevice, s));
     HIPCHK(ctx, hipMemsetAsync(r->blob_size, 0, 8 * (size_t)r->n, s));
     HIPCHK(ctx, hipMemsetAsync(r->overflow, 0, 16, s));
@@ -679,6 +692,12 @@ extern "C" int znippy_encode_hash_rounds_async(znippy_ctx *ctx, znippy_rounds *r
     ktime_begin(ctx, "zstd_encode");
     launch_encode(a, std::min<int>(ctx->encode_grid, (int)r->n_items), s);
     ktime_end(ctx);
+    // checksum over the ORIGINAL bytes (stream_packer.rs:L219): VALU-bound, submitted to the
+    // auxiliary stream right after the persistent (latency-bound) encoder so both share the CUs
+    HIPCHK(ctx, hipStreamWaitEvent(ctx->aux, ctx->ev_fork, 0));
+    int rc = hash_rounds_async(ctx, r, d_src, ctx->aux);
+    if (rc) return rc;
+    HIPCHK(ctx, hipEventRecord(ctx->ev_join, ctx->aux));
     ktime_begin(ctx, "piece_scan");
     launch_piece_scan(r->piece_len, r->n_items, r->local_excl, r->block_tot, s);
     ktime_end(ctx);
@@ -691,6 +710,7 @@ extern "C" int znippy_encode_hash_rounds_async(znippy_ctx *ctx, znippy_rounds *r
     ktime_begin(ctx, "gather");
     launch_gather(g, s);
     ktime_end(ctx);
+    HIPCHK(ctx, hipStreamWaitEvent(s, ctx->ev_join, 0));  // digests are complete once the main stream drains
     HIPCHK(ctx, hipGetLastError());
     return ZNIPPY_OK;
 }

@@ -105,13 +105,33 @@ void init_fused_tables() {
 }
 
 // ---- device helpers ---------------------------------------------------------------------------------
+constexpr uint32_t WIN = 256;       // bytes of every row's frame staged in LDS by the tile prologue
+constexpr uint32_t WROWS = 8;       // rows per tile that get a staged window (others load on demand)
+constexpr uint32_t WSTRIDE = WIN + 32;
+
 __device__ __forceinline__ uint32_t uni(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
 __device__ __forceinline__ int fhib(uint32_t v) { return 31 - __clz(v); }
 __device__ __forceinline__ void fwave_mem_sync() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
-// 256-byte window of the frame held across the wave: lane l keeps bytes [wbase+4l, wbase+4l+4).
+// scalar a % b without the VALU reciprocal sequence (operands are wave-uniform -> SALU loop)
+__device__ __forceinline__ uint32_t smod(uint32_t a, uint32_t b) {
+    if (a < b) return a;
+    uint32_t sh = (uint32_t)(__clz(b) - __clz(a));
+    uint32_t d = b << sh;
+    for (;;) {
+        if (a >= d) a -= d;
+        if (sh == 0) break;
+        d >>= 1;
+        sh--;
+    }
+    return a;
+}
+
+// The frame as the wave sees it: bytes [0, min(n,WIN)) staged in LDS (`wl`, zero padded) and, for
+// scalar parsing, a 256-byte register window (lane l = dword l of [wbase, wbase+256)).
 struct FrameWin {
-    const uint8_t *src;
+    const uint8_t *src;  // global
+    const uint8_t *wl;   // LDS copy of the first WIN bytes, or nullptr
     uint32_t n, wbase, w;
     __device__ __forceinline__ void load(uint32_t base) {
         const uint32_t lane = threadIdx.x & 63;
@@ -124,7 +144,7 @@ struct FrameWin {
                 if (o + k < n) v |= (uint32_t)src[o + k] << (8 * k);
         w = v;
     }
-    // 8 bytes at byte position pos (wave-uniform), zero past the end of the frame
+    // 8 bytes at byte position pos (wave-uniform)
     __device__ __forceinline__ uint64_t u64(uint32_t pos) {
         const uint32_t rel = pos - wbase, idx = rel >> 2, sh = (rel & 3) * 8;
         const uint32_t d0 = __builtin_amdgcn_readlane(w, idx), d1 = __builtin_amdgcn_readlane(w, idx + 1),
@@ -140,20 +160,33 @@ struct FrameWin {
         if (pos < wbase || pos + 12 > wbase + 256) load(pos >= 240 ? pos - 240 : 0);
         return u64(pos);
     }
+    // LDS pointer to frame bytes [at, at+len) if they are inside the staged window
+    __device__ __forceinline__ const uint8_t *lds(uint32_t at, uint32_t len) const {
+        return (wl && at + len <= WIN) ? wl + at : nullptr;
+    }
 };
 
-// backward bit reader over frame bytes [s_begin, ...): bp = unread bits
+// backward bit reader over frame bytes [s_begin, ...): bp = unread bits.  A 64-bit scalar cache
+// holds stream bits [cb, cb+64); it is refilled (3 readlanes) only when a read leaves it.
 struct SBits {
     uint32_t s_begin;
     int32_t bp;
+    uint64_t cw;
+    int32_t cb;  // bit index of cw's bit 0; INT32_MIN = empty
     __device__ __forceinline__ uint32_t read(FrameWin &W, uint32_t nb) {  // nb <= 32, scalar
         if (nb == 0) return 0;
-        uint32_t v;
-        if (bp <= 0) v = 0;
-        else {
+        uint32_t v = 0;
+        if (bp > 0) {
             const uint32_t take = (uint32_t)bp < nb ? (uint32_t)bp : nb;  // real bits available
-            const uint32_t lo_bit = (uint32_t)bp - take;
-            const uint64_t x = W.bwd(s_begin + (lo_bit >> 3)) >> (lo_bit & 7);
+            const int32_t lo_bit = bp - (int32_t)take;
+            if (lo_bit < cb || bp > cb + 64) {
+                // refill so that the window ends at the byte holding bit bp-1
+                int32_t top_byte = (bp + 7) >> 3;
+                int32_t b0 = top_byte > 8 ? top_byte - 8 : 0;
+                cw = W.bwd(s_begin + (uint32_t)b0);
+                cb = b0 * 8;
+            }
+            const uint64_t x = cw >> (uint32_t)(lo_bit - cb);
             v = (uint32_t)(x & ((1ull << take) - 1)) << (nb - take);
         }
         bp -= (int32_t)nb;
@@ -161,6 +194,8 @@ struct SBits {
     }
 };
 
+// ---- wave-cooperative byte movers (64 lanes) ----------------------------------------------------
+// global -> global
 __device__ __forceinline__ void fwave_copy(uint8_t *dst, const uint8_t *src, uint32_t n, uint32_t lane) {
     if (n < 128) {
         for (uint32_t i = lane; i < n; i += 64) dst[i] = src[i];
@@ -175,6 +210,11 @@ __device__ __forceinline__ void fwave_copy(uint8_t *dst, const uint8_t *src, uin
     }
     const uint32_t done = head + body * 16;
     if (done + lane < n) dst[done + lane] = src[done + lane];
+}
+
+// LDS -> global, n <= WIN
+__device__ __forceinline__ void fwave_copy_l2g(uint8_t *dst, const uint8_t *l, uint32_t n, uint32_t lane) {
+    for (uint32_t i = lane; i < n; i += 64) dst[i] = l[i];
 }
 
 __device__ __forceinline__ void fwave_fill(uint8_t *dst, uint8_t byte, uint32_t n, uint32_t lane) {
@@ -192,30 +232,30 @@ __device__ __forceinline__ void fwave_fill(uint8_t *dst, uint8_t byte, uint32_t 
     if (done + lane < n) dst[done + lane] = byte;
 }
 
-// dst[i] = pat[i % off], i < ml.  `pat` points at `off` bytes that are final (read-only frame
-// literals, or output already drained with fwave_mem_sync).  E = this wave's LDS pattern buffer.
-__device__ __forceinline__ void fwave_match(uint8_t *dst, const uint8_t *pat, uint32_t off, uint32_t ml, uint8_t *E,
-                                            uint32_t lane) {
-    if (off >= ml) {
-        fwave_copy(dst, pat, ml, lane);
-        return;
-    }
-    if (ml <= 256 || off > EOFF_MAX) {
-        for (uint32_t i = lane; i < ml; i += 64) dst[i] = pat[i % off];
-        return;
-    }
-    // E[i] = pat[i % off] for i < off + 1024, by doubling inside LDS (ds ops of one wave are ordered).
-    // Chunks are whole 16-byte pieces: a step may copy up to 15 bytes past its end; that spill is
-    // rewritten by the next step (or lands in the buffer's slack), so no byte loop is needed.
-    {
-        const uint32_t full = off & ~15u;
-        for (uint32_t i = lane * 16; i < full; i += 1024) {
-            uint4 v = ld16(pat + i);
+// dst[i] = pat[i % off], i < ml, for an OVERLAPPING match (off < ml) with off <= EOFF_MAX.
+// The period comes from LDS (`pl`, staged frame literals) or from final global bytes (`pg`).
+// E = this wave's LDS pattern buffer: E[i] = pat[i % off] for i < off + min(ml, 1024) is built by
+// doubling inside LDS (ds ops of one wave are ordered), then streamed out 1 KiB per step with
+// 16-byte aligned stores; head and tail bytes go out lane-parallel.
+__device__ __forceinline__ void fwave_expand(uint8_t *dst, const uint8_t *pg, const uint8_t *pl, uint32_t off,
+                                             uint32_t ml, uint8_t *E, uint32_t lane) {
+    // 1) the period itself into E (16-byte pieces may spill up to 15 bytes; rewritten below)
+    if (pl) {
+        for (uint32_t i = lane * 16; i < off; i += 1024) {
+            uint4 v;
+            __builtin_memcpy(&v, pl + i, 16);  // staged window has 32 bytes of readable padding
             __builtin_memcpy(E + i, &v, 16);
         }
-        if (lane < (off & 15)) E[full + lane] = pat[full + lane];
+    } else {
+        const uint32_t full = off & ~15u;
+        for (uint32_t i = lane * 16; i < full; i += 1024) {
+            uint4 v = ld16(pg + i);
+            __builtin_memcpy(E + i, &v, 16);
+        }
+        if (lane < (off & 15)) E[full + lane] = pg[full + lane];
     }
-    const uint32_t need = off + 1024;
+    // 2) doubling
+    const uint32_t need = off + (ml < 1024 ? ml : 1024);
     uint32_t w = off;
     while (w < need) {
         const uint32_t c = w < need - w ? w : need - w;
@@ -226,34 +266,72 @@ __device__ __forceinline__ void fwave_match(uint8_t *dst, const uint8_t *pat, ui
         }
         w += c;
     }
+    // 3) stream out
     const uint32_t head = (uint32_t)((16 - ((uintptr_t)dst & 15)) & 15);
+    if (ml < head + 16) {  // too short for an aligned piece
+        for (uint32_t i = lane; i < ml; i += 64) dst[i] = E[i];
+        return;
+    }
     if (lane < head) dst[lane] = E[lane];
-    uint32_t x = head, s = head % off;
-    const uint32_t step = 1024 % off;
+    uint32_t x = head, s = smod(head, off);
+    const uint32_t step = smod(1024, off);
+    uint8_t *d = dst + head + 16 * lane;
     while (x + 1024 <= ml) {
         uint4 v;
         __builtin_memcpy(&v, E + s + 16 * lane, 16);
-        *reinterpret_cast<uint4 *>(dst + x + 16 * lane) = v;
+        *reinterpret_cast<uint4 *>(d) = v;
+        d += 1024;
         x += 1024;
         s += step;
         if (s >= off) s -= off;
     }
-    const uint32_t rem = ml - x;
-    if (16 * lane + 16 <= rem) {
+    const uint32_t rem = ml - x;             // < 1024
+    const uint32_t full16 = rem >> 4;        // whole 16-byte pieces left
+    if (lane < full16) {
         uint4 v;
         __builtin_memcpy(&v, E + s + 16 * lane, 16);
-        *reinterpret_cast<uint4 *>(dst + x + 16 * lane) = v;
-    } else if (16 * lane < rem) {
-        for (uint32_t k = 16 * lane; k < rem; k++) dst[x + k] = E[s + k];
+        *reinterpret_cast<uint4 *>(d) = v;
     }
+    const uint32_t tail = rem & 15, tbase = full16 * 16;
+    if (lane < tail) dst[x + tbase + lane] = E[s + tbase + lane];
+}
+
+// LZ match of the fused path: dst[i] = dst[i - off].  `pl`/`pg_fwd`: the period forwarded from
+// the frame's literals when it lies inside the literal run just copied (no read-after-write
+// through memory); otherwise the period is re-read from the output after a store drain.
+__device__ __forceinline__ void fwave_match(uint8_t *dst, const uint8_t *pg_fwd, const uint8_t *pl, uint32_t off,
+                                            uint32_t ml, uint8_t *E, uint32_t lane) {
+    const uint8_t *pg = pg_fwd;
+    if (!pg && !pl) {
+        fwave_mem_sync();  // earlier output of this wave must have landed before it is re-read
+        pg = dst - off;
+    }
+    if (off >= ml) {  // no overlap: plain copy
+        if (pl) fwave_copy_l2g(dst, pl, ml, lane);
+        else fwave_copy(dst, pg, ml, lane);
+        return;
+    }
+    if (off <= EOFF_MAX) {
+        fwave_expand(dst, pg, pl, off, ml, E, lane);
+        return;
+    }
+    // long period + overlap (rare in small rows): byte-parallel modulo copy from the final period
+    if (pl) { for (uint32_t i = lane; i < ml; i += 64) dst[i] = pl[i % off]; }
+    else { for (uint32_t i = lane; i < ml; i += 64) dst[i] = pg[i % off]; }
 }
 
 // Decode one simple frame with the calling wave.  Returns 0, F_NOT_SIMPLE or a negative error.
-__device__ int decode_simple(const uint8_t *src, uint32_t n, uint8_t *out, uint64_t usize, uint8_t *E) {
+__device__ int decode_simple(const uint8_t *src, uint32_t n, uint8_t *out, uint64_t usize, uint8_t *E,
+                             const uint8_t *wl) {
     const uint32_t lane = threadIdx.x & 63;
     FrameWin W;
-    W.src = src; W.n = n;
-    W.load(0);
+    W.src = src; W.n = n; W.wl = wl;
+    if (wl) {  // staged by the tile prologue: the register window comes from LDS, not from HBM
+        W.wbase = 0;
+        W.w = *reinterpret_cast<const uint32_t *>(wl + 4 * lane);
+    } else {
+        W.load(0);
+    }
     if (n < 5) return F_E_CORRUPT;
     uint64_t h = W.fwd(0);
     if ((uint32_t)h != 0xFD2FB528u) return F_E_CORRUPT;
@@ -288,7 +366,8 @@ __device__ int decode_simple(const uint8_t *src, uint32_t n, uint8_t *out, uint6
         if (btype == 3) return F_E_CORRUPT;
         if (btype == 0) {
             if (pos + bsize > n || opos + bsize > osize) return F_E_CORRUPT;
-            fwave_copy(out + opos, src + pos, bsize, lane);
+            if (const uint8_t *l = W.lds(pos, bsize)) fwave_copy_l2g(out + opos, l, bsize, lane);
+            else fwave_copy(out + opos, src + pos, bsize, lane);
             opos += bsize; pos += bsize;
         } else if (btype == 1) {
             if (pos + 1 > n || opos + bsize > osize) return F_E_CORRUPT;
@@ -360,6 +439,8 @@ __device__ int decode_simple(const uint8_t *src, uint32_t n, uint8_t *out, uint6
                 SBits B;
                 B.s_begin = pos;
                 B.bp = (int32_t)((bend - pos) * 8 - (8 - fhib(lastb)));
+                B.cw = 0;
+                B.cb = INT32_MIN / 2;
                 uint32_t sl = m_ll ? 0 : B.read(W, 6);
                 uint32_t so = m_of ? 0 : B.read(W, 5);
                 uint32_t sm = m_ml ? 0 : B.read(W, 6);
@@ -393,18 +474,21 @@ __device__ int decode_simple(const uint8_t *src, uint32_t n, uint8_t *out, uint6
                     if ((uint64_t)opos + ll + ml > osize) return F_E_CORRUPT;
                     // literals
                     if (ll) {
-                        if (ltype == 0) fwave_copy(out + opos, src + lit_at + lit_pos, ll, lane);
-                        else fwave_fill(out + opos, (uint8_t)rle_byte, ll, lane);
+                        if (ltype == 0) {
+                            if (const uint8_t *l = W.lds(lit_at + lit_pos, ll)) fwave_copy_l2g(out + opos, l, ll, lane);
+                            else fwave_copy(out + opos, src + lit_at + lit_pos, ll, lane);
+                        } else fwave_fill(out + opos, (uint8_t)rle_byte, ll, lane);
                     }
                     opos += ll; lit_pos += ll;
                     if (offset > opos) return F_E_CORRUPT;
                     // match: the period is forwarded from the frame when it lies inside this literal run
                     if (offset <= ll) {
-                        if (ltype == 0) fwave_match(out + opos, src + lit_at + lit_pos - offset, offset, ml, E, lane);
-                        else fwave_fill(out + opos, (uint8_t)rle_byte, ml, lane);
+                        if (ltype == 0) {
+                            const uint32_t pat_at = lit_at + lit_pos - offset;
+                            fwave_match(out + opos, src + pat_at, W.lds(pat_at, offset), offset, ml, E, lane);
+                        } else fwave_fill(out + opos, (uint8_t)rle_byte, ml, lane);
                     } else {
-                        fwave_mem_sync();  // earlier output of this wave must have landed before it is re-read
-                        fwave_match(out + opos, out + opos - offset, offset, ml, E, lane);
+                        fwave_match(out + opos, nullptr, nullptr, offset, ml, E, lane);
                     }
                     opos += ml;
                 }
@@ -415,8 +499,10 @@ __device__ int decode_simple(const uint8_t *src, uint32_t n, uint8_t *out, uint6
             const uint32_t rest = regen - lit_pos;
             if ((uint64_t)opos + rest > osize) return F_E_CORRUPT;
             if (rest) {
-                if (ltype == 0) fwave_copy(out + opos, src + lit_at + lit_pos, rest, lane);
-                else fwave_fill(out + opos, (uint8_t)rle_byte, rest, lane);
+                if (ltype == 0) {
+                    if (const uint8_t *l = W.lds(lit_at + lit_pos, rest)) fwave_copy_l2g(out + opos, l, rest, lane);
+                    else fwave_copy(out + opos, src + lit_at + lit_pos, rest, lane);
+                } else fwave_fill(out + opos, (uint8_t)rle_byte, rest, lane);
             }
             opos += rest;
             pos = bend;
@@ -430,22 +516,72 @@ __device__ int decode_simple(const uint8_t *src, uint32_t n, uint8_t *out, uint6
 
 __global__ __launch_bounds__(256) void k_fused_small(FusedArgs a) {
     __shared__ __attribute__((aligned(16))) uint8_t s_E[4][EBUF];
+    __shared__ __attribute__((aligned(16))) uint8_t s_W[4][WROWS * WSTRIDE];
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wave = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (wave >= a.h.n_tiles) return;
     const Tile t = a.h.tiles[wave];
     if (t.n_units == 0) return;  // slices of big rows: general decoder + second hash pass
     uint8_t *const E = s_E[threadIdx.x >> 6];
+    uint8_t *const WL = s_W[threadIdx.x >> 6];
+
+    // Stagger: waves sharing a SIMD run the same decode(memory)->hash(VALU) program and fall into
+    // lockstep (all waiting, then all contending for VALU).  Delaying the wave in hardware slot k by
+    // k quanta puts SIMD-mates in different phases so one wave's stores overlap another's hashing.
+    if (a.stagger) {
+        const uint32_t slot = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4) & 15;  // HW_REG_HW_ID.wave_id
+        for (uint32_t i = 0; i < (slot & 3) * a.stagger; i++) __builtin_amdgcn_s_sleep(127);
+    }
+
+    // ---- tile prologue: the rows' index columns, one row per lane (coalesced), then the first
+    // WIN bytes of up to WROWS frames staged into LDS with all loads in flight at once ----
+    uint32_t c_sel = 0, c_bs = 0;
+    uint64_t c_len = 0, c_src = 0, c_oo = 0;
+    if (lane < t.n_units) {
+        const uint32_t row = t.first_unit + lane;
+        c_sel = a.h.sel[row];
+        c_len = a.h.len[row];
+        c_src = a.h.offA[row] - a.h.baseA;
+        c_oo = a.h.offB[row];
+        c_bs = (uint32_t)a.blob_size[row];
+    }
+    if (!(a.dbg & 2)) {
+        const uint32_t nw = t.n_units < WROWS ? t.n_units : WROWS;
+        uint32_t wv[WROWS];
+#pragma unroll
+        for (uint32_t u = 0; u < WROWS; u++) {
+            wv[u] = 0;
+            if (u < nw) {
+                const uint64_t so = __shfl(c_src, u);
+                const uint32_t n = __shfl(c_bs, u), o = 4 * lane;
+                const uint8_t *p = a.h.srcA + so + o;
+                if (__shfl(c_sel, u)) {
+                    if (o + 4 <= n) __builtin_memcpy(&wv[u], p, 4);
+                    else
+                        for (uint32_t k = 0; k < 4; k++)
+                            if (o + k < n) wv[u] |= (uint32_t)p[k] << (8 * k);
+                }
+            }
+        }
+#pragma unroll
+        for (uint32_t u = 0; u < WROWS; u++) {
+            if (u < nw) {
+                *reinterpret_cast<uint32_t *>(WL + u * WSTRIDE + 4 * lane) = wv[u];
+                if (lane < 8) *reinterpret_cast<uint32_t *>(WL + u * WSTRIDE + WIN + 4 * lane) = 0;  // padding
+            }
+        }
+    }
 
     for (uint32_t u = 0; u < t.n_units && !(a.dbg & 2); u++) {
         const uint32_t row = t.first_unit + u;
-        if (!a.h.sel[row]) continue;  // stored row: copied while it is hashed below
-        const uint64_t usize = a.h.len[row];
-        const uint64_t ooff = a.h.offB[row];
+        if (!uni(__shfl(c_sel, u))) continue;  // stored row: copied while it is hashed below
+        const uint64_t usize = ((uint64_t)uni((uint32_t)(__shfl(c_len, u) >> 32)) << 32) | uni((uint32_t)__shfl(c_len, u));
+        const uint64_t ooff = ((uint64_t)uni((uint32_t)(__shfl(c_oo, u) >> 32)) << 32) | uni((uint32_t)__shfl(c_oo, u));
+        const uint64_t soff = ((uint64_t)uni((uint32_t)(__shfl(c_src, u) >> 32)) << 32) | uni((uint32_t)__shfl(c_src, u));
+        const uint32_t bsz = uni(__shfl(c_bs, u));
         int rc;
         if (ooff + usize > a.out_cap) rc = F_E_DST;
-        else
-            rc = decode_simple(a.h.srcA + (a.h.offA[row] - a.h.baseA), (uint32_t)a.blob_size[row], a.h.srcB + ooff, usize, E);
+        else rc = decode_simple(a.h.srcA + soff, bsz, a.h.srcB + ooff, usize, E, u < WROWS ? WL + u * WSTRIDE : nullptr);
         rc = (int)uni((uint32_t)rc);
         if (rc != 0 && lane == 0) {
             a.status[row] = rc;
@@ -458,7 +594,7 @@ __global__ __launch_bounds__(256) void k_fused_small(FusedArgs a) {
 
 void launch_fused_small(const FusedArgs &a, hipStream_t s) {
     if (!a.h.n_tiles) return;
-    hipLaunchKernelGGL(k_fused_small, dim3((a.h.n_tiles + 3) / 4), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(k_fused_small, dim3((a.h.n_tiles + 3) / 4), dim3(256), a.lds_pad, s, a);
 }
 
 }  // namespace zn

@@ -9,6 +9,17 @@ from . import _lib
 from ._lib import VerifyCounters, ZnippyError, as_np, np_ptr, vp
 
 
+def _pinned(shape, dtype):
+    """Host result buffer; pinned when torch can (direct DMA on D2H), reused across calls."""
+    try:
+        import torch
+        n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        t = torch.empty(max(n, 1), dtype=torch.uint8, pin_memory=torch.cuda.is_available())
+        return t.numpy()[:n].view(dtype).reshape(shape), t
+    except Exception:  # no torch / no pinning: plain numpy
+        return np.zeros(shape, dtype=dtype), None
+
+
 def _dptr(t):
     if t is None:
         return None
@@ -108,6 +119,8 @@ class RowTable:
         self.h = h
         self.row_begin, self.row_end = row_begin, row_end
         self.n = row_end - row_begin
+        self._corrupt, self._k1 = _pinned((max(self.n, 1),), np.uint64)
+        self._status, self._k2 = _pinned((max(self.n, 1),), np.int32)
 
     def close(self):
         if getattr(self, "h", None):
@@ -124,8 +137,7 @@ class RowTable:
 
     def results(self, want_status=True):
         c = VerifyCounters()
-        corrupt = np.zeros(max(self.n, 1), dtype=np.uint64)
-        status = np.zeros(max(self.n, 1), dtype=np.int32)
+        corrupt, status = self._corrupt, self._status
         self.ctx._chk(self.ctx.L.znippy_rows_results(self.ctx.h, self.h, C.byref(c), np_ptr(corrupt), corrupt.size,
                                                      np_ptr(status) if want_status else None), "znippy_rows_results")
         return c.as_dict(), corrupt[:min(c.corrupt_rows, corrupt.size)].copy(), status[:self.n]
@@ -149,6 +161,7 @@ class RoundTable:
         ln = as_np(length, np.uint64)
         sk = as_np(skip, np.uint8) if skip is not None else None
         self.n = len(so)
+        self._res = None
         h = vp()
         ctx._chk(ctx.L.znippy_rounds_create(ctx.h, np_ptr(so), np_ptr(ln), np_ptr(sk) if sk is not None else None,
                                             self.n, C.byref(h)), "znippy_rounds_create")
@@ -176,10 +189,10 @@ class RoundTable:
 
     def results(self):
         n = max(self.n, 1)
-        bo = np.zeros(n, dtype=np.uint64)
-        bs = np.zeros(n, dtype=np.uint64)
-        ck = np.zeros((n, 32), dtype=np.uint8)
-        cm = np.zeros(n, dtype=np.uint8)
+        if self._res is None:  # result buffers are reused (and overwritten) by every call
+            self._res = [_pinned((n,), np.uint64), _pinned((n,), np.uint64), _pinned((n, 32), np.uint8),
+                         _pinned((n,), np.uint8)]
+        (bo, _), (bs, _), (ck, _), (cm, _) = self._res
         total = C.c_uint64()
         self.ctx._chk(self.ctx.L.znippy_rounds_results(self.ctx.h, self.h, np_ptr(bo), np_ptr(bs), np_ptr(ck),
                                                        np_ptr(cm), C.byref(total)), "znippy_rounds_results")
