@@ -45,7 +45,7 @@ struct znippy_ctx {
     uint8_t *shim_in = nullptr, *shim_out = nullptr;
     size_t shim_in_cap = 0, shim_out_cap = 0;
     // encoder scratch (grow-only) + tables
-    int encode_grid = 0;
+    int encode_grid = 0, encode_grid_small = 0;
     uint8_t *enc_prov = nullptr;
     size_t enc_prov_cap = 0;
     uint32_t *enc_seq = nullptr;
@@ -157,6 +157,7 @@ struct znippy_rounds {
     // encoder plan: one item per output piece
     EncItem *items = nullptr;
     uint32_t n_items = 0;
+    bool small_blocks = true;  // every encoded block <= 16 KiB: small-table encoder variant, more waves
     uint64_t prov_bytes = 0;
     uint32_t *piece_len = nullptr, *piece_len_init = nullptr;
     uint64_t *piece_start = nullptr, *local_excl = nullptr, *block_tot = nullptr;
@@ -215,10 +216,11 @@ int znippy_ctx_create(int device, void *hip_stream, znippy_ctx **out) {
     {
         hipDeviceProp_t p;
         int cus = hipGetDeviceProperties(&p, device) == hipSuccess ? p.multiProcessorCount : 256;
-        ctx->encode_grid = cus * 12;
+        ctx->encode_grid = cus * 8;         // 16 KiB hash table per wave
+        ctx->encode_grid_small = cus * 16;  // 4 KiB hash table per wave
         EncTables t;
         build_encode_tables(&t);
-        if (hipMalloc(&ctx->enc_seq, (size_t)ctx->encode_grid * MAX_SEQ * 3 * 4) != hipSuccess ||
+        if (hipMalloc(&ctx->enc_seq, (size_t)ctx->encode_grid_small * MAX_SEQ * 3 * 4) != hipSuccess ||
             hipMalloc(&ctx->enc_tabs, sizeof(EncTables)) != hipSuccess ||
             hipMemcpy(ctx->enc_tabs, &t, sizeof t, hipMemcpyHostToDevice) != hipSuccess) {
             delete ctx;
@@ -544,6 +546,7 @@ int znippy_rounds_create(znippy_ctx *ctx, const uint64_t *src_offset, const uint
             uint32_t nb = (uint32_t)std::max<uint64_t>(1, (L + BLOCK_BYTES - 1) / BLOCK_BYTES);
             for (uint32_t k = 0; k < nb; k++) {
                 uint32_t bl = (uint32_t)std::min<uint64_t>(BLOCK_BYTES, L - (uint64_t)k * BLOCK_BYTES);
+                if (bl > 16 * 1024) r->small_blocks = false;
                 items.push_back(EncItem{(uint32_t)i, k, nb, k == 0 ? ITEM_FIRST : 0u, r->prov_bytes});
                 plen.push_back(0);
                 r->prov_bytes += enc_slot_bytes(bl);
@@ -686,11 +689,16 @@ extern "C" int znippy_encode_hash_rounds_async(znippy_ctx *ctx, znippy_rounds *r
     HIPCHK(ctx, hipMemsetAsync(ctx->cursor, 0, 64, s));
     EncodeArgs a{};
     a.items = r->items; a.n_items = r->n_items; a.cursor = ctx->cursor;
+    {
+        const int g = r->small_blocks ? ctx->encode_grid_small : ctx->encode_grid;
+        a.batch = std::max<uint32_t>(1, std::min<uint32_t>(16, r->n_items / (uint32_t)(g * 2)));
+    }
     a.src = (const uint8_t *)d_src; a.src_off = r->src_off; a.len = r->len;
     a.prov = ctx->enc_prov; a.seq_scratch = ctx->enc_seq;
     a.piece_len = r->piece_len; a.piece_start = r->piece_start; a.tabs = ctx->enc_tabs;
     ktime_begin(ctx, "zstd_encode");
-    launch_encode(a, std::min<int>(ctx->encode_grid, (int)r->n_items), s);
+    launch_encode(a, std::min<int>(r->small_blocks ? ctx->encode_grid_small : ctx->encode_grid, (int)r->n_items),
+                  r->small_blocks, s);
     ktime_end(ctx);
     // checksum over the ORIGINAL bytes (stream_packer.rs:L219): VALU-bound, submitted to the
     // auxiliary stream right after the persistent (latency-bound) encoder so both share the CUs

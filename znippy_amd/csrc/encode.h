@@ -40,6 +40,7 @@ struct EncodeArgs {
     const EncItem *items;
     uint32_t n_items;
     uint32_t *cursor;
+    uint32_t batch;  // items per cursor dequeue
     const uint8_t *src;
     const uint64_t *src_off, *len;
     uint8_t *prov;
@@ -63,7 +64,7 @@ struct GatherArgs {
     uint32_t *overflow;
 };
 
-void launch_encode(const EncodeArgs &a, int grid, hipStream_t s);
+void launch_encode(const EncodeArgs &a, int grid, bool small_blocks, hipStream_t s);
 void launch_piece_scan(const uint32_t *piece_len, uint32_t n, uint64_t *local_excl, uint64_t *block_tot, hipStream_t s);
 void launch_gather(const GatherArgs &g, hipStream_t s);
 void build_encode_tables(EncTables *t);

@@ -16,9 +16,6 @@
 
 namespace zn {
 
-constexpr uint32_t HASH_LOG = 12;
-constexpr uint32_t HASH_SIZE = 1u << HASH_LOG;
-constexpr uint32_t MIN_MATCH = 4;
 
 __device__ __forceinline__ uint32_t ld32(const uint8_t *p) {
     uint32_t v;
@@ -30,6 +27,7 @@ __device__ __forceinline__ uint4 ld128(const uint8_t *p) {
     __builtin_memcpy(&v, p, 16);
     return v;
 }
+template <uint32_t HASH_LOG>
 __device__ __forceinline__ uint32_t hash4(uint32_t v) { return (v * 2654435761u) >> (32 - HASH_LOG); }
 __device__ __forceinline__ int hib(uint32_t v) { return 31 - __clz(v); }
 
@@ -104,8 +102,10 @@ struct CState {
     __device__ __forceinline__ void flush(BitW &b) { b.add(v, log); }
 };
 
+template <uint32_t HASH_LOG>
 struct EncShared {
-    uint16_t table[HASH_SIZE];
+    uint16_t table[1u << HASH_LOG];
+    EncTables tabs;  // FSE encoding tables, copied once per persistent wave (lane 0 reads them per sequence)
 };
 
 // n bytes src -> dst by one wave (ranges do not overlap)
@@ -125,19 +125,35 @@ __device__ __forceinline__ void wave_copy(uint8_t *dst, const uint8_t *src, uint
     if (done + lane < n) dst[done + lane] = src[done + lane];
 }
 
-// One wave encodes one block item pulled from the atomic cursor.
+// One wave encodes one block item pulled from the atomic cursor.  HASH_LOG 11 (4 KiB table, more
+// resident waves) serves batches of small rounds, 13 serves 128 KiB blocks.
+template <uint32_t HASH_LOG>
 __global__ __launch_bounds__(64) void k_zstd_encode(EncodeArgs a) {
-    __shared__ EncShared S;
+    constexpr uint32_t HASH_SIZE = 1u << HASH_LOG;
+    __shared__ __attribute__((aligned(16))) EncShared<HASH_LOG> S;
     __shared__ uint32_t s_item, s_raw;
     const uint32_t lane = threadIdx.x;
+    {
+        const uint32_t *g = reinterpret_cast<const uint32_t *>(a.tabs);
+        uint32_t *l = reinterpret_cast<uint32_t *>(&S.tabs);
+        for (uint32_t i = lane; i < sizeof(EncTables) / 4; i += 64) l[i] = g[i];
+    }
     uint32_t *const seqs = a.seq_scratch + (size_t)blockIdx.x * MAX_SEQ * 3;  // {ll, ml-3, offset} per sequence
 
+    // Work cursor: one atomic per `a.batch` consecutive items (a single word saturates near 88
+    // dequeues/us on this chip, so 100k one-item dequeues alone would cost > 1 ms).
+    uint32_t next = 0, lim = 0;
     for (;;) {
-        __syncthreads();
-        if (lane == 0) s_item = atomicAdd(a.cursor, 1u);
-        __syncthreads();
-        const uint32_t item = s_item;
+        if (next == lim) {
+            __syncthreads();
+            if (lane == 0) s_item = atomicAdd(a.cursor, a.batch);
+            __syncthreads();
+            next = s_item;
+            lim = next + a.batch;
+        }
+        const uint32_t item = next++;
         if (item >= a.n_items) break;
+        __syncthreads();
         const EncItem it = a.items[item];
         if (it.flags & ITEM_SKIP) continue;  // store path: the gather pass copies it from the staging buffer
         const uint64_t rlen = a.len[it.round];
@@ -151,7 +167,11 @@ __global__ __launch_bounds__(64) void k_zstd_encode(EncodeArgs a) {
         const uint32_t max_seq = (n / 40) < MAX_SEQ ? (n / 40) : MAX_SEQ;
 
         // ---- match finding ----
-        for (uint32_t i = lane; i < HASH_SIZE; i += 64) S.table[i] = 0xFFFF;
+        {
+            uint4 *t4 = reinterpret_cast<uint4 *>(S.table);
+            const uint4 ones = make_uint4(~0u, ~0u, ~0u, ~0u);
+            for (uint32_t i = lane; i < HASH_SIZE / 8; i += 64) t4[i] = ones;
+        }
         __syncthreads();
         uint32_t nseq = 0, lit_total = 0;
         uint32_t anchor = 0;  // first byte not yet emitted
@@ -162,7 +182,7 @@ __global__ __launch_bounds__(64) void k_zstd_encode(EncodeArgs a) {
             uint32_t cand = 0, hitf = 0;
             if (pos < scan_end) {
                 const uint32_t v = ld32(in + pos);
-                const uint32_t h = hash4(v);
+                const uint32_t h = hash4<HASH_LOG>(v);
                 const uint32_t e = S.table[h];
                 S.table[h] = (uint16_t)pos;  // low 16 bits; candidates are within 64 KiB
                 if (e != 0xFFFF) {
@@ -180,29 +200,41 @@ __global__ __launch_bounds__(64) void k_zstd_encode(EncodeArgs a) {
             misses = 0;
             const uint32_t win = __ffsll((unsigned long long)hit) - 1;
             const uint32_t mpos = __shfl(pos, win), mcand = __shfl(cand, win);
-            // cooperative extension: 16 bytes per lane, 1 KiB per step
+            // cooperative extension: 16 bytes per lane per piece, 4 pieces (4 KiB) in flight per step
             uint32_t ml = 4;
             for (;;) {
-                const uint32_t o = ml + lane * 16;
-                uint32_t good = 0;  // matching bytes in my 16-byte piece
-                if (mpos + o + 16 <= n) {
-                    uint4 x = ld128(in + mpos + o), y = ld128(in + mcand + o);
-                    uint32_t d0 = x.x ^ y.x, d1 = x.y ^ y.y, d2 = x.z ^ y.z, d3 = x.w ^ y.w;
-                    if (d0) good = (__ffs(d0) - 1) >> 3;
-                    else if (d1) good = 4 + ((__ffs(d1) - 1) >> 3);
-                    else if (d2) good = 8 + ((__ffs(d2) - 1) >> 3);
-                    else if (d3) good = 12 + ((__ffs(d3) - 1) >> 3);
-                    else good = 16;
-                } else {
-                    while (good < 16 && mpos + o + good < n && in[mpos + o + good] == in[mcand + o + good]) good++;
+                uint32_t good[4];
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const uint32_t o = ml + q * 1024 + lane * 16;
+                    uint32_t g = 0;  // matching bytes in my 16-byte piece
+                    if (mpos + o + 16 <= n) {
+                        uint4 x = ld128(in + mpos + o), y = ld128(in + mcand + o);
+                        uint32_t d0 = x.x ^ y.x, d1 = x.y ^ y.y, d2 = x.z ^ y.z, d3 = x.w ^ y.w;
+                        if (d0) g = (__ffs(d0) - 1) >> 3;
+                        else if (d1) g = 4 + ((__ffs(d1) - 1) >> 3);
+                        else if (d2) g = 8 + ((__ffs(d2) - 1) >> 3);
+                        else if (d3) g = 12 + ((__ffs(d3) - 1) >> 3);
+                        else g = 16;
+                    } else {
+                        while (g < 16 && mpos + o + g < n && in[mpos + o + g] == in[mcand + o + g]) g++;
+                    }
+                    good[q] = g;
                 }
-                const uint64_t partial = __ballot(good != 16);
-                if (partial) {
-                    const uint32_t fl = __ffsll((unsigned long long)partial) - 1;
-                    ml += fl * 16 + __shfl(good, fl);
-                    break;
+                bool done = false;
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    if (done) break;
+                    const uint64_t partial = __ballot(good[q] != 16);
+                    if (partial) {
+                        const uint32_t fl = __ffsll((unsigned long long)partial) - 1;
+                        ml += fl * 16 + __shfl(good[q], fl);
+                        done = true;
+                    } else {
+                        ml += 1024;
+                    }
                 }
-                ml += 1024;
+                if (done) break;
             }
             // emit: literals [anchor, mpos) then the match
             const uint32_t ll = mpos - anchor;
@@ -244,9 +276,9 @@ __global__ __launch_bounds__(64) void k_zstd_encode(EncodeArgs a) {
                     const uint32_t mc = mlb < 128 ? c_ml_code[mlb] : (uint32_t)hib(mlb) + 36;
                     const uint32_t oc = (uint32_t)hib(ov);
                     if (i == (int32_t)nseq - 1) {
-                        sm.init(a.tabs->ml_state, a.tabs->ml_tt, 6, mc);
-                        so.init(a.tabs->of_state, a.tabs->of_tt, 5, oc);
-                        sl.init(a.tabs->ll_state, a.tabs->ll_tt, 6, lc);
+                        sm.init(S.tabs.ml_state, S.tabs.ml_tt, 6, mc);
+                        so.init(S.tabs.of_state, S.tabs.of_tt, 5, oc);
+                        sl.init(S.tabs.ll_state, S.tabs.ll_tt, 6, lc);
                     } else {
                         so.encode(b, oc);
                         sm.encode(b, mc);
@@ -338,9 +370,10 @@ __global__ __launch_bounds__(256) void k_gather(GatherArgs g) {
     }
 }
 
-void launch_encode(const EncodeArgs &a, int grid, hipStream_t s) {
+void launch_encode(const EncodeArgs &a, int grid, bool small_blocks, hipStream_t s) {
     if (!a.n_items) return;
-    hipLaunchKernelGGL(k_zstd_encode, dim3(grid), dim3(64), 0, s, a);
+    if (small_blocks) hipLaunchKernelGGL(k_zstd_encode<11>, dim3(grid), dim3(64), 0, s, a);
+    else hipLaunchKernelGGL(k_zstd_encode<13>, dim3(grid), dim3(64), 0, s, a);
 }
 
 void launch_piece_scan(const uint32_t *piece_len, uint32_t n, uint64_t *local_excl, uint64_t *block_tot, hipStream_t s) {
