@@ -30,14 +30,37 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 
 
-def build_workload(name, O, gen):
-    """Returns (entries_desc) = dict(frames=[bytes], usize=[int], repeat=n, chunk=bytes...)."""
-    if name == "c2":
-        chunk = gen.text(10 * 1024)
-        return dict(chunk=chunk, n=100_000, name="100k x 10KiB text chunks (BASELINE configs[1])")
-    if name == "c2small":
-        chunk = gen.text(10 * 1024)
-        return dict(chunk=chunk, n=2_000, name="2k x 10KiB text chunks (reduced; NOT the headline config)")
+def measured_traffic(kernel, workload):
+    """HBM bytes per launch of `kernel` from the PMC passes recorded under profiles/ (rocprofv3 --pmc
+    FETCH_SIZE and --pmc WRITE_SIZE in separate runs, FETCH_SIZE doubled per the gfx950 correction)."""
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+        return d.get(workload, {}).get(kernel)
+    except (OSError, ValueError):
+        return None
+
+
+def build_workload(name, torch):
+    """-> dict(d_src, lens, skip, name, sample): this rank's Rounds over a resident staging buffer."""
+    import gen
+    import gen_gpu
+    if name in ("c2", "c2small"):
+        n = 100_000 if name == "c2" else 2_000
+        chunk = np.frombuffer(gen.text(10 * 1024), dtype=np.uint8)
+        d_src = torch.from_numpy(np.tile(chunk, n)).cuda()
+        label = ("100k x 10KiB text chunks (BASELINE configs[1])" if name == "c2"
+                 else "2k x 10KiB text chunks (reduced; NOT the headline config)")
+        return dict(d_src=d_src, lens=np.full(n, 10240, np.uint64), skip=None, name=label)
+    if name == "c3":
+        size, sl = 2 << 30, 8 << 20
+        return dict(d_src=gen_gpu.text(size), lens=np.full(size // sl, sl, np.uint64), skip=None,
+                    name="single 2 GiB text file, 256 x 8 MiB slices (BASELINE configs[2] at the reference's slice size)")
+    if name in ("c4store", "c4codec"):
+        size, sl = 500 << 20, 8 << 20
+        lens = np.array([sl] * (size // sl) + ([size % sl] if size % sl else []), dtype=np.uint64)
+        skip = np.ones(len(lens), np.uint8) if name == "c4store" else None
+        return dict(d_src=gen_gpu.random_lcg(size), lens=lens, skip=skip,
+                    name="500 MiB LCG blob, 8 MiB slices, " + ("store path (random.jar)" if skip is not None else "codec path (random.bin)"))
     raise SystemExit(f"unknown workload {name}")
 
 
@@ -62,53 +85,39 @@ def main():
     if world > 1:
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
-    import gen
+    import gen  # noqa: F401
     from oracle import oracle as O  # checker + cpu_baseline leg only
     from znippy_amd import hip
 
-    wl = build_workload(args.workload, O, gen)
-    chunk, n = wl["chunk"], wl["n"]
-    sz = len(chunk)
+    wl = build_workload(args.workload, torch)
+    d_src, lens, skip = wl["d_src"], wl["lens"], wl["skip"]
+    n = len(lens)
+    total_in = int(lens.sum())
+    src_off = np.concatenate([[0], np.cumsum(lens)[:-1]]).astype(np.uint64)
     ctx = hip.Context(local_rank)
 
-    # ---- write side inputs: this rank's Rounds over a resident staging buffer ----
-    chunk_np = np.frombuffer(chunk, dtype=np.uint8)
-    d_src = torch.from_numpy(np.tile(chunk_np, n)).cuda()
-    src_off = np.arange(n, dtype=np.uint64) * sz
-    lens = np.full(n, sz, dtype=np.uint64)
-    rounds = hip.RoundTable(ctx, src_off, lens)
-    have_encoder = True
+    # ---- write side: this rank's Rounds over the resident staging buffer ----
+    rounds = hip.RoundTable(ctx, src_off, lens, skip)
     d_blob = torch.zeros(rounds.blob_bound() + 64, dtype=torch.uint8, device="cuda")
-    try:
-        enc = rounds.encode_hash(d_src, d_blob)
-    except Exception as e:  # encoder not built yet: fall back to CPU-made frames for the read side
-        have_encoder = False
-        enc_err = str(e)
+    enc = rounds.encode_hash(d_src, d_blob)
+    enc = {k: (v.copy() if hasattr(v, "copy") else v) for k, v in enc.items()}
+    # parity spot checks against the oracle: digests and frames of a few rounds
+    host_blob_head = None
+    for i in sorted({0, n // 2, n - 1}):
+        src_i = d_src[int(src_off[i]):int(src_off[i] + lens[i])].cpu().numpy()
+        assert enc["checksum"][i].tobytes() == O.blake3(src_i), "GPU write-side digest != oracle"
+        f = d_blob[int(enc["blob_offset"][i]):int(enc["blob_offset"][i] + enc["blob_size"][i])].cpu().numpy()
+        if enc["compressed"][i]:
+            assert O.zstd_decompress(f.tobytes()) == src_i.tobytes(), "GPU frame does not decode on the oracle"
+        else:
+            assert f.tobytes() == src_i.tobytes()
+    bo, bs, comp, ck = enc["blob_offset"], enc["blob_size"], enc["compressed"], enc["checksum"]
+    d_blobs = d_blob
+    archive_src = "gpu-encoded (this build's zstd frames)"
+    sz = int(lens[0])
 
-    want_digest = np.frombuffer(O.blake3(chunk), dtype=np.uint8)
-    if have_encoder:
-        assert (enc["checksum"] == want_digest[None, :]).all(), "GPU write-side digests != oracle"
-        bo, bs, comp = enc["blob_offset"], enc["blob_size"], enc["compressed"]
-        ck = enc["checksum"]
-        # parity spot check: frames decode with the oracle
-        host_blob = d_blob[:enc["blob_bytes"]].cpu().numpy()
-        for i in (0, n // 2, n - 1):
-            f = host_blob[int(bo[i]):int(bo[i] + bs[i])].tobytes()
-            assert O.zstd_decompress(f) == chunk, "GPU frame does not decode on the oracle"
-        d_blobs = d_blob
-        archive_src = "gpu-encoded (this build's zstd frames)"
-    else:
-        frame = np.frombuffer(O.libzstd_compress(chunk, 19), dtype=np.uint8)
-        fl = len(frame)
-        d_blobs = torch.from_numpy(np.concatenate([np.tile(frame, n), np.zeros(64, np.uint8)])).cuda()
-        bo = np.arange(n, dtype=np.uint64) * fl
-        bs = np.full(n, fl, dtype=np.uint64)
-        comp = np.ones(n, dtype=np.uint8)
-        ck = np.tile(want_digest, (n, 1))
-        archive_src = "cpu libzstd-19 frames (GPU encoder unavailable: %s)" % enc_err
-
-    out_off = np.arange(n, dtype=np.uint64) * sz
-    d_out = torch.zeros(n * sz + 64, dtype=torch.uint8, device="cuda")
+    out_off = src_off
+    d_out = torch.zeros(total_in + 64, dtype=torch.uint8, device="cuda")
     rows = hip.RowTable(ctx, bo, bs, lens, out_off, np.packbits(comp.astype(bool), bitorder="little"), ck)
 
     def barrier():
@@ -153,23 +162,23 @@ def main():
     # ---- read side (the headline) ----
     counters = read_step()
     assert counters["corrupt_rows"] == 0 and counters["decode_errors"] == 0 and \
-        counters["verified_bytes"] == n * sz, counters
-    ref = torch.from_numpy(chunk_np.copy()).cuda()
-    assert bool((d_out[:n * sz].view(n, sz)[:: max(1, n // 997)] == ref[None, :]).all()), "decoded bytes differ"
+        counters["verified_bytes"] == total_in, counters
+    assert torch.equal(d_out[:total_in], d_src[:total_in]), "decoded bytes differ from the source"
     dt_read, k_read = timed(read_step, args.steps, args.warmup)
-    dt_write, k_write = (timed(write_step, args.steps, args.warmup) if have_encoder else (None, {}))
+    dt_write, k_write = timed(write_step, args.steps, args.warmup)
 
-    total_bytes = n * sz * world
+    total_bytes = total_in * world
     mbps_read = total_bytes / 2**20 / (dt_read / args.steps)
     mbps_write = total_bytes / 2**20 / (dt_write / args.steps) if dt_write else None
 
     if rank == 0:
         # roofline of the dominant read-side kernel, algorithmic bytes per launch
         blob_bytes = int(bs.sum())
+        path_alg = blob_bytes + total_in + 57 * n        # read each blob byte, write each output byte, index columns
         alg = {
-            "zstd_decode": blob_bytes + n * sz + 57 * n,        # read frame, write output, index columns
-            "blake3_tiles": n * sz + 32 * n,                      # read every decoded byte once (unfused pass)
-            "decode_verify_fused": blob_bytes + n * sz + 57 * n,  # SURVEY §8d figure for the whole path
+            "decode_verify_fused": path_alg,             # one launch does the whole path for small rows
+            "zstd_decode_general": blob_bytes + total_in + 57 * n,
+            "blake3_second_pass": total_in + 32 * n + (0 if skip is None else total_in),  # read (+ copy on the store path)
         }
         dom = max((k for k in k_read if k in alg), key=lambda k: k_read[k]) if k_read else None
         roofline = None
@@ -179,21 +188,24 @@ def main():
             roofline = dict(bound="hbm", kernel=dom, achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit="GB/s",
                             frac=round(ach / HBM_PEAK_GBS, 4), traffic=None,
                             kernel_ms={k: round(v, 4) for k, v in k_read.items()},
-                            path_achieved=round(alg["decode_verify_fused"] / (path_ms * 1e-3) / 1e9, 1),
-                            path_frac=round(alg["decode_verify_fused"] / (path_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4))
+                            path_achieved=round(path_alg / (path_ms * 1e-3) / 1e9, 1),
+                            path_frac=round(path_alg / (path_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4))
+            tr = measured_traffic(dom, args.workload)
+            if tr is not None:
+                roofline["traffic"] = tr
         cpu = None
         if not args.no_cpu_baseline and world == 1:
             cores = len(os.sched_getaffinity(0))
             threads = max(1, int(np.ceil(0.9 * cores)))  # common_config.rs:L34 rule on what we can see
             host_blobs = d_blobs.cpu().numpy()
             bitmap = np.packbits(comp.astype(bool), bitorder="little")
-            host_out = np.zeros(n * sz, dtype=np.uint8)
+            host_out = np.zeros(total_in, dtype=np.uint8)
             t0 = time.perf_counter()
             st, _ = O.decompress_rows(host_blobs, bo, bs, lens, out_off, bitmap, ck, 0, n, out=host_out,
                                       n_threads=threads, use_libzstd=O.have_libzstd())
             dt_cpu = time.perf_counter() - t0
-            assert st["verified_bytes"] == n * sz
-            cpu = dict(value=round(n * sz / 2**20 / dt_cpu, 1), unit="MB/s", cores=threads, kind="port",
+            assert st["verified_bytes"] == total_in
+            cpu = dict(value=round(total_in / 2**20 / dt_cpu, 1), unit="MB/s", cores=threads, kind="port",
                        sample=f"all {n} rows once: oracle read loop (libzstd decode + scalar C BLAKE3), "
                               f"{threads} threads of {cores} visible cores")
         line = {
@@ -202,7 +214,8 @@ def main():
             "warmup": args.warmup, "ms_per_step": round(dt_read / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8",
             "data": "synthetic",
-            "config": {"workload": wl["name"], "rows_per_gpu": n, "chunk_bytes": sz, "archive": archive_src,
+            "config": {"workload": wl["name"], "rows_per_gpu": n, "chunk_bytes": sz, "bytes_per_gpu": total_in,
+                       "blob_bytes_per_gpu": int(bs.sum()), "archive": archive_src,
                        "parallelism": f"row-cursor ranges x{world}"},
             "compress_MBps": round(mbps_write, 1) if mbps_write else None,
             "compress_ms_per_step": round(dt_write / args.steps * 1e3, 4) if dt_write else None,

@@ -139,6 +139,7 @@ struct znippy_rows {
     uint32_t corrupt_cap = 0;
     uint32_t *list_a = nullptr;   // compressed rows with > 64 leaves: general decoder
     uint32_t n_list_a = 0;
+    bool wide_rows = false;       // big rows average >= 1 MiB: 1024-thread workgroups
     uint32_t *pending = nullptr;  // rows the fused kernel hands over (+ its counter)
     uint32_t *pending_count = nullptr;
     DevPlan plan;
@@ -365,6 +366,11 @@ int znippy_rows_create(znippy_ctx *ctx, const uint64_t *blob_offset, const uint6
     for (uint32_t i = 0; i < n; i++)
         if (comp[i] && uncompressed_size[row_begin + i] > 64 * 1024) la.push_back(i);
     r->n_list_a = (uint32_t)la.size();
+    {
+        uint64_t big_bytes = 0;
+        for (uint32_t i : la) big_bytes += uncompressed_size[row_begin + i];
+        r->wide_rows = !la.empty() && big_bytes / la.size() >= (1u << 20);
+    }
     if ((rc = dev_upload(ctx, &r->list_a, la.data(), la.size()))) {
         znippy_rows_destroy(r);
         return rc;
@@ -425,7 +431,7 @@ int znippy_decode_verify_rows_async(znippy_ctx *ctx, znippy_rows *r, const void 
         a.status = r->status; a.n_rows = r->n; a.cursor = ctx->cursor;
         a.lit_scratch = ctx->lit_scratch;
         ktime_begin(ctx, "zstd_decode_general");
-        launch_decode(a, std::min<int>(ctx->decode_grid, (int)r->n_compressed), s);
+        launch_decode(a, std::min<int>(ctx->decode_grid, (int)r->n_compressed), r->wide_rows, s);
         ktime_end(ctx);
     }
     // 3) second hash pass: slices of big rows + rows the general decoder finished

@@ -92,6 +92,6 @@ void launch_verify(const uint32_t *digests, const uint8_t *checksum, const uint6
                    const int32_t *status, uint32_t n_rows, uint64_t row_begin, uint64_t *counters,
                    uint64_t *corrupt_rows, uint32_t corrupt_cap, hipStream_t s);
 int decode_grid_size(int device);
-void launch_decode(const DecodeArgs &a, int grid, hipStream_t s);
+void launch_decode(const DecodeArgs &a, int grid, bool wide, hipStream_t s);
 
 }  // namespace zn

@@ -818,9 +818,11 @@ int decode_grid_size(int device) {
 
 size_t decode_lit_scratch_bytes(int grid) { return (size_t)grid * LIT_SCRATCH_BYTES; }
 
-void launch_decode(const DecodeArgs &a, int grid, hipStream_t s) {
+void launch_decode(const DecodeArgs &a, int grid, bool wide, hipStream_t s) {
     if (!a.n_rows) return;
-    hipLaunchKernelGGL(k_zstd_decode<4>, dim3(grid), dim3(256), 0, s, a);
+    // wide: few, multi-MiB rows -> 16 waves per row share the long copies (raw blocks, long matches)
+    if (wide) hipLaunchKernelGGL(k_zstd_decode<16>, dim3(grid), dim3(1024), 0, s, a);
+    else hipLaunchKernelGGL(k_zstd_decode<4>, dim3(grid), dim3(256), 0, s, a);
 }
 
 }  // namespace zn
