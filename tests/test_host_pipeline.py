@@ -281,3 +281,48 @@ def test_skip_extension_list():  # index.rs:L470-488
         assert ix.should_skip_compression(name), name
     for name in ("a.txt", "noext", ".gz", "a.gz.txt", "dir.zip/readme", "pom.xml", "random.bin"):
         assert not ix.should_skip_compression(name), name
+
+
+# ─── Directory compressor tests (integration_test.rs:L228-354) ─────────────────────────────────
+def _mk_tree(root, files):
+    for rel, data in files.items():
+        p = root / rel
+        p.parent.mkdir(parents=True, exist_ok=True)
+        p.write_bytes(data)
+
+
+def test_compress_dir_basic_and_mixed(backend, tmp_path, tmp_path_factory):  # L228-299
+    from znippy_amd.slot_packer import compress_dir
+    src = tmp_path / "in"
+    files = {"a.txt": b"alpha " * 100, "sub/b.txt": b"beta " * 300, "sub/deep/c.bin": gen.binary(5000),
+             "img.png": gen.incompressible(1, 2000), "empty.txt": b""}
+    _mk_tree(src, files)
+    report = compress_dir(src, tmp_path / "out.znippy", False, backend=backend)
+    assert report.total_files == 5 and report.uncompressed_files == 1 and report.compressed_files == 4
+    assert report.chunks == 5 and report.total_dirs == 3
+    out = decompress_to_map(tmp_path / "out.znippy", backend, tmp_path_factory)
+    assert out == files
+    _, batches = ix.read_znippy_index(str(tmp_path / "out.znippy"))
+    rows = {p: (s, f) for p, s, f in zip(batches[0].column(0).to_pylist(), batches[0].column(1).to_pylist(),
+                                         batches[0].column(2).to_pylist())}
+    assert all(v == (0, 0) for v in rows.values())      # small files: chunk_seq = fdata_offset = 0 (L499)
+
+
+def test_compress_dir_slots_round_trip(backend, tmp_path, tmp_path_factory):  # L301-354
+    from znippy_amd import index as ix2
+    from znippy_amd.slot_packer import compress_dir
+    src = tmp_path / "in"
+    files = {f"small/f{i:02}.txt": gen.pseudo_text(500 + 37 * i, seed=i) for i in range(50)}
+    files["nested/a/b/c.txt"] = b"nested"
+    files["archive.gz"] = gen.incompressible(3, 4096)
+    files["empty.dat"] = b""
+    files["big.bin"] = gen.binary(8 * 1024 * 1024)
+    _mk_tree(src, files)
+    cfg = ix2.StrategicConfig(max_core_in_flight=64)   # slice_size = 200 MiB / 64 = 3.125 MiB -> big.bin is cut
+    report = compress_dir(src, tmp_path / "slots", False, repo="r", backend=backend, config=cfg)
+    assert report.total_files == len(files)
+    assert report.chunks == len(files) - 1 + 3          # big.bin -> 3 slices
+    out = decompress_to_map(tmp_path / "slots.znippy", backend, tmp_path_factory)
+    assert out == files
+    m = ix.read_znippy_manifest(str(tmp_path / "slots.znippy"))
+    assert len(m) == 1 and (m[0].pkg_type, m[0].repo, m[0].row_count) == (0, "r", report.chunks)
