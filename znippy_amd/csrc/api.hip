@@ -14,6 +14,8 @@
 
 namespace zn {
 size_t decode_lit_scratch_bytes(int grid);
+void set_fused_dbg(unsigned long long *p);
+void set_fused_abl(int v);
 }  // namespace zn
 
 using namespace zn;
@@ -412,7 +414,20 @@ int znippy_decode_verify_rows_async(znippy_ctx *ctx, znippy_rows *r, const void 
         f.blob_size = r->blob_size; f.out_cap = out_cap; f.status = r->status;
         f.pending = r->pending; f.pending_count = r->pending_count;
         { const char *e = getenv("ZNIPPY_DBG"); f.dbg = e ? atoi(e) : 0; }
+        if (f.dbg & 8) {  // diagnostic: print the previous launch's phase stamps, then reset them
+            static unsigned long long *dbg = nullptr;
+            if (!dbg) { (void)hipMalloc(&dbg, 64); (void)hipMemset(dbg, 0, 64); }
+            unsigned long long h4[8];
+            (void)hipStreamSynchronize(s);
+            (void)hipMemcpy(h4, dbg, 64, hipMemcpyDeviceToHost);
+            if (h4[3]) fprintf(stderr, "[znippy dbg] waves=%llu prologue=%.0f decode=%.0f hash=%.0f | parse+lits=%.0f expand-build=%.0f stream-out=%.0f after-match=%.0f cycles/wave\n", h4[3],
+                               (double)h4[0] / h4[3], (double)h4[1] / h4[3], (double)h4[2] / h4[3], (double)h4[6] / h4[3], (double)h4[4] / h4[3], (double)h4[5] / h4[3], (double)h4[7] / h4[3]);
+            set_fused_dbg(dbg);
+            (void)hipMemset(dbg, 0, 64);
+            f.dbg_buf = dbg;
+        }
         { const char *e = getenv("ZNIPPY_STAGGER"); f.stagger = e ? (uint32_t)atoi(e) : 0; }
+        if (f.dbg & (16 | 32 | 64)) set_fused_abl(f.dbg);
         { const char *e = getenv("ZNIPPY_LDS_PAD"); f.lds_pad = e ? (uint32_t)atoi(e) : 0; }
         ktime_begin(ctx, "decode_verify_fused");
         launch_fused_small(f, s);

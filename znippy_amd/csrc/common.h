@@ -80,6 +80,7 @@ struct FusedArgs {
     uint32_t *pending;
     uint32_t *pending_count;
     int dbg;  // diagnostic builds only (ZNIPPY_DBG): 1 = skip hash, 2 = skip decode
+    unsigned long long *dbg_buf;  // diagnostic stamps (ZNIPPY_DBG & 8)
     uint32_t lds_pad;  // extra dynamic LDS per block: caps blocks/CU (in-flight footprint vs Infinity Cache)
     uint32_t stagger;  // start-up skew per hardware wave slot, in units of 127*64 cycles
 };

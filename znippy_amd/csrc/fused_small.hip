@@ -20,7 +20,7 @@
 
 namespace zn {
 
-constexpr uint32_t EOFF_MAX = 2048;             // longest period expanded in LDS
+constexpr uint32_t EOFF_MAX = 1024;             // longest period expanded in LDS
 constexpr uint32_t EBUF = EOFF_MAX + 1024 + 64; // pattern buffer per wave
 constexpr int F_E_CORRUPT = -5, F_E_UNSUP = -6, F_E_DST = -4;
 constexpr int F_NOT_SIMPLE = 1;
@@ -104,10 +104,23 @@ void init_fused_tables() {
     (void)hipMemcpyToSymbol(HIP_SYMBOL(c_dof), to, sizeof to);
 }
 
+__device__ int g_abl = 0;  // diagnostic ablations (ZNIPPY_DBG bits 16/32/64), never set in normal runs
+// diagnostic stamp accumulators (ZNIPPY_DBG & 8 only): per-wave LDS slots, flushed once at the end
+#define STAMP_BEGIN() unsigned long long st__ = acc ? __builtin_amdgcn_s_memtime() : 0
+#define STAMP_BEGIN2() st__ = acc ? __builtin_amdgcn_s_memtime() : 0
+#define STAMP_END(slot)                                                        \
+    do {                                                                       \
+        if (acc) {                                                             \
+            unsigned long long e__ = __builtin_amdgcn_s_memtime();             \
+            if ((threadIdx.x & 63) == 0) acc[slot] += e__ - st__;              \
+            st__ = e__;                                                        \
+        }                                                                      \
+    } while (0)
+
 // ---- device helpers ---------------------------------------------------------------------------------
-constexpr uint32_t WIN = 256;       // bytes of every row's frame staged in LDS by the tile prologue
-constexpr uint32_t WROWS = 8;       // rows per tile that get a staged window (others load on demand)
-constexpr uint32_t WSTRIDE = WIN + 32;
+constexpr uint32_t WIN = 512;       // bytes of every row's frame staged in LDS by the tile prologue
+constexpr uint32_t WROWS = 6;       // rows per tile that get a staged window (others load on demand)
+constexpr uint32_t WSTRIDE = WIN + 96;  // + slack: 16-byte over-reads and the 64 period bytes appended for hashing
 
 __device__ __forceinline__ uint32_t uni(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
 __device__ __forceinline__ int fhib(uint32_t v) { return 31 - __clz(v); }
@@ -131,7 +144,7 @@ __device__ __forceinline__ uint32_t smod(uint32_t a, uint32_t b) {
 // scalar parsing, a 256-byte register window (lane l = dword l of [wbase, wbase+256)).
 struct FrameWin {
     const uint8_t *src;  // global
-    const uint8_t *wl;   // LDS copy of the first WIN bytes, or nullptr
+    uint8_t *wl;         // LDS copy of the first WIN bytes, or nullptr
     uint32_t n, wbase, w;
     __device__ __forceinline__ void load(uint32_t base) {
         const uint32_t lane = threadIdx.x & 63;
@@ -238,7 +251,8 @@ __device__ __forceinline__ void fwave_fill(uint8_t *dst, uint8_t byte, uint32_t 
 // doubling inside LDS (ds ops of one wave are ordered), then streamed out 1 KiB per step with
 // 16-byte aligned stores; head and tail bytes go out lane-parallel.
 __device__ __forceinline__ void fwave_expand(uint8_t *dst, const uint8_t *pg, const uint8_t *pl, uint32_t off,
-                                             uint32_t ml, uint8_t *E, uint32_t lane) {
+                                             uint32_t ml, uint8_t *E, uint32_t lane, unsigned long long *acc) {
+    STAMP_BEGIN();
     // 1) the period itself into E (16-byte pieces may spill up to 15 bytes; rewritten below)
     if (pl) {
         for (uint32_t i = lane * 16; i < off; i += 1024) {
@@ -266,6 +280,8 @@ __device__ __forceinline__ void fwave_expand(uint8_t *dst, const uint8_t *pg, co
         }
         w += c;
     }
+    STAMP_END(4);
+    if (g_abl & 16) return;  // ablation: no stream-out
     // 3) stream out
     const uint32_t head = (uint32_t)((16 - ((uintptr_t)dst & 15)) & 15);
     if (ml < head + 16) {  // too short for an aligned piece
@@ -294,13 +310,14 @@ __device__ __forceinline__ void fwave_expand(uint8_t *dst, const uint8_t *pg, co
     }
     const uint32_t tail = rem & 15, tbase = full16 * 16;
     if (lane < tail) dst[x + tbase + lane] = E[s + tbase + lane];
+    STAMP_END(5);
 }
 
 // LZ match of the fused path: dst[i] = dst[i - off].  `pl`/`pg_fwd`: the period forwarded from
 // the frame's literals when it lies inside the literal run just copied (no read-after-write
 // through memory); otherwise the period is re-read from the output after a store drain.
 __device__ __forceinline__ void fwave_match(uint8_t *dst, const uint8_t *pg_fwd, const uint8_t *pl, uint32_t off,
-                                            uint32_t ml, uint8_t *E, uint32_t lane) {
+                                            uint32_t ml, uint8_t *E, uint32_t lane, unsigned long long *acc) {
     const uint8_t *pg = pg_fwd;
     if (!pg && !pl) {
         fwave_mem_sync();  // earlier output of this wave must have landed before it is re-read
@@ -312,7 +329,7 @@ __device__ __forceinline__ void fwave_match(uint8_t *dst, const uint8_t *pg_fwd,
         return;
     }
     if (off <= EOFF_MAX) {
-        fwave_expand(dst, pg, pl, off, ml, E, lane);
+        if (!(g_abl & 32)) fwave_expand(dst, pg, pl, off, ml, E, lane, acc);
         return;
     }
     // long period + overlap (rare in small rows): byte-parallel modulo copy from the final period
@@ -321,8 +338,14 @@ __device__ __forceinline__ void fwave_match(uint8_t *dst, const uint8_t *pg_fwd,
 }
 
 // Decode one simple frame with the calling wave.  Returns 0, F_NOT_SIMPLE or a negative error.
+struct Periodic {  // row = literal prefix + ONE overlapping match to the end (hashable from LDS)
+    uint32_t ok, lit_at, L0, off;
+};
+
 __device__ int decode_simple(const uint8_t *src, uint32_t n, uint8_t *out, uint64_t usize, uint8_t *E,
-                             const uint8_t *wl) {
+                             uint8_t *wl, Periodic *per, unsigned long long *acc) {
+    per->ok = 0;
+    STAMP_BEGIN();
     const uint32_t lane = threadIdx.x & 63;
     FrameWin W;
     W.src = src; W.n = n; W.wl = wl;
@@ -485,10 +508,20 @@ __device__ int decode_simple(const uint8_t *src, uint32_t n, uint8_t *out, uint6
                     if (offset <= ll) {
                         if (ltype == 0) {
                             const uint32_t pat_at = lit_at + lit_pos - offset;
-                            fwave_match(out + opos, src + pat_at, W.lds(pat_at, offset), offset, ml, E, lane);
+                            const uint8_t *pl = W.lds(pat_at, offset);
+                            STAMP_END(6);
+                            fwave_match(out + opos, src + pat_at, pl, offset, ml, E, lane, acc);
+                            STAMP_BEGIN2();
+                            // whole row = these literals + this one periodic match: keep out[0..L0+64) in LDS
+                            // (the literals are already staged; 64 more bytes of the period come from E)
+                            if (pl && nseq == 1 && last && opos == ll && ll == regen && (uint64_t)ll + ml == osize &&
+                                offset < ml && offset <= EOFF_MAX && ml >= 64 && lit_at + ll + 64 <= WSTRIDE) {
+                                W.wl[lit_at + ll + lane] = E[lane];
+                                per->ok = 1; per->lit_at = lit_at; per->L0 = ll; per->off = offset;
+                            }
                         } else fwave_fill(out + opos, (uint8_t)rle_byte, ml, lane);
                     } else {
-                        fwave_match(out + opos, nullptr, nullptr, offset, ml, E, lane);
+                        fwave_match(out + opos, nullptr, nullptr, offset, ml, E, lane, acc);
                     }
                     opos += ml;
                 }
@@ -509,12 +542,13 @@ __device__ int decode_simple(const uint8_t *src, uint32_t n, uint8_t *out, uint6
         }
         if (last) break;
     }
+    STAMP_END(7);
     if (opos != osize) return F_E_CORRUPT;
     if (has_ck && pos + 4 > n) return F_E_CORRUPT;
     return 0;
 }
 
-__global__ __launch_bounds__(256) void k_fused_small(FusedArgs a) {
+__global__ __launch_bounds__(256, 4) void k_fused_small(FusedArgs a) {
     __shared__ __attribute__((aligned(16))) uint8_t s_E[4][EBUF];
     __shared__ __attribute__((aligned(16))) uint8_t s_W[4][WROWS * WSTRIDE];
     const uint32_t lane = threadIdx.x & 63;
@@ -524,6 +558,11 @@ __global__ __launch_bounds__(256) void k_fused_small(FusedArgs a) {
     if (t.n_units == 0) return;  // slices of big rows: general decoder + second hash pass
     uint8_t *const E = s_E[threadIdx.x >> 6];
     uint8_t *const WL = s_W[threadIdx.x >> 6];
+    const bool stamp = (a.dbg & 8) && a.dbg_buf;  // diagnostic only: phase durations -> a.dbg_buf (never an output)
+    __shared__ unsigned long long s_acc[4][8];
+    if (lane < 8) s_acc[threadIdx.x >> 6][lane] = 0;
+    unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0;
+    if (stamp) t0 = __builtin_amdgcn_s_memtime();
 
     // Stagger: waves sharing a SIMD run the same decode(memory)->hash(VALU) program and fall into
     // lockstep (all waiting, then all contending for VALU).  Delaying the wave in hardware slot k by
@@ -545,33 +584,45 @@ __global__ __launch_bounds__(256) void k_fused_small(FusedArgs a) {
         c_oo = a.h.offB[row];
         c_bs = (uint32_t)a.blob_size[row];
     }
+    __shared__ uint16_t s_desc[4][3][WROWS];  // per wave: ybase, B, off of each staged row
+    uint16_t *const d_y = s_desc[threadIdx.x >> 6][0], *const d_B = s_desc[threadIdx.x >> 6][1],
+                   *const d_off = s_desc[threadIdx.x >> 6][2];
+    __shared__ int32_t s_st[4][64];  // per wave: status of each row of the tile (0 = hash it)
+    int32_t *const l_st = s_st[threadIdx.x >> 6];
+    if (lane < WROWS) d_y[lane] = 0xFFFF;
+    l_st[lane] = 0;
+    uint32_t need_reread = 0;  // some compressed row of the tile must be hashed from its global output
     if (!(a.dbg & 2)) {
         const uint32_t nw = t.n_units < WROWS ? t.n_units : WROWS;
-        uint32_t wv[WROWS];
+        uint2 wv[WROWS];
 #pragma unroll
         for (uint32_t u = 0; u < WROWS; u++) {
-            wv[u] = 0;
+            wv[u] = make_uint2(0, 0);
             if (u < nw) {
                 const uint64_t so = __shfl(c_src, u);
-                const uint32_t n = __shfl(c_bs, u), o = 4 * lane;
+                const uint32_t n = __shfl(c_bs, u), o = 8 * lane;
                 const uint8_t *p = a.h.srcA + so + o;
                 if (__shfl(c_sel, u)) {
-                    if (o + 4 <= n) __builtin_memcpy(&wv[u], p, 4);
-                    else
-                        for (uint32_t k = 0; k < 4; k++)
-                            if (o + k < n) wv[u] |= (uint32_t)p[k] << (8 * k);
+                    if (o + 8 <= n) __builtin_memcpy(&wv[u], p, 8);
+                    else {
+                        uint64_t v = 0;
+                        for (uint32_t k = 0; k < 8; k++)
+                            if (o + k < n) v |= (uint64_t)p[k] << (8 * k);
+                        wv[u] = make_uint2((uint32_t)v, (uint32_t)(v >> 32));
+                    }
                 }
             }
         }
 #pragma unroll
         for (uint32_t u = 0; u < WROWS; u++) {
             if (u < nw) {
-                *reinterpret_cast<uint32_t *>(WL + u * WSTRIDE + 4 * lane) = wv[u];
-                if (lane < 8) *reinterpret_cast<uint32_t *>(WL + u * WSTRIDE + WIN + 4 * lane) = 0;  // padding
+                *reinterpret_cast<uint2 *>(WL + u * WSTRIDE + 8 * lane) = wv[u];
+                if (lane < (WSTRIDE - WIN) / 4) *reinterpret_cast<uint32_t *>(WL + u * WSTRIDE + WIN + 4 * lane) = 0;
             }
         }
     }
 
+    if (stamp) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); t1 = __builtin_amdgcn_s_memtime(); }
     for (uint32_t u = 0; u < t.n_units && !(a.dbg & 2); u++) {
         const uint32_t row = t.first_unit + u;
         if (!uni(__shfl(c_sel, u))) continue;  // stored row: copied while it is hashed below
@@ -580,17 +631,50 @@ __global__ __launch_bounds__(256) void k_fused_small(FusedArgs a) {
         const uint64_t soff = ((uint64_t)uni((uint32_t)(__shfl(c_src, u) >> 32)) << 32) | uni((uint32_t)__shfl(c_src, u));
         const uint32_t bsz = uni(__shfl(c_bs, u));
         int rc;
+        Periodic per;
+        per.ok = 0;
         if (ooff + usize > a.out_cap) rc = F_E_DST;
-        else rc = decode_simple(a.h.srcA + soff, bsz, a.h.srcB + ooff, usize, E, u < WROWS ? WL + u * WSTRIDE : nullptr);
+        else rc = decode_simple(a.h.srcA + soff, bsz, a.h.srcB + ooff, usize, E, u < WROWS ? WL + u * WSTRIDE : nullptr, &per,
+                                stamp ? s_acc[threadIdx.x >> 6] : nullptr);
         rc = (int)uni((uint32_t)rc);
+        const bool periodic = rc == 0 && uni(per.ok) && u < WROWS && !(a.dbg & 4);
+        if (periodic) {
+            if (lane == 0) {
+                d_y[u] = (uint16_t)(u * WSTRIDE + per.lit_at);
+                d_B[u] = (uint16_t)(per.L0 - per.off);
+                d_off[u] = (uint16_t)per.off;
+            }
+        } else if (rc == 0) {
+            need_reread = 1;
+        }
         if (rc != 0 && lane == 0) {
             a.status[row] = rc;
+            l_st[u] = rc;
             if (rc == F_NOT_SIMPLE) a.pending[atomicAdd(a.pending_count, 1u)] = row;
         }
     }
-    fwave_mem_sync();  // decoded bytes + status words have landed (same CU: visible to this wave's loads)
-    if (!(a.dbg & 1)) hash_tile<true>(a.h, t);
+    // Rows hashed from LDS do not depend on their stores having landed, so the store queue drains
+    // in the background while this wave hashes.  Only a global re-read needs the drain.
+    if (need_reread) fwave_mem_sync();
+    if (stamp) t2 = __builtin_amdgcn_s_memtime();
+    if (!(a.dbg & 1)) {
+        LdsSrc ls{WL, d_y, d_B, d_off, WROWS, l_st, c_len, c_src, c_oo, c_sel};
+        hash_tile<true, true>(a.h, t, &ls);
+    }
+    if (stamp) {
+        t3 = __builtin_amdgcn_s_memtime();
+        if (lane == 0) {
+            atomicAdd(&a.dbg_buf[0], t1 - t0);
+            atomicAdd(&a.dbg_buf[1], t2 - t1);
+            atomicAdd(&a.dbg_buf[2], t3 - t2);
+            atomicAdd(&a.dbg_buf[3], 1ull);
+            for (int q = 4; q < 8; q++) atomicAdd(&a.dbg_buf[q], s_acc[threadIdx.x >> 6][q]);
+        }
+    }
 }
+
+void set_fused_dbg(unsigned long long *) {}
+void set_fused_abl(int v) { (void)hipMemcpyToSymbol(HIP_SYMBOL(g_abl), &v, sizeof v); }
 
 void launch_fused_small(const FusedArgs &a, hipStream_t s) {
     if (!a.h.n_tiles) return;

@@ -78,16 +78,33 @@ __device__ __forceinline__ void fold_segments(uint32_t cv[8], uint32_t s, uint32
 //   PASS_SECOND big-unit slices (status >= 0) and small-tile units the general decoder finished (status == 2)
 enum { PASS_ALL = 0, PASS_FUSED = 1, PASS_SECOND = 2 };
 
+// Optional on-chip source for the fused kernel: rows whose whole output is "literal prefix + one
+// periodic match" are hashed from LDS (the staged literals followed by 64 bytes of the period),
+// so their decoded bytes are written to HBM once and never read back.
+//   out[i] = Y[i]                          for i <  B + off + 64   (Y = ybase .. in LDS)
+//   out[i] = Y[B + ((i - B) mod off)]      for i >= B              (period `off` starts at B)
+struct LdsSrc {
+    const uint8_t *wl;        // this wave's staged windows
+    const uint16_t *ybase;    // per tile-local row: offset of Y in wl, 0xFFFF = not periodic
+    const uint16_t *pB, *poff;
+    uint32_t rows;            // rows that have descriptors
+    const int32_t *st;        // per tile-local row status kept on-chip (replaces the global status read)
+    // the tile's index columns as loaded by the prologue, lane u = row u of the tile: with these the
+    // hash issues no global load of its own, so it never queues behind the decode's pending stores
+    uint64_t c_len, c_src, c_oo;
+    uint32_t c_sel;
+};
+
 // Hash one tile with the calling wavefront.  Every lane of the wave must call it.
-template <bool COPY>
-__device__ __forceinline__ void hash_tile(const HashArgs &a, const Tile &t) {
+template <bool COPY, bool LDSRC = false>
+__device__ __forceinline__ void hash_tile(const HashArgs &a, const Tile &t, const LdsSrc *ls = nullptr) {
     const uint32_t lane = threadIdx.x & 63;
-    uint32_t unit, k, unit_leaves, seg_start;
+    uint32_t unit, k, unit_leaves, seg_start, local = 0xFFFFFFFFu;
     bool active = lane < t.n_leaves;
     if (t.n_units) {
         uint32_t cnt = 0;
         if (lane < t.n_units) {
-            uint64_t L = a.len[t.first_unit + lane];
+            uint64_t L = LDSRC ? ls->c_len : a.len[t.first_unit + lane];
             cnt = L ? (uint32_t)((L + 1023) >> 10) : 1u;
         }
         uint32_t inc = cnt;
@@ -110,6 +127,7 @@ __device__ __forceinline__ void hash_tile(const HashArgs &a, const Tile &t) {
         unit_leaves = __shfl(cnt, i);
         seg_start = __shfl(inc, i) - unit_leaves;
         unit = t.first_unit + i;
+        local = i;
         k = lane - seg_start;
     } else {
         unit = t.first_unit;
@@ -119,15 +137,28 @@ __device__ __forceinline__ void hash_tile(const HashArgs &a, const Tile &t) {
     }
     if (!active) { unit = t.first_unit; k = 0; }
     if (a.pass != PASS_ALL) {
-        const int32_t st = a.status[unit];
+        const int32_t st = (LDSRC && t.n_units) ? ls->st[local < 64 ? local : 0] : a.status[unit];
         if (a.pass == PASS_FUSED) active = active && st == 0;
         else active = active && (t.n_units ? st == 2 : st >= 0);
     }
 
-    const uint64_t ulen = a.len[unit];
-    const bool from_b = a.sel && a.sel[unit];
-    const uint8_t *src = from_b ? a.srcB + a.offB[unit] : a.srcA + (a.offA[unit] - a.baseA);
-    uint8_t *dst = (COPY && !from_b && a.srcB) ? a.srcB + a.offB[unit] : nullptr;
+    uint64_t ulen;
+    bool from_b;
+    const uint8_t *src;
+    uint8_t *dst;
+    if (LDSRC && t.n_units) {  // columns from the prologue's registers (row = lane `local`)
+        const uint32_t li = local < 64 ? local : 0;
+        ulen = __shfl(ls->c_len, li);
+        from_b = __shfl(ls->c_sel, li) != 0;
+        const uint64_t so = __shfl(ls->c_src, li), oo = __shfl(ls->c_oo, li);
+        src = from_b ? a.srcB + oo : a.srcA + so;
+        dst = (COPY && !from_b && a.srcB) ? a.srcB + oo : nullptr;
+    } else {
+        ulen = a.len[unit];
+        from_b = a.sel && a.sel[unit];
+        src = from_b ? a.srcB + a.offB[unit] : a.srcA + (a.offA[unit] - a.baseA);
+        dst = (COPY && !from_b && a.srcB) ? a.srcB + a.offB[unit] : nullptr;
+    }
     const uint64_t leaf_off = (uint64_t)k << 10;
     uint32_t leaf_len = 0;
     if (active && ulen > leaf_off) leaf_len = (uint32_t)((ulen - leaf_off) < 1024 ? (ulen - leaf_off) : 1024);
@@ -142,16 +173,44 @@ __device__ __forceinline__ void hash_tile(const HashArgs &a, const Tile &t) {
     if (__ballot(active && leaf_len != 1024) == 0ull) {
         // fast path (wave-uniform): every active lane owns a full 1 KiB leaf -> 16 full blocks,
         // next block's 64 bytes are in flight while the current one is compressed
+        // per-lane on-chip source (fused kernel, periodic rows): Y holds out[0 .. L0+64), L0 = B + off
+        const uint8_t *Y = nullptr;
+        uint32_t yB = 0, yoff = 1, yL0 = 0, r = 0, step64 = 0;
+        if (LDSRC && active && local < ls->rows && ls->ybase[local] != 0xFFFF) {
+            Y = ls->wl + ls->ybase[local];
+            yB = ls->pB[local];
+            yoff = ls->poff[local];
+            yL0 = yB + yoff;
+            const uint32_t p0 = (uint32_t)leaf_off;
+            const uint32_t p1 = p0 > yL0 ? p0 : ((yL0 >> 6) + 1) << 6;  // first block read through the period
+            r = (p1 - yB) % yoff;
+            step64 = 64 % yoff;
+        }
         if (active) {
-            uint4 n0 = ld16(src), n1 = ld16(src + 16), n2 = ld16(src + 32), n3 = ld16(src + 48);
+            uint4 n0, n1, n2, n3;
+            uint32_t p = (uint32_t)leaf_off;  // row position of the next block (LDS path)
+            auto fetch = [&](uint32_t b) {
+                if (LDSRC && Y) {
+                    const uint8_t *q = Y + p;
+                    if (p > yL0) {
+                        q = Y + yB + r;
+                        r += step64;
+                        if (r >= yoff) r -= yoff;
+                    }
+                    __builtin_memcpy(&n0, q, 16); __builtin_memcpy(&n1, q + 16, 16);
+                    __builtin_memcpy(&n2, q + 32, 16); __builtin_memcpy(&n3, q + 48, 16);
+                    p += 64;
+                } else {
+                    const uint8_t *q = src + b * 64;
+                    n0 = ld16(q); n1 = ld16(q + 16); n2 = ld16(q + 32); n3 = ld16(q + 48);
+                }
+            };
+            fetch(0);
 #pragma unroll 1
             for (uint32_t b = 0; b < 16; b++) {
                 uint32_t m[16] = {n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, n1.z, n1.w,
                                   n2.x, n2.y, n2.z, n2.w, n3.x, n3.y, n3.z, n3.w};
-                if (b < 15) {
-                    const uint8_t *q = src + (b + 1) * 64;
-                    n0 = ld16(q); n1 = ld16(q + 16); n2 = ld16(q + 32); n3 = ld16(q + 48);
-                }
+                if (b < 15) fetch(b + 1);
                 if (COPY && dst) {
                     uint8_t *d = dst + b * 64;
                     st16(d, make_uint4(m[0], m[1], m[2], m[3]));
