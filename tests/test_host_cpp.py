@@ -1,0 +1,155 @@
+"""The compiled host layer (csrc/host/*.cpp, include/znippy_host.h).
+
+CPU part (-m "not gpu"): the hand-written Arrow IPC writer/reader against pyarrow — what C++ writes
+pyarrow must read back identically (schema, metadata, values) and what pyarrow writes C++ must read.
+GPU part: compress_stream / decompress_archive / ZnippyArchive through the C ABI, cross-checked with
+the Python mirror (pyarrow index I/O) in both directions.
+"""
+import os
+import re
+import struct
+
+import numpy as np
+import pyarrow as pa
+import pytest
+
+import gen
+from znippy_amd import index as ix
+
+
+def test_header_symbols_exported():
+    import __graft_entry__ as g
+    g.build()
+    from znippy_amd import host
+    L = host.lib()
+    hdr = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "znippy_host.h")).read()
+    declared = set(re.findall(r"\b(znippy_[a-z0-9_]+)\s*\(", hdr))
+    assert declared == set(host.HOST_EXPORTS), declared ^ set(host.HOST_EXPORTS)
+    for n in declared:
+        assert hasattr(L, n), n
+
+
+def test_manifest_written_by_cpp_is_read_by_pyarrow_and_back():
+    from znippy_amd import host
+    entries = [ix.ManifestEntry(1, "central", "maven", 0, 1024, 42), ix.ManifestEntry(2, "crates-io", "cargo", 1024, 512, 17),
+               ix.ManifestEntry(-3, "", "", 2**40, 7, 0)]
+    b = host.write_manifest_bytes(entries)
+    assert ix.read_manifest_bytes(b) == entries                      # pyarrow parses the C++ stream
+    r = pa.ipc.open_stream(pa.py_buffer(b))
+    assert r.schema.equals(ix.manifest_schema())
+    assert host.write_manifest_bytes([]) and ix.read_manifest_bytes(host.write_manifest_bytes([])) == []
+    # framing per the IPC spec / arrow-rs defaults: continuation marker, 64-byte aligned messages, EOS marker
+    assert b[:4] == b"\xff\xff\xff\xff" and b[-8:] == b"\xff\xff\xff\xff\x00\x00\x00\x00"
+    meta_len = struct.unpack("<i", b[4:8])[0]
+    assert (8 + meta_len) % 64 == 0
+
+
+def test_interpret_footer_cpp():
+    from znippy_amd import host
+    assert host.interpret_footer(struct.pack("<Q", 12345)) == ("single", 12345)
+    assert host.interpret_footer(ix.MULTI_INDEX_MAGIC + struct.pack("<Q", 99999)) == ("multi", 99999)
+
+
+def test_cpp_index_reader_reads_pyarrow_written_archive(tmp_path, oracle):
+    """Archive written by the Python mirror (pyarrow IPC) with the checker backend, read by the C++ reader."""
+    from oracle_backend import OracleBackend
+    from znippy_amd import host
+    from znippy_amd.stream_packer import ArchiveEntry, compress_stream
+    c = compress_stream(tmp_path / "a.znippy", False, backend=OracleBackend())
+    ents = [ArchiveEntry("pom.xml", b"<project/>" * 50, 1, "maven"), ArchiveEntry("lib.jar", gen.incompressible(1, 5000), 1, "maven"),
+            ArchiveEntry("Cargo.toml", b"[package]", 2, "cargo"), ArchiveEntry("empty", b""),
+            ArchiveEntry("big.bin", gen.binary(9 * 1024 * 1024))]
+    for e in ents:
+        c.sender().send(e)
+    c.finish()
+    rows, manifest, md = host.read_index(tmp_path / "a.znippy")
+    _, batches = ix.read_znippy_index(str(tmp_path / "a.znippy"))
+    want = batches[0].to_pylist()
+    assert len(rows) == len(want) == 6
+    for a, b in zip(rows, want):
+        assert a == b
+    assert manifest == ix.read_znippy_manifest(str(tmp_path / "a.znippy"))
+    assert md["znippy_format_version"] == "3" and "compression_level" in md and "checksum_group_0" not in md
+
+
+gpu = pytest.mark.gpu
+
+
+@gpu
+def test_cpp_compress_stream_roundtrip_and_cross_read(tmp_path):
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from znippy_amd import host
+    from znippy_amd.decompress import decompress_archive as py_decompress
+    from znippy_amd.stream_packer import ArchiveEntry
+    ents = [ArchiveEntry("hello.txt", b"Hello, Znippy! This is a small test file."),
+            ArchiveEntry("sub/dir/text.txt", gen.pseudo_text(200000, seed=4)), ArchiveEntry("image.png", gen.incompressible(2, 30000)),
+            ArchiveEntry("empty.txt", b""), ArchiveEntry("large.bin", gen.binary(12 * 1024 * 1024)),
+            ArchiveEntry("pom.xml", gen.text(10240), 1, "maven"), ArchiveEntry("Cargo.toml", b"[package]", 2, "cargo")]
+    c = host.compress_stream(tmp_path / "cpp.tmp", False)
+    for e in ents:
+        c.sender().send(e)
+    rep = c.finish()
+    archive = tmp_path / "cpp.znippy"                                      # extension forced (stream_packer.rs:L132)
+    assert archive.exists()
+    assert (rep.total_files, rep.uncompressed_files, rep.compressed_files) == (7, 1, 6)
+    assert rep.chunks == 8 and rep.total_bytes_in == sum(len(e.data) for e in ents)
+    assert rep.total_bytes_out == archive.stat().st_size
+    # pyarrow reads what C++ wrote: schema, metadata, groups, rows
+    schema, batches = ix.read_znippy_index(str(archive))
+    assert schema.names == ix.znippy_index_schema().names
+    assert all(not f.nullable for f in schema)
+    md = {k.decode(): v.decode() for k, v in schema.metadata.items()}
+    assert md["znippy_format_version"] == "3" and len(md) == 9 and "compression_level" in md
+    manifest = ix.read_znippy_manifest(str(archive))
+    assert [(m.pkg_type, m.repo, m.row_count) for m in manifest] == [(0, "", 6), (1, "maven", 1), (2, "cargo", 1)]
+    raw = archive.read_bytes()
+    assert raw[-16:-8] == b"ZNPYMIDX"
+    # the Python mirror (pyarrow + HIP backend) decodes the C++-written archive
+    rep_py = py_decompress(archive, True, tmp_path / "out_py")
+    assert (rep_py.corrupt_files, rep_py.total_files, rep_py.chunks) == (0, 7, 8)
+    for e in ents:
+        assert (tmp_path / "out_py" / e.relative_path).read_bytes() == e.data
+    # and the C++ reader decodes it too; reports agree
+    rep_cpp = host.decompress_archive(archive, True, tmp_path / "out_cpp")
+    assert rep_cpp == rep_py
+    for e in ents:
+        assert (tmp_path / "out_cpp" / e.relative_path).read_bytes() == e.data
+    # verify-only path and per-rank split
+    v = host.decompress_archive(archive, False, "/dev/null")
+    assert (v.total_files, v.corrupt_files, v.total_bytes) == (7, 0, rep.total_bytes_in)
+    parts = [host.decompress_archive(archive, False, "/dev/null", rank=r, world=3) for r in range(3)]
+    assert sum(p.chunks for p in parts) == 8 and sum(p.total_bytes for p in parts) == rep.total_bytes_in
+
+
+@gpu
+def test_cpp_reads_python_written_archive_and_random_access(tmp_path):
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from znippy_amd import host
+    from znippy_amd.stream_packer import ArchiveEntry, compress_stream
+    c = compress_stream(tmp_path / "py.znippy", False)
+    data = {"big.bin": gen.binary(12 * 1024 * 1024), "a/b.txt": gen.pseudo_text(5000, 2), "z.jar": gen.incompressible(5, 70000),
+            "e": b""}
+    for k, v in data.items():
+        c.sender().send(ArchiveEntry(k, v))
+    c.finish()
+    rep = host.decompress_archive(tmp_path / "py.znippy", True, tmp_path / "o")
+    assert (rep.total_files, rep.corrupt_files, rep.verified_files) == (4, 0, 4)
+    for k, v in data.items():
+        assert (tmp_path / "o" / k).read_bytes() == v
+    a = host.ZnippyArchive.open(tmp_path / "py.znippy")
+    assert a.file_count() == 4 and a.contains("big.bin") and not a.contains("nope")
+    assert a.extract_file("big.bin") == data["big.bin"]                      # multi-chunk order (integration_test.rs:L617-642)
+    assert a.extract_file("z.jar") == data["z.jar"] and a.extract_file("e") == b""
+    with pytest.raises(KeyError):
+        a.extract_file("nope")
+    # corruption is counted, not fatal
+    raw = bytearray((tmp_path / "py.znippy").read_bytes())
+    i = bytes(raw).find(data["z.jar"][:64])
+    raw[i + 9] ^= 0x40
+    (tmp_path / "bad.znippy").write_bytes(bytes(raw))
+    bad = host.decompress_archive(tmp_path / "bad.znippy", True, tmp_path / "o2")
+    assert (bad.corrupt_files, bad.verified_files, bad.corrupt_bytes) == (1, 3, 70000) and len(bad.corrupt_rows) == 1

@@ -9,14 +9,15 @@ SO = os.path.join(HERE, "libznippy_hip.so")
 
 
 def sources():
-    return sorted(glob.glob(os.path.join(CSRC, "*.hip")))
+    return sorted(glob.glob(os.path.join(CSRC, "*.hip"))) + sorted(glob.glob(os.path.join(CSRC, "host", "*.cpp")))
 
 
 def needs_build():
     if not os.path.exists(SO):
         return True
     t = os.path.getmtime(SO)
-    deps = sources() + glob.glob(os.path.join(CSRC, "*.h")) + [os.path.join(HERE, "..", "include", "znippy_hip.h")]
+    deps = (sources() + glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(CSRC, "host", "*.h")) +
+            glob.glob(os.path.join(HERE, "..", "include", "*.h")))
     return any(os.path.getmtime(d) > t for d in deps)
 
 
@@ -27,7 +28,7 @@ def build(force=False, verbose=False):
     objs = []
     procs = []
     for src in sources():
-        obj = src[:-4] + ".o"
+        obj = os.path.splitext(src)[0] + ".o"
         cmd = [hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-c", src, "-o", obj,
                "-Wall", "-Wno-unused-function"]
         if verbose:

@@ -56,6 +56,12 @@ def lib():
     global _lib
     if _lib is not None:
         return _lib
+    # PyTorch-ROCm ships its own libamdhip64; load it FIRST so this library's hip* symbols bind to the
+    # same runtime instance (two HIP runtimes in one process: the second one finds no device).
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     path = lib_path()
     if not os.path.exists(path):
         raise ImportError(f"{path} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
