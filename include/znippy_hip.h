@@ -139,6 +139,11 @@ int znippy_rounds_results(znippy_ctx *ctx, znippy_rounds *rounds, uint64_t *blob
                           uint64_t *blob_size, uint8_t *checksum, uint8_t *compressed,
                           uint64_t *blob_bytes);
 
+/* Zero-copy results: pointers into the table's pinned host mirror (one D2H), valid until the next
+ * encode call on the same table. */
+int znippy_rounds_results_view(znippy_ctx *ctx, znippy_rounds *rounds, const uint64_t **blob_offset,
+                               const uint64_t **blob_size, const uint8_t **checksum, uint64_t *blob_bytes);
+
 /* Hash only (store path / verify-only): digests[i] = BLAKE3(d_src[off_i .. off_i+len_i]).
  * digests: HOST, 32 bytes per round. */
 int znippy_hash_rounds(znippy_ctx *ctx, znippy_rounds *rounds, const void *d_src, uint8_t *digests);

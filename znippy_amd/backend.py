@@ -29,6 +29,7 @@ class HipBackend:
         rt = self.hip.RoundTable(self.ctx, off, length, skip)
         d_blob = self.torch.empty(rt.blob_bound() + 64, dtype=self.torch.uint8, device=f"cuda:{self.device}")
         res = rt.encode_hash(d_src, d_blob)
+        res = {k: (v.copy() if hasattr(v, "copy") else v) for k, v in res.items()}  # views die with the table
         blob = d_blob[:res["blob_bytes"]].cpu().numpy()
         rt.close()
         return res, blob

@@ -164,6 +164,10 @@ struct znippy_rounds {
     uint64_t prov_bytes = 0;
     uint32_t *piece_len = nullptr, *piece_len_init = nullptr;
     uint64_t *piece_start = nullptr, *local_excl = nullptr, *block_tot = nullptr;
+    // results live in ONE device slab (one D2H per call): [total u64][overflow u64][blob_offset n][blob_size n][digests 32n]
+    uint8_t *res = nullptr, *h_res = nullptr;  // device slab + pinned host mirror
+    size_t res_bytes = 0;
+    bool h_valid = false;
     uint64_t *blob_offset = nullptr, *blob_size = nullptr, *total = nullptr;
     uint32_t *overflow = nullptr;
 };
@@ -514,8 +518,9 @@ int znippy_rows_digests(znippy_ctx *ctx, znippy_rows *r, uint8_t *digests) {
 void znippy_rounds_destroy(znippy_rounds *r) {
     if (!r) return;
     (void)hipSetDevice(r->ctx->device);
-    void *ptrs[] = {r->src_off, r->len, r->skip, r->digests, r->items, r->piece_len, r->piece_len_init,
-                    r->piece_start, r->local_excl, r->block_tot, r->blob_offset, r->blob_size, r->total, r->overflow};
+    void *ptrs[] = {r->src_off, r->len, r->skip, r->res, r->items, r->piece_len, r->piece_len_init,
+                    r->piece_start, r->local_excl, r->block_tot};
+    if (r->h_res) (void)hipHostFree(r->h_res);
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     free_plan(r->plan);
@@ -540,10 +545,16 @@ int znippy_rounds_create(znippy_ctx *ctx, const uint64_t *src_offset, const uint
         znippy_rounds_destroy(r);
         return rc;
     }
-    if (hipMalloc(&r->digests, std::max<size_t>(32 * n, 32)) != hipSuccess) {
+    r->res_bytes = 16 + (size_t)n * (8 + 8 + 32);
+    if (hipMalloc(&r->res, r->res_bytes) != hipSuccess || hipHostMalloc(&r->h_res, r->res_bytes) != hipSuccess) {
         znippy_rounds_destroy(r);
         return ZNIPPY_E_NOMEM;
     }
+    r->total = reinterpret_cast<uint64_t *>(r->res);
+    r->overflow = reinterpret_cast<uint32_t *>(r->res + 8);
+    r->blob_offset = reinterpret_cast<uint64_t *>(r->res + 16);
+    r->blob_size = r->blob_offset + n;
+    r->digests = reinterpret_cast<uint32_t *>(r->res + 16 + (size_t)n * 16);
     PlanBuf p;
     build_plan(len, (uint32_t)n, p);
     if ((rc = upload_plan(ctx, p, r->plan))) {
@@ -584,12 +595,13 @@ int znippy_rounds_create(znippy_ctx *ctx, const uint64_t *src_offset, const uint
     }
     if (hipMalloc(&r->piece_len, 4 * ni) != hipSuccess || hipMalloc(&r->piece_start, 8 * ni) != hipSuccess ||
         hipMalloc(&r->local_excl, 8 * ni) != hipSuccess || hipMalloc(&r->block_tot, 8 * nsb) != hipSuccess ||
-        hipMalloc(&r->blob_offset, std::max<size_t>(8 * n, 16)) != hipSuccess ||
-        hipMalloc(&r->blob_size, std::max<size_t>(8 * n, 16)) != hipSuccess ||
-        hipMalloc(&r->total, 16) != hipSuccess || hipMalloc(&r->overflow, 16) != hipSuccess) {
+        false) {
         znippy_rounds_destroy(r);
         return ZNIPPY_E_NOMEM;
     }
+    // store-path pieces keep their fixed lengths for the table's lifetime; encoded pieces are rewritten by
+    // the encoder on every run, so one copy at creation is enough
+    if (r->n_items) HIPCHK(ctx, hipMemcpy(r->piece_len, r->piece_len_init, 4 * (size_t)r->n_items, hipMemcpyDeviceToDevice));
     *out = r;
     return ZNIPPY_OK;
 }
@@ -703,10 +715,8 @@ extern "C" int znippy_encode_hash_rounds_async(znippy_ctx *ctx, znippy_rounds *r
         ctx->enc_prov_cap = r->prov_bytes + 64;
     }
     HIPCHK(ctx, hipEventRecord(ctx->ev_fork, s));
-    HIPCHK(ctx, hipMemcpyAsync(r->piece_len, r->piece_len_init, 4 * (size_t)r->n_items, hipMemcpyDeviceToDevice, s));
-    HIPCHK(ctx, hipMemsetAsync(r->blob_size, 0, 8 * (size_t)r->n, s));
-    HIPCHK(ctx, hipMemsetAsync(r->overflow, 0, 16, s));
-    HIPCHK(ctx, hipMemsetAsync(r->total, 0, 16, s));
+    HIPCHK(ctx, hipMemsetAsync(r->res, 0, 16 + 16 * (size_t)r->n, s));  // total, overflow, blob_offset, blob_size
+    r->h_valid = false;
     HIPCHK(ctx, hipMemsetAsync(ctx->cursor, 0, 64, s));
     EncodeArgs a{};
     a.items = r->items; a.n_items = r->n_items; a.cursor = ctx->cursor;
@@ -724,7 +734,7 @@ extern "C" int znippy_encode_hash_rounds_async(znippy_ctx *ctx, znippy_rounds *r
     // checksum over the ORIGINAL bytes (stream_packer.rs:L219): VALU-bound, submitted to the
     // auxiliary stream right after the persistent (latency-bound) encoder so both share the CUs
     HIPCHK(ctx, hipStreamWaitEvent(ctx->aux, ctx->ev_fork, 0));
-    int rc = hash_rounds_async(ctx, r, d_src, ctx->aux);
+    int rc = getenv("ZNIPPY_NOHASH") ? ZNIPPY_OK : hash_rounds_async(ctx, r, d_src, ctx->aux);  // diagnostic switch
     if (rc) return rc;
     HIPCHK(ctx, hipEventRecord(ctx->ev_join, ctx->aux));
     ktime_begin(ctx, "piece_scan");
@@ -751,17 +761,35 @@ extern "C" int znippy_rounds_results(znippy_ctx *ctx, znippy_rounds *r, uint64_t
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     if (blob_bytes) *blob_bytes = 0;
     if (!r->n) return ZNIPPY_OK;
-    uint32_t ovf = 0;
-    uint64_t total = 0;
-    HIPCHK(ctx, hipMemcpy(&ovf, r->overflow, 4, hipMemcpyDeviceToHost));
-    HIPCHK(ctx, hipMemcpy(&total, r->total, 8, hipMemcpyDeviceToHost));
+    if (!r->h_valid) {
+        HIPCHK(ctx, hipMemcpy(r->h_res, r->res, r->res_bytes, hipMemcpyDeviceToHost));  // pinned: one DMA
+        r->h_valid = true;
+    }
+    uint64_t total;
+    uint32_t ovf;
+    memcpy(&total, r->h_res, 8);
+    memcpy(&ovf, r->h_res + 8, 4);
     if (ovf) return ZNIPPY_E_DST_SMALL;
-    if (blob_offset) HIPCHK(ctx, hipMemcpy(blob_offset, r->blob_offset, 8 * (size_t)r->n, hipMemcpyDeviceToHost));
-    if (blob_size) HIPCHK(ctx, hipMemcpy(blob_size, r->blob_size, 8 * (size_t)r->n, hipMemcpyDeviceToHost));
-    if (checksum) HIPCHK(ctx, hipMemcpy(checksum, r->digests, 32 * (size_t)r->n, hipMemcpyDeviceToHost));
+    const size_t n = r->n;
+    if (blob_offset) memcpy(blob_offset, r->h_res + 16, 8 * n);
+    if (blob_size) memcpy(blob_size, r->h_res + 16 + 8 * n, 8 * n);
+    if (checksum) memcpy(checksum, r->h_res + 16 + 16 * n, 32 * n);
     if (compressed)
         for (uint32_t i = 0; i < r->n; i++) compressed[i] = r->h_skip[i] ? 0 : 1;
     if (blob_bytes) *blob_bytes = total;
+    return ZNIPPY_OK;
+}
+
+// Zero-copy variant: pointers into the table's pinned result mirror, valid until the next encode call
+// on this table (compressed[] = !skip is known to the caller already).
+extern "C" int znippy_rounds_results_view(znippy_ctx *ctx, znippy_rounds *r, const uint64_t **blob_offset,
+                                          const uint64_t **blob_size, const uint8_t **checksum, uint64_t *blob_bytes) {
+    int rc = znippy_rounds_results(ctx, r, nullptr, nullptr, nullptr, nullptr, blob_bytes);
+    if (rc) return rc;
+    const size_t n = r->n;
+    if (blob_offset) *blob_offset = reinterpret_cast<const uint64_t *>(r->h_res + 16);
+    if (blob_size) *blob_size = reinterpret_cast<const uint64_t *>(r->h_res + 16 + 8 * n);
+    if (checksum) *checksum = r->h_res + 16 + 16 * n;
     return ZNIPPY_OK;
 }
 

@@ -102,10 +102,15 @@ struct CState {
     __device__ __forceinline__ void flush(BitW &b) { b.add(v, log); }
 };
 
+constexpr uint32_t SMALL_BLOCK = 16 * 1024;           // blocks of the small-table variant
+constexpr uint32_t SMALL_MAX_SEQ = SMALL_BLOCK / 40;  // their sequence budget fits in LDS
+
 template <uint32_t HASH_LOG>
 struct EncShared {
     uint16_t table[1u << HASH_LOG];
     EncTables tabs;  // FSE encoding tables, copied once per persistent wave (lane 0 reads them per sequence)
+    uint32_t seqs[HASH_LOG == 11 ? 3 * (SMALL_MAX_SEQ + 1) : 4];  // small variant: sequences stay on chip
+    uint32_t sink[64];  // landing area of the prefetch touches (never read)
 };
 
 // n bytes src -> dst by one wave (ranges do not overlap)
@@ -138,26 +143,42 @@ __global__ __launch_bounds__(64) void k_zstd_encode(EncodeArgs a) {
         uint32_t *l = reinterpret_cast<uint32_t *>(&S.tabs);
         for (uint32_t i = lane; i < sizeof(EncTables) / 4; i += 64) l[i] = g[i];
     }
-    uint32_t *const seqs = a.seq_scratch + (size_t)blockIdx.x * MAX_SEQ * 3;  // {ll, ml-3, offset} per sequence
+    // {ll, ml-3, offset} per sequence: LDS for the small-block variant, per-wave global scratch otherwise
+    uint32_t *const seqs = HASH_LOG == 11 ? S.seqs : a.seq_scratch + (size_t)blockIdx.x * MAX_SEQ * 3;
 
     // Work cursor: one atomic per `a.batch` consecutive items (a single word saturates near 88
     // dequeues/us on this chip, so 100k one-item dequeues alone would cost > 1 ms).
-    uint32_t next = 0, lim = 0;
+    uint32_t next = 0, lim = 0, first = 0;
+    // descriptors of the dequeued batch, one item per lane (loaded together: one memory round trip
+    // per batch instead of three dependent ones per item)
+    uint32_t d_round = 0, d_block = 0, d_nblocks = 0, d_flags = ITEM_SKIP;
+    uint64_t d_prov = 0, d_rlen = 0, d_soff = 0;
     for (;;) {
         if (next == lim) {
             __syncthreads();
             if (lane == 0) s_item = atomicAdd(a.cursor, a.batch);
             __syncthreads();
-            next = s_item;
+            next = first = s_item;
             lim = next + a.batch;
+            const uint32_t mine = first + lane;
+            d_flags = ITEM_SKIP;
+            if (lane < a.batch && mine < a.n_items) {
+                const EncItem e = a.items[mine];
+                d_round = e.round; d_block = e.block; d_nblocks = e.n_blocks; d_flags = e.flags; d_prov = e.prov;
+                d_rlen = a.len[e.round];
+                d_soff = a.src_off[e.round];
+            }
         }
         const uint32_t item = next++;
         if (item >= a.n_items) break;
         __syncthreads();
-        const EncItem it = a.items[item];
+        const uint32_t bl = item - first;
+        EncItem it;
+        it.round = __shfl(d_round, bl); it.block = __shfl(d_block, bl); it.n_blocks = __shfl(d_nblocks, bl);
+        it.flags = __shfl(d_flags, bl); it.prov = __shfl(d_prov, bl);
         if (it.flags & ITEM_SKIP) continue;  // store path: the gather pass copies it from the staging buffer
-        const uint64_t rlen = a.len[it.round];
-        const uint8_t *const rsrc = a.src + a.src_off[it.round];
+        const uint64_t rlen = __shfl(d_rlen, bl);
+        const uint8_t *const rsrc = a.src + __shfl(d_soff, bl);
         const uint64_t boff = (uint64_t)it.block * BLOCK_BYTES;
         const uint32_t n = (uint32_t)((rlen - boff) < BLOCK_BYTES ? (rlen - boff) : BLOCK_BYTES);
         const uint8_t *const in = rsrc + boff;
@@ -165,7 +186,12 @@ __global__ __launch_bounds__(64) void k_zstd_encode(EncodeArgs a) {
         uint8_t *const blk = a.prov + it.prov + HDR_ROOM;  // block header goes here
         uint8_t *const lits = blk + 3 + 3;                 // literals after a 3-byte literals header
         const uint32_t max_seq = (n / 40) < MAX_SEQ ? (n / 40) : MAX_SEQ;
-
+        // touch every 128-byte line of the block now: all of its HBM fetches are in flight at once and
+        // the match finder's dependent loads below hit in L2/L1.  LDS-DMA loads (no VGPR destination,
+        // nothing ever reads the sink) so no register is exposed to a late-arriving result.
+        for (uint32_t o = lane * 128; o + 4 <= n; o += 64 * 128)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(in + o),
+                                             (__attribute__((address_space(3))) void *)S.sink, 4, 0, 0);
         // ---- match finding ----
         {
             uint4 *t4 = reinterpret_cast<uint4 *>(S.table);

@@ -161,7 +161,7 @@ class RoundTable:
         ln = as_np(length, np.uint64)
         sk = as_np(skip, np.uint8) if skip is not None else None
         self.n = len(so)
-        self._res = None
+        self._compressed = (1 - sk).astype(np.uint8) if sk is not None else np.ones(self.n, np.uint8)
         h = vp()
         ctx._chk(ctx.L.znippy_rounds_create(ctx.h, np_ptr(so), np_ptr(ln), np_ptr(sk) if sk is not None else None,
                                             self.n, C.byref(h)), "znippy_rounds_create")
@@ -188,16 +188,19 @@ class RoundTable:
                                                                  blob_cap), "znippy_encode_hash_rounds_async")
 
     def results(self):
-        n = max(self.n, 1)
-        if self._res is None:  # result buffers are reused (and overwritten) by every call
-            self._res = [_pinned((n,), np.uint64), _pinned((n,), np.uint64), _pinned((n, 32), np.uint8),
-                         _pinned((n,), np.uint8)]
-        (bo, _), (bs, _), (ck, _), (cm, _) = self._res
+        """Per-round outputs as numpy VIEWS of the table's pinned result mirror (zero-copy; they are
+        overwritten by the next encode call on this table — copy what must outlive it)."""
+        bo, bs, ck = vp(), vp(), vp()
         total = C.c_uint64()
-        self.ctx._chk(self.ctx.L.znippy_rounds_results(self.ctx.h, self.h, np_ptr(bo), np_ptr(bs), np_ptr(ck),
-                                                       np_ptr(cm), C.byref(total)), "znippy_rounds_results")
+        self.ctx._chk(self.ctx.L.znippy_rounds_results_view(self.ctx.h, self.h, C.byref(bo), C.byref(bs), C.byref(ck),
+                                                            C.byref(total)), "znippy_rounds_results_view")
         k = self.n
-        return dict(blob_offset=bo[:k], blob_size=bs[:k], checksum=ck[:k], compressed=cm[:k],
+        if k == 0:
+            return dict(blob_offset=np.zeros(0, np.uint64), blob_size=np.zeros(0, np.uint64),
+                        checksum=np.zeros((0, 32), np.uint8), compressed=np.zeros(0, np.uint8), blob_bytes=0)
+        mk = lambda p, nbytes, dt: np.frombuffer((C.c_uint8 * nbytes).from_address(p.value), dtype=dt)
+        return dict(blob_offset=mk(bo, 8 * k, np.uint64), blob_size=mk(bs, 8 * k, np.uint64),
+                    checksum=mk(ck, 32 * k, np.uint8).reshape(k, 32), compressed=self._compressed,
                     blob_bytes=int(total.value))
 
     def encode_hash(self, d_src, d_blob_out, blob_cap=None):
