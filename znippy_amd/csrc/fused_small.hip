@@ -292,6 +292,24 @@ __device__ __forceinline__ void fwave_expand(uint8_t *dst, const uint8_t *pg, co
     uint32_t x = head, s = smod(head, off);
     const uint32_t step = smod(1024, off);
     uint8_t *d = dst + head + 16 * lane;
+    while (x + 4096 <= ml) {  // 4 KiB per trip: four independent LDS reads in flight before the stores
+        uint32_t s1 = s + step; if (s1 >= off) s1 -= off;
+        uint32_t s2 = s1 + step; if (s2 >= off) s2 -= off;
+        uint32_t s3 = s2 + step; if (s3 >= off) s3 -= off;
+        uint4 v0, v1, v2, v3;
+        __builtin_memcpy(&v0, E + s + 16 * lane, 16);
+        __builtin_memcpy(&v1, E + s1 + 16 * lane, 16);
+        __builtin_memcpy(&v2, E + s2 + 16 * lane, 16);
+        __builtin_memcpy(&v3, E + s3 + 16 * lane, 16);
+        *reinterpret_cast<uint4 *>(d) = v0;
+        *reinterpret_cast<uint4 *>(d + 1024) = v1;
+        *reinterpret_cast<uint4 *>(d + 2048) = v2;
+        *reinterpret_cast<uint4 *>(d + 3072) = v3;
+        d += 4096;
+        x += 4096;
+        s = s3 + step;
+        if (s >= off) s -= off;
+    }
     while (x + 1024 <= ml) {
         uint4 v;
         __builtin_memcpy(&v, E + s + 16 * lane, 16);
@@ -623,6 +641,9 @@ __global__ __launch_bounds__(256, 4) void k_fused_small(FusedArgs a) {
     }
 
     if (stamp) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); t1 = __builtin_amdgcn_s_memtime(); }
+    // decode = short bursts of scalar parsing + store issue: let it issue ahead of SIMD-mates that are in
+    // their VALU-bound hash phase, so the stores get out early and drain while this wave hashes
+    if (!(a.dbg & 64)) __builtin_amdgcn_s_setprio(3);
     for (uint32_t u = 0; u < t.n_units && !(a.dbg & 2); u++) {
         const uint32_t row = t.first_unit + u;
         if (!uni(__shfl(c_sel, u))) continue;  // stored row: copied while it is hashed below
@@ -655,6 +676,7 @@ __global__ __launch_bounds__(256, 4) void k_fused_small(FusedArgs a) {
     }
     // Rows hashed from LDS do not depend on their stores having landed, so the store queue drains
     // in the background while this wave hashes.  Only a global re-read needs the drain.
+    __builtin_amdgcn_s_setprio(0);
     if (need_reread) fwave_mem_sync();
     if (stamp) t2 = __builtin_amdgcn_s_memtime();
     if (!(a.dbg & 1)) {
