@@ -168,3 +168,29 @@ def test_c2_shape_100k_rows_roundtrip_property(gpu_ctx, oracle):
     out = d_out[:n * sz].view(n, sz)
     ref = torch.from_numpy(np.frombuffer(chunk, dtype=np.uint8).copy()).cuda()
     assert bool((out == ref[None, :]).all())
+
+
+def _with_checksum(oracle, frame, content):
+    """Turn a libzstd frame (no checksum) into one WITH the Content_Checksum flag + XXH64 trailer."""
+    import struct
+    import xxhash
+    b = bytearray(frame)
+    assert not (b[4] & 4)
+    b[4] |= 4
+    return bytes(b) + struct.pack("<I", xxhash.xxh64(content).intdigest() & 0xFFFFFFFF)
+
+
+@pytest.mark.parametrize("gname,n", [("text", 10240), ("pseudo_text", 70000), ("binary", 300000), ("text", 0)])
+def test_frame_content_checksum_is_verified(gpu_ctx, oracle, gname, n):
+    from znippy_amd._lib import ZnippyError, E_CHECKSUM
+    data = _gen(gname, n)
+    frame = _with_checksum(oracle, oracle.libzstd_compress(data, 3), data)
+    assert oracle.zstd_decompress(frame) == data and oracle.libzstd_decompress(frame, max(n, 1)) == data
+    assert gpu_ctx.decompress(frame) == data
+    bad = bytearray(frame)
+    bad[-1] ^= 0x10                                      # wrong checksum -> ZNIPPY_E_CHECKSUM (oracle: error too)
+    with pytest.raises(ValueError):
+        oracle.zstd_decompress(bytes(bad))
+    with pytest.raises(ZnippyError) as ei:
+        gpu_ctx.decompress(bytes(bad))
+    assert ei.value.code == E_CHECKSUM

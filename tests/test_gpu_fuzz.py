@@ -1,0 +1,84 @@
+"""Robustness: mutated frames through the batch decoder.  Every mutant is one index row; one
+launch decodes them all.  Contract (decompress.rs:L159-162): a frame that fails to decode is a
+per-row error, never a fault or a hang.  Cross-check with the oracle: whenever the oracle accepts
+a mutant the GPU must accept it too and produce the same bytes; whenever the oracle rejects it,
+the GPU must either reject it or (checksum-less frames carry no integrity) produce bytes the
+BLAKE3 verify then flags — it must never report a verified row with different bytes.
+"""
+import numpy as np
+import pytest
+
+import gen
+
+pytestmark = pytest.mark.gpu
+
+
+def _mutants(frame: bytes, rng, count):
+    out = []
+    n = len(frame)
+    for i in range(count):
+        b = bytearray(frame)
+        kind = i % 5
+        if kind == 0:                      # single bit flip
+            p = int(rng.integers(0, n)); b[p] ^= 1 << int(rng.integers(0, 8))
+        elif kind == 1:                    # random byte
+            p = int(rng.integers(0, n)); b[p] = int(rng.integers(0, 256))
+        elif kind == 2:                    # truncate
+            b = b[:int(rng.integers(1, n))]
+        elif kind == 3:                    # burst of 4 random bytes
+            p = int(rng.integers(0, max(n - 4, 1)))
+            for k in range(min(4, n - p)):
+                b[p + k] = int(rng.integers(0, 256))
+        else:                              # swap two bytes
+            p, q = int(rng.integers(0, n)), int(rng.integers(0, n)); b[p], b[q] = b[q], b[p]
+        out.append(bytes(b))
+    return out
+
+
+def test_mutated_frames_never_fault_and_agree_with_oracle(gpu_ctx, oracle):
+    import torch
+    from znippy_amd import hip
+    rng = np.random.default_rng(2024)
+    bases = [(gen.text(10240), 19), (gen.binary(10240), 19), (gen.pseudo_text(6000, 3), 3), (gen.pseudo_text(6000, 4), 19),
+             (gen.pseudo_text(70000, 5), 3), (gen.random_lcg(3000), 3), (bytes(5000), 3)]
+    frames, sizes, originals = [], [], []
+    for data, lvl in bases:
+        f = oracle.libzstd_compress(data, lvl)
+        g = gpu_ctx.compress(data)                       # this build's own frames too
+        for base in (f, g):
+            frames.append(base); sizes.append(len(data)); originals.append(data)   # the intact frame as control
+            for m in _mutants(base, rng, 120):
+                frames.append(m); sizes.append(len(data)); originals.append(data)
+    n = len(frames)
+    bs = np.array([len(f) for f in frames], dtype=np.uint64)
+    bo = np.concatenate([[0], np.cumsum(bs)[:-1]]).astype(np.uint64)
+    us = np.array(sizes, dtype=np.uint64)
+    oo = np.concatenate([[0], np.cumsum(us)[:-1]]).astype(np.uint64)
+    ck = np.stack([np.frombuffer(oracle.blake3(d), dtype=np.uint8) for d in originals])
+    d_blobs = torch.from_numpy(np.frombuffer(b"".join(frames) + bytes(64), dtype=np.uint8).copy()).cuda()
+    d_out = torch.zeros(int(us.sum()) + 64, dtype=torch.uint8, device="cuda")
+    rt = hip.RowTable(gpu_ctx, bo, bs, us, oo, None, ck)
+    counters, corrupt, status = rt.decode_verify(d_blobs, d_out)
+    out = d_out.cpu().numpy()
+    corrupt = set(int(x) for x in corrupt)
+    n_ok = n_rej = n_flagged = 0
+    for i in range(n):
+        try:
+            want = oracle.zstd_decompress(frames[i], cap=sizes[i])
+            oracle_ok = len(want) == sizes[i]
+        except ValueError:
+            oracle_ok = False
+        got = out[int(oo[i]):int(oo[i] + us[i])].tobytes()
+        if oracle_ok:
+            assert status[i] == 0, (i, status[i])
+            assert got == want, i
+            assert (i in corrupt) == (want != originals[i]), i       # verify flags exactly the changed contents
+            n_ok += 1
+        elif status[i] < 0:
+            n_rej += 1
+        else:
+            assert i in corrupt or got == originals[i], i            # never "verified" with wrong bytes
+            n_flagged += 1
+    assert counters["total_chunks"] == n and counters["decode_errors"] == int((status < 0).sum())
+    assert n_ok > 14 and n_rej > 200
+    print(f"mutants: {n} rows, oracle-accepted {n_ok}, rejected by both {n_rej}, gpu-decoded-but-flagged {n_flagged}")

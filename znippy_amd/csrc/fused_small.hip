@@ -380,6 +380,7 @@ __device__ int decode_simple(const uint8_t *src, uint32_t n, uint8_t *out, uint6
     const uint32_t fcs_flag = fhd >> 6, single = (fhd >> 5) & 1, did_flag = fhd & 3;
     if (fhd & 8) return F_E_CORRUPT;
     const uint32_t has_ck = (fhd >> 2) & 1;
+    if (has_ck) return F_NOT_SIMPLE;  // content checksum (XXH64): verified by the general decoder
     const uint32_t fcs_bytes = fcs_flag == 0 ? single : (1u << fcs_flag);
     const uint32_t did_bytes = did_flag == 3 ? 4 : did_flag;
     uint32_t pos = 5 + (single ? 0 : 1);

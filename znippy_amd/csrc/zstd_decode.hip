@@ -416,6 +416,40 @@ __device__ int huf_decode_stream(const Shared &S, const uint8_t *p, uint32_t n, 
     return b.pos == 0 ? 0 : E_CORRUPT;
 }
 
+// XXH64 (RFC 8878 §3.1.1 content checksum), seed 0, computed by lanes 0..3 of one wave (one stripe
+// accumulator each; the stripe recurrence is serial by definition), finalised by lane 0.
+__device__ uint64_t wave_xxh64(const uint8_t *p, uint64_t len, uint32_t lane) {
+    const uint64_t P1 = 0x9E3779B185EBCA87ull, P2 = 0xC2B2AE3D27D4EB4Full, P3 = 0x165667B19E3779F9ull,
+                   P4 = 0x85EBCA77C2B2AE63ull, P5 = 0x27D4EB2F165667C5ull;
+    auto rotl = [](uint64_t x, int r) { return (x << r) | (x >> (64 - r)); };
+    auto rd64 = [](const uint8_t *q) { uint64_t v; __builtin_memcpy(&v, q, 8); return v; };
+    auto rd32 = [](const uint8_t *q) { uint32_t v; __builtin_memcpy(&v, q, 4); return v; };
+    auto round = [&](uint64_t acc, uint64_t in) { acc += in * P2; acc = rotl(acc, 31); return acc * P1; };
+    uint64_t v = 0;
+    const uint64_t stripes = len / 32;
+    if (lane < 4) {
+        v = lane == 0 ? P1 + P2 : (lane == 1 ? P2 : (lane == 2 ? 0 : 0 - P1));
+        const uint8_t *q = p + 8 * lane;
+        for (uint64_t i = 0; i < stripes; i++) v = round(v, rd64(q + 32 * i));
+    }
+    const uint64_t v1 = __shfl(v, 0), v2 = __shfl(v, 1), v3 = __shfl(v, 2), v4 = __shfl(v, 3);
+    uint64_t h;
+    if (len >= 32) {
+        h = rotl(v1, 1) + rotl(v2, 7) + rotl(v3, 12) + rotl(v4, 18);
+        auto merge = [&](uint64_t acc, uint64_t val) { val = round(0, val); acc ^= val; return acc * P1 + P4; };
+        h = merge(h, v1); h = merge(h, v2); h = merge(h, v3); h = merge(h, v4);
+    } else {
+        h = P5;
+    }
+    h += len;
+    const uint8_t *q = p + stripes * 32, *end = p + len;
+    while (q + 8 <= end) { h ^= round(0, rd64(q)); h = rotl(h, 27) * P1 + P4; q += 8; }
+    if (q + 4 <= end) { h ^= (uint64_t)rd32(q) * P1; h = rotl(h, 23) * P2 + P3; q += 4; }
+    while (q < end) { h ^= (*q) * P5; h = rotl(h, 11) * P1; q++; }
+    h ^= h >> 33; h *= P2; h ^= h >> 29; h *= P3; h ^= h >> 32;
+    return h;
+}
+
 // ---------------------------------------------------------------------------------------------
 // the kernel
 // ---------------------------------------------------------------------------------------------
@@ -799,12 +833,20 @@ __global__ __launch_bounds__(NWAVES * 64) void k_zstd_decode(DecodeArgs a) {
                 __syncthreads();
             }
         }
-        __syncthreads();
-        if (tid == 0) {
+        __syncthreads();  // every wave's output stores have landed (same CU)
+        {
             int err = S.err;
             if (!err && S.out_pos != S.content_size) err = E_CORRUPT;
-            if (!err && S.has_cksum && S.src_pos + 4 > S.src_end) err = E_TRUNC;
-            a.status[row] = err ? err : 2;  // 2 = decoded here, to be hashed by the second pass
+            if (!err && S.has_cksum) {
+                if (S.src_pos + 4 > S.src_end) err = E_TRUNC;
+                else if (wave0) {  // frame content checksum: low 32 bits of XXH64(content)
+                    const uint64_t h = wave_xxh64(out, S.content_size, tid);
+                    const uint8_t *c = src + S.src_pos;
+                    const uint32_t want = c[0] | (c[1] << 8) | (c[2] << 16) | ((uint32_t)c[3] << 24);
+                    if ((uint32_t)h != want) err = -7;  // ZNIPPY_E_CHECKSUM
+                }
+            }
+            if (tid == 0) a.status[row] = err ? err : 2;  // 2 = decoded here, to be hashed by the second pass
         }
         __syncthreads();
     }
