@@ -199,22 +199,29 @@ __global__ __launch_bounds__(64) void k_zstd_encode(EncodeArgs a) {
             for (uint32_t i = lane; i < HASH_SIZE / 8; i += 64) t4[i] = ones;
         }
         __syncthreads();
+        // Blocks after the first are seeded with the 64 bytes in front of them (positions 0..PRE-1 of the
+        // shifted coordinate q = pos + PRE are hashed but never emitted), so a match can reach back into
+        // the previous block — legal inside one frame's window — and periodic data costs ~12 bytes per
+        // block instead of a fresh 64-byte literal run.
+        const uint32_t PRE = it.block ? 64u : 0u;
+        const uint8_t *const inb = in - PRE;
+        const uint32_t nq = n + PRE;
         uint32_t nseq = 0, lit_total = 0;
-        uint32_t anchor = 0;  // first byte not yet emitted
+        uint32_t anchor = PRE;  // first byte not yet emitted
         uint32_t base = 0, misses = 0;
-        const uint32_t scan_end = n >= 8 ? n - 7 : 0;  // positions with >= 8 bytes ahead
+        const uint32_t scan_end = nq >= 8 ? nq - 7 : 0;  // positions with >= 8 bytes ahead
         while (base < scan_end && nseq < max_seq) {
             const uint32_t pos = base + lane;
             uint32_t cand = 0, hitf = 0;
             if (pos < scan_end) {
-                const uint32_t v = ld32(in + pos);
+                const uint32_t v = ld32(inb + pos);
                 const uint32_t h = hash4<HASH_LOG>(v);
                 const uint32_t e = S.table[h];
                 S.table[h] = (uint16_t)pos;  // low 16 bits; candidates are within 64 KiB
                 if (e != 0xFFFF) {
                     uint32_t c = (pos & ~0xFFFFu) | e;
                     if (c >= pos) c -= 0x10000u;  // wraps to a huge value when there is no earlier half
-                    if (c < pos && ld32(in + c) == v) { cand = c; hitf = 1; }
+                    if (c < pos && pos >= PRE && ld32(inb + c) == v) { cand = c; hitf = 1; }
                 }
             }
             const uint64_t hit = __ballot(hitf != 0);
@@ -234,8 +241,8 @@ __global__ __launch_bounds__(64) void k_zstd_encode(EncodeArgs a) {
                 for (int q = 0; q < 4; q++) {
                     const uint32_t o = ml + q * 1024 + lane * 16;
                     uint32_t g = 0;  // matching bytes in my 16-byte piece
-                    if (mpos + o + 16 <= n) {
-                        uint4 x = ld128(in + mpos + o), y = ld128(in + mcand + o);
+                    if (mpos + o + 16 <= nq) {
+                        uint4 x = ld128(inb + mpos + o), y = ld128(inb + mcand + o);
                         uint32_t d0 = x.x ^ y.x, d1 = x.y ^ y.y, d2 = x.z ^ y.z, d3 = x.w ^ y.w;
                         if (d0) g = (__ffs(d0) - 1) >> 3;
                         else if (d1) g = 4 + ((__ffs(d1) - 1) >> 3);
@@ -243,7 +250,7 @@ __global__ __launch_bounds__(64) void k_zstd_encode(EncodeArgs a) {
                         else if (d3) g = 12 + ((__ffs(d3) - 1) >> 3);
                         else g = 16;
                     } else {
-                        while (g < 16 && mpos + o + g < n && in[mpos + o + g] == in[mcand + o + g]) g++;
+                        while (g < 16 && mpos + o + g < nq && inb[mpos + o + g] == inb[mcand + o + g]) g++;
                     }
                     good[q] = g;
                 }
@@ -264,7 +271,7 @@ __global__ __launch_bounds__(64) void k_zstd_encode(EncodeArgs a) {
             }
             // emit: literals [anchor, mpos) then the match
             const uint32_t ll = mpos - anchor;
-            wave_copy(lits + lit_total, in + anchor, ll, lane);
+            wave_copy(lits + lit_total, inb + anchor, ll, lane);
             if (lane == 0) {
                 seqs[3 * nseq] = ll;
                 seqs[3 * nseq + 1] = ml - 3;
@@ -276,8 +283,8 @@ __global__ __launch_bounds__(64) void k_zstd_encode(EncodeArgs a) {
             base = anchor;
         }
         // trailing literals
-        wave_copy(lits + lit_total, in + anchor, n - anchor, lane);
-        lit_total += n - anchor;
+        wave_copy(lits + lit_total, inb + anchor, nq - anchor, lane);
+        lit_total += nq - anchor;
         __syncthreads();  // sequences + literal bytes of all lanes are visible to lane 0
 
         // ---- entropy stage (lane 0) ----
