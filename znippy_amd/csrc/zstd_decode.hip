@@ -20,6 +20,7 @@ constexpr uint32_t BLOCK_MAX = 128 * 1024;
 constexpr int LIT_SCRATCH_BYTES = 128 * 1024 + 64;
 constexpr int SEQ_BATCH = 256;
 constexpr uint32_t BIG_COPY = 8192;  // copies at least this long are shared by all waves of the workgroup
+constexpr uint32_t EXP_OFF_MAX = 4096;  // longest period expanded through LDS
 
 struct FseEntry {
     uint16_t next;    // new-state base
@@ -63,6 +64,8 @@ struct Shared {
     uint16_t fse_next[256];
     uint8_t fse_sym[512];
     uint32_t seq_ll[SEQ_BATCH], seq_ml[SEQ_BATCH], seq_off[SEQ_BATCH];
+    // pattern buffer for long overlapping matches: E[i] = period[i % off], i < off + 16 * threads
+    __attribute__((aligned(16))) uint8_t ebuf[EXP_OFF_MAX + 16 * 1024 + 64];
     // per-row / per-block state broadcast from lane 0
     int32_t err;
     uint32_t row;
@@ -204,11 +207,71 @@ __device__ __forceinline__ void wave_mem_sync() { asm volatile("s_waitcnt vmcnt(
 // LZ match: dst[i] = dst[i - off] for i in [0, n), executed by `nthreads` lanes.  An overlapping
 // match (off < n) is a periodic extension; it is laid down by period doubling so that every step
 // is a non-overlapping cooperative copy whose source is already final.
+// Long overlapping match by the whole workgroup: expand the period once into LDS
+// (E[i] = period[i % off] for i < off + 16*NT, built by tail-free doubling), then every trip all NT
+// threads store 16 aligned bytes each (NT*16 contiguous bytes per trip) — no global read-after-write,
+// one barrier per doubling step instead of one store drain + barrier per step through memory.
 template <int NWAVES>
-__device__ __forceinline__ void coop_match(uint8_t *dst, uint32_t off, uint64_t n, uint32_t tid, bool all_waves) {
+__device__ __forceinline__ void wg_expand_match(uint8_t *dst, uint32_t off, uint64_t n, uint32_t tid, uint8_t *E) {
+    constexpr uint32_t NT = NWAVES * 64, CHUNK = NT * 16;
+    const uint8_t *pat = dst - off;  // final: the caller's barrier drained every earlier store
+    {
+        const uint32_t full = off & ~15u;
+        for (uint32_t i = tid * 16; i < full; i += CHUNK) {
+            uint4 v;
+            __builtin_memcpy(&v, pat + i, 16);
+            __builtin_memcpy(E + i, &v, 16);
+        }
+        if (tid < (off & 15)) E[full + tid] = pat[full + tid];
+    }
+    __syncthreads();
+    const uint32_t need = off + CHUNK;
+    uint32_t w = off;
+    while (w < need) {
+        const uint32_t c = w < need - w ? w : need - w;
+        for (uint32_t i = tid * 16; i < c; i += CHUNK) {
+            uint4 v;
+            __builtin_memcpy(&v, E + i, 16);
+            __builtin_memcpy(E + w + i, &v, 16);  // may spill < 16 bytes past c: rewritten by the next step / slack
+        }
+        w += c;
+        __syncthreads();
+    }
+    const uint32_t head = (uint32_t)((16 - ((uintptr_t)dst & 15)) & 15);
+    if (tid < head) dst[tid] = E[tid];
+    uint64_t x = head;
+    uint32_t s = head % off;
+    const uint32_t step = CHUNK % off;
+    uint8_t *d = dst + head + 16 * tid;
+    while (x + CHUNK <= n) {
+        uint4 v;
+        __builtin_memcpy(&v, E + s + 16 * tid, 16);
+        *reinterpret_cast<uint4 *>(d) = v;
+        d += CHUNK;
+        x += CHUNK;
+        s += step;
+        if (s >= off) s -= off;
+    }
+    const uint32_t rem = (uint32_t)(n - x), full16 = rem >> 4;
+    if (tid < full16) {
+        uint4 v;
+        __builtin_memcpy(&v, E + s + 16 * tid, 16);
+        *reinterpret_cast<uint4 *>(d) = v;
+    }
+    const uint32_t tail = rem & 15, tbase = full16 * 16;
+    if (tid < tail) dst[x + tbase + tid] = E[s + tbase + tid];
+}
+
+template <int NWAVES>
+__device__ __forceinline__ void coop_match(uint8_t *dst, uint32_t off, uint64_t n, uint32_t tid, bool all_waves,
+                                           uint8_t *E) {
     const uint32_t nthreads = all_waves ? NWAVES * 64 : 64;
     if (off >= n) {
         coop_copy(dst, dst - off, n, tid, nthreads);
+        return;
+    }
+    if (all_waves && NWAVES > 1 && off <= EXP_OFF_MAX && n >= 4ull * NWAVES * 64 * 16) {
+        wg_expand_match<NWAVES>(dst, off, n, tid, E);
         return;
     }
     uint64_t w = 0;
@@ -808,7 +871,7 @@ __global__ __launch_bounds__(NWAVES * 64) void k_zstd_decode(DecodeArgs a) {
                             const bool big = NWAVES > 1 && ml >= BIG_COPY;
                             if (big) __syncthreads();
                             else if (wave0) wave_mem_sync();
-                            if (big || wave0) coop_match<NWAVES>(out + opos, off, ml, tid, big);
+                            if (big || wave0) coop_match<NWAVES>(out + opos, off, ml, tid, big, S.ebuf);
                             if (big) __syncthreads();
                             opos += ml;
                         }
