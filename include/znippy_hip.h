@@ -118,6 +118,11 @@ int znippy_rows_digests(znippy_ctx *ctx, znippy_rows *rows, uint8_t *digests);
 int znippy_rounds_create(znippy_ctx *ctx, const uint64_t *src_offset, const uint64_t *len,
                          const uint8_t *skip, uint64_t n, znippy_rounds **out);
 void znippy_rounds_destroy(znippy_rounds *rounds);
+/* Opt-in content-based store path (the reference's wish list, TODO_NOW.md:L37-38):
+ * a round whose frame would not be smaller than its input is emitted as-is with compressed = 0.
+ * OFF by default — the reference decides by file extension only (index.rs:L470-488), so turning this
+ * on changes the `compressed` column for incompressible rounds. */
+int znippy_rounds_set_store_incompressible(znippy_rounds *rounds, int on);
 /* Upper bound of the blob bytes znippy_encode_hash_rounds can produce for this batch. */
 uint64_t znippy_rounds_blob_bound(const znippy_rounds *rounds);
 

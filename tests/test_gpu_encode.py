@@ -131,3 +131,36 @@ def test_c2_shape_100k_rounds(gpu_ctx, oracle):
     frames = blob.reshape(n, fl)
     assert (frames == frames[0][None, :]).all()            # identical inputs -> identical frames
     assert oracle.libzstd_decompress(frames[0].tobytes(), sz) == chunk
+
+
+def test_store_if_incompressible_opt_in(gpu_ctx, oracle):
+    """with the opt-in flag, incompressible rounds are stored raw (compressed=0) and the
+    read path passes them through; default behaviour (flag off) keeps them in raw-block frames."""
+    import torch
+    from znippy_amd import hip
+    entries = [gen.random_lcg(300000), gen.text(20000), gen.incompressible(4, 5000), b"", gen.pseudo_text(9000, 2)]
+    lens = np.array([len(e) for e in entries], dtype=np.uint64)
+    offs = np.concatenate([[0], np.cumsum(lens)[:-1]]).astype(np.uint64)
+    d_src = torch.from_numpy(np.frombuffer(b"".join(entries) + bytes(64), dtype=np.uint8).copy()).cuda()
+    for flag, want_comp in ((False, [1, 1, 1, 1, 1]), (True, [0, 1, 0, 1, 1])):
+        rt = hip.RoundTable(gpu_ctx, offs, lens)
+        if flag:
+            rt.set_store_incompressible(True)
+        d_blob = torch.zeros(rt.blob_bound() + 64, dtype=torch.uint8, device="cuda")
+        res = rt.encode_hash(d_src, d_blob)
+        res = {k: (v.copy() if hasattr(v, "copy") else v) for k, v in res.items()}
+        assert list(res["compressed"]) == want_comp
+        assert np.array_equal(res["blob_offset"][1:], np.cumsum(res["blob_size"])[:-1])
+        blob = d_blob[:res["blob_bytes"]].cpu().numpy()
+        for i, e in enumerate(entries):
+            b = blob[int(res["blob_offset"][i]):int(res["blob_offset"][i] + res["blob_size"][i])].tobytes()
+            if res["compressed"][i]:
+                assert oracle.libzstd_decompress(b, max(len(e), 1)) == e
+            else:
+                assert b == e
+        bitmap = np.packbits(res["compressed"].astype(bool), bitorder="little")
+        rows = hip.RowTable(gpu_ctx, res["blob_offset"], res["blob_size"], lens, offs, bitmap, res["checksum"])
+        d_out = torch.zeros(int(lens.sum()) + 64, dtype=torch.uint8, device="cuda")
+        counters, corrupt, status = rows.decode_verify(d_blob, d_out)
+        assert counters["verified_bytes"] == int(lens.sum()) and len(corrupt) == 0
+        assert d_out[:int(lens.sum())].cpu().numpy().tobytes() == b"".join(entries)

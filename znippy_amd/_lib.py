@@ -43,7 +43,7 @@ EXPORTS = [
     "znippy_decode_verify_rows_async", "znippy_rows_results", "znippy_rows_digests",
     "znippy_rounds_create", "znippy_rounds_destroy", "znippy_rounds_blob_bound",
     "znippy_encode_hash_rounds", "znippy_encode_hash_rounds_async", "znippy_rounds_results",
-    "znippy_rounds_results_view", "znippy_hash_rounds", "znippy_last_kernel_times",
+    "znippy_rounds_results_view", "znippy_rounds_set_store_incompressible", "znippy_hash_rounds", "znippy_last_kernel_times",
 ]
 
 
@@ -96,6 +96,7 @@ def lib():
     L.znippy_encode_hash_rounds_async.argtypes = [vp, vp, vp, vp, C.c_uint64]
     L.znippy_rounds_results.argtypes = [vp, vp, vp, vp, vp, vp, C.POINTER(C.c_uint64)]
     L.znippy_rounds_results_view.argtypes = [vp, vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(C.c_uint64)]
+    L.znippy_rounds_set_store_incompressible.argtypes = [vp, C.c_int]
     L.znippy_hash_rounds.argtypes = [vp, vp, vp, vp]
     L.znippy_last_kernel_times.argtypes = [vp, C.POINTER(C.c_char_p), C.POINTER(C.c_float), C.c_int]
     _lib = L

@@ -168,6 +168,9 @@ struct znippy_rounds {
     uint8_t *res = nullptr, *h_res = nullptr;  // device slab + pinned host mirror
     size_t res_bytes = 0;
     bool h_valid = false;
+    bool store_incompressible = false;  // opt-in (znippy_rounds_set_store_incompressible)
+    uint32_t *first_item = nullptr;     // first piece of every round
+    uint8_t *stored = nullptr, *h_stored = nullptr;  // per round: turned into a raw payload by the opt-in pass
     uint64_t *blob_offset = nullptr, *blob_size = nullptr, *total = nullptr;
     uint32_t *overflow = nullptr;
 };
@@ -519,8 +522,9 @@ void znippy_rounds_destroy(znippy_rounds *r) {
     if (!r) return;
     (void)hipSetDevice(r->ctx->device);
     void *ptrs[] = {r->src_off, r->len, r->skip, r->res, r->items, r->piece_len, r->piece_len_init,
-                    r->piece_start, r->local_excl, r->block_tot};
+                    r->piece_start, r->local_excl, r->block_tot, r->first_item, r->stored};
     if (r->h_res) (void)hipHostFree(r->h_res);
+    if (r->h_stored) (void)hipHostFree(r->h_stored);
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     free_plan(r->plan);
@@ -563,8 +567,9 @@ int znippy_rounds_create(znippy_ctx *ctx, const uint64_t *src_offset, const uint
     }
     // encoder plan: one item per output piece, in round order
     std::vector<EncItem> items;
-    std::vector<uint32_t> plen;
+    std::vector<uint32_t> plen, first_item(n, 0);
     for (uint64_t i = 0; i < n; i++) {
+        first_item[i] = (uint32_t)items.size();
         if (r->h_skip[i]) {
             uint64_t L = len[i];
             uint32_t np = (uint32_t)std::max<uint64_t>(1, (L + SKIP_PIECE - 1) / SKIP_PIECE);
@@ -588,6 +593,11 @@ int znippy_rounds_create(znippy_ctx *ctx, const uint64_t *src_offset, const uint
     if (items.size() >= 0xFFFFFFF0ull) { znippy_rounds_destroy(r); return ZNIPPY_E_INVAL; }
     r->n_items = (uint32_t)items.size();
     const size_t ni = std::max<size_t>(r->n_items, 1), nsb = (ni + 1023) / 1024;
+    if ((rc = dev_upload(ctx, &r->first_item, first_item.data(), first_item.size())) ||
+        hipMalloc(&r->stored, std::max<size_t>(n, 16)) != hipSuccess || hipHostMalloc(&r->h_stored, std::max<size_t>(n, 16)) != hipSuccess) {
+        znippy_rounds_destroy(r);
+        return rc ? rc : ZNIPPY_E_NOMEM;
+    }
     if ((rc = dev_upload(ctx, &r->items, items.data(), items.size())) ||
         (rc = dev_upload(ctx, &r->piece_len_init, plen.data(), plen.size()))) {
         znippy_rounds_destroy(r);
@@ -737,6 +747,11 @@ extern "C" int znippy_encode_hash_rounds_async(znippy_ctx *ctx, znippy_rounds *r
     int rc = getenv("ZNIPPY_NOHASH") ? ZNIPPY_OK : hash_rounds_async(ctx, r, d_src, ctx->aux);  // diagnostic switch
     if (rc) return rc;
     HIPCHK(ctx, hipEventRecord(ctx->ev_join, ctx->aux));
+    if (r->store_incompressible) {
+        ktime_begin(ctx, "store_decide");
+        launch_store_decide(r->first_item, r->items, r->len, r->skip, r->n, r->piece_len, r->stored, s);
+        ktime_end(ctx);
+    }
     ktime_begin(ctx, "piece_scan");
     launch_piece_scan(r->piece_len, r->n_items, r->local_excl, r->block_tot, s);
     ktime_end(ctx);
@@ -746,6 +761,7 @@ extern "C" int znippy_encode_hash_rounds_async(znippy_ctx *ctx, znippy_rounds *r
     g.src = (const uint8_t *)d_src; g.src_off = r->src_off;
     g.blob_out = (uint8_t *)d_blob_out; g.blob_cap = blob_cap;
     g.blob_offset = r->blob_offset; g.blob_size = r->blob_size; g.total = r->total; g.overflow = r->overflow;
+    g.stored = r->store_incompressible ? r->stored : nullptr;
     ktime_begin(ctx, "gather");
     launch_gather(g, s);
     ktime_end(ctx);
@@ -763,6 +779,7 @@ extern "C" int znippy_rounds_results(znippy_ctx *ctx, znippy_rounds *r, uint64_t
     if (!r->n) return ZNIPPY_OK;
     if (!r->h_valid) {
         HIPCHK(ctx, hipMemcpy(r->h_res, r->res, r->res_bytes, hipMemcpyDeviceToHost));  // pinned: one DMA
+        if (r->store_incompressible) HIPCHK(ctx, hipMemcpy(r->h_stored, r->stored, r->n, hipMemcpyDeviceToHost));
         r->h_valid = true;
     }
     uint64_t total;
@@ -775,7 +792,8 @@ extern "C" int znippy_rounds_results(znippy_ctx *ctx, znippy_rounds *r, uint64_t
     if (blob_size) memcpy(blob_size, r->h_res + 16 + 8 * n, 8 * n);
     if (checksum) memcpy(checksum, r->h_res + 16 + 16 * n, 32 * n);
     if (compressed)
-        for (uint32_t i = 0; i < r->n; i++) compressed[i] = r->h_skip[i] ? 0 : 1;
+        for (uint32_t i = 0; i < r->n; i++)
+            compressed[i] = (r->h_skip[i] || (r->store_incompressible && r->h_stored[i])) ? 0 : 1;
     if (blob_bytes) *blob_bytes = total;
     return ZNIPPY_OK;
 }
@@ -825,4 +843,10 @@ extern "C" int znippy_compress(znippy_ctx *ctx, const void *src, size_t n, void 
 extern "C" size_t znippy_compress_bound(size_t n) {
     // every 128 KiB block can fall back to a raw block (3-byte header) + frame header
     return n + 3 * (n / BLOCK_BYTES + 1) + 16;
+}
+
+extern "C" int znippy_rounds_set_store_incompressible(znippy_rounds *r, int on) {
+    if (!r) return ZNIPPY_E_INVAL;
+    r->store_incompressible = on != 0;
+    return ZNIPPY_OK;
 }

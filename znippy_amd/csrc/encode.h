@@ -62,11 +62,14 @@ struct GatherArgs {
     uint64_t blob_cap;
     uint64_t *blob_offset, *blob_size, *total;
     uint32_t *overflow;
+    const uint8_t *stored;  // optional: rounds the store-if-incompressible pass turned into raw payloads
 };
 
 void launch_encode(const EncodeArgs &a, int grid, bool small_blocks, hipStream_t s);
 void launch_piece_scan(const uint32_t *piece_len, uint32_t n, uint64_t *local_excl, uint64_t *block_tot, hipStream_t s);
 void launch_gather(const GatherArgs &g, hipStream_t s);
+void launch_store_decide(const uint32_t *first_item, const EncItem *items, const uint64_t *len, const uint8_t *skip,
+                         uint32_t n_rounds, uint32_t *piece_len, uint8_t *stored, hipStream_t s);
 void build_encode_tables(EncTables *t);
 
 }  // namespace zn

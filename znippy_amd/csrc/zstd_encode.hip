@@ -243,12 +243,14 @@ __global__ __launch_bounds__(64) void k_zstd_encode(EncodeArgs a) {
                     uint32_t g = 0;  // matching bytes in my 16-byte piece
                     if (mpos + o + 16 <= nq) {
                         uint4 x = ld128(inb + mpos + o), y = ld128(inb + mcand + o);
-                        uint32_t d0 = x.x ^ y.x, d1 = x.y ^ y.y, d2 = x.z ^ y.z, d3 = x.w ^ y.w;
-                        if (d0) g = (__ffs(d0) - 1) >> 3;
-                        else if (d1) g = 4 + ((__ffs(d1) - 1) >> 3);
-                        else if (d2) g = 8 + ((__ffs(d2) - 1) >> 3);
-                        else if (d3) g = 12 + ((__ffs(d3) - 1) >> 3);
-                        else g = 16;
+                        const uint32_t d0 = x.x ^ y.x, d1 = x.y ^ y.y, d2 = x.z ^ y.z, d3 = x.w ^ y.w;
+                        g = 16;
+                        if (d0 | d1 | d2 | d3) {  // rare: only the piece where the match ends
+                            if (d0) g = (__ffs(d0) - 1) >> 3;
+                            else if (d1) g = 4 + ((__ffs(d1) - 1) >> 3);
+                            else if (d2) g = 8 + ((__ffs(d2) - 1) >> 3);
+                            else g = 12 + ((__ffs(d3) - 1) >> 3);
+                        }
                     } else {
                         while (g < 16 && mpos + o + g < nq && inb[mpos + o + g] == inb[mcand + o + g]) g++;
                     }
@@ -393,6 +395,7 @@ __global__ __launch_bounds__(256) void k_gather(GatherArgs g) {
     const uint32_t len = g.piece_len[piece];
     const EncItem it = g.items[piece];
     const uint8_t *s = (it.flags & ITEM_SKIP) ? g.src + g.src_off[it.round] + it.prov : g.prov + g.piece_start[piece];
+    if (g.stored && g.stored[it.round]) s = g.src + g.src_off[it.round] + (uint64_t)it.block * BLOCK_BYTES;  // raw bytes of this block
     uint8_t *d = g.blob_out + off;
     if (off + len <= g.blob_cap) wave_copy(d, s, len, lane);
     else if (lane == 0) atomicOr(g.overflow, 1u);
@@ -412,6 +415,38 @@ void launch_encode(const EncodeArgs &a, int grid, bool small_blocks, hipStream_t
 void launch_piece_scan(const uint32_t *piece_len, uint32_t n, uint64_t *local_excl, uint64_t *block_tot, hipStream_t s) {
     if (!n) return;
     hipLaunchKernelGGL(k_piece_scan, dim3((n + 1023) / 1024), dim3(1024), 0, s, piece_len, n, local_excl, block_tot);
+}
+
+// Opt-in store-if-incompressible (reference wish list, TODO_NOW.md:L37-38): a round whose frame is not
+// smaller than its input is emitted as-is (compressed=false) — one thread per round rewrites the lengths
+// of the round's pieces to the raw block sizes before the scan.
+__global__ __launch_bounds__(256) void k_store_decide(const uint32_t *first_item, const EncItem *items, const uint64_t *len,
+                                                      const uint8_t *skip, uint32_t n_rounds, uint32_t *piece_len,
+                                                      uint8_t *stored) {
+    const uint32_t r = blockIdx.x * 256 + threadIdx.x;
+    if (r >= n_rounds) return;
+    uint8_t st = 0;
+    const uint64_t L = len[r];
+    if (!skip[r] && L > 0) {
+        const uint32_t f = first_item[r], nb = items[f].n_blocks;
+        uint64_t sum = 0;
+        for (uint32_t k = 0; k < nb; k++) sum += piece_len[f + k];
+        if (sum >= L) {
+            st = 1;
+            for (uint32_t k = 0; k < nb; k++) {
+                const uint64_t o = (uint64_t)k * BLOCK_BYTES;
+                piece_len[f + k] = (uint32_t)(L - o < BLOCK_BYTES ? L - o : BLOCK_BYTES);
+            }
+        }
+    }
+    stored[r] = st;
+}
+
+void launch_store_decide(const uint32_t *first_item, const EncItem *items, const uint64_t *len, const uint8_t *skip,
+                         uint32_t n_rounds, uint32_t *piece_len, uint8_t *stored, hipStream_t s) {
+    if (!n_rounds) return;
+    hipLaunchKernelGGL(k_store_decide, dim3((n_rounds + 255) / 256), dim3(256), 0, s, first_item, items, len, skip, n_rounds,
+                       piece_len, stored);
 }
 
 void launch_gather(const GatherArgs &g, hipStream_t s) {

@@ -174,6 +174,11 @@ class RoundTable:
 
     __del__ = close
 
+    def set_store_incompressible(self, on=True):
+        """Opt-in: rounds whose frame is not smaller than the input are emitted as-is (compressed=0)."""
+        self.ctx._chk(self.ctx.L.znippy_rounds_set_store_incompressible(self.h, int(on)), "set_store_incompressible")
+        self._store_inc = bool(on)
+
     def blob_bound(self):
         return int(self.ctx.L.znippy_rounds_blob_bound(self.h))
 
@@ -199,9 +204,13 @@ class RoundTable:
             return dict(blob_offset=np.zeros(0, np.uint64), blob_size=np.zeros(0, np.uint64),
                         checksum=np.zeros((0, 32), np.uint8), compressed=np.zeros(0, np.uint8), blob_bytes=0)
         mk = lambda p, nbytes, dt: np.frombuffer((C.c_uint8 * nbytes).from_address(p.value), dtype=dt)
+        comp = self._compressed
+        if getattr(self, "_store_inc", False):  # the device decided per round: take the full (copying) result call
+            comp = np.zeros(k, dtype=np.uint8)
+            self.ctx._chk(self.ctx.L.znippy_rounds_results(self.ctx.h, self.h, None, None, None, np_ptr(comp), None),
+                          "znippy_rounds_results")
         return dict(blob_offset=mk(bo, 8 * k, np.uint64), blob_size=mk(bs, 8 * k, np.uint64),
-                    checksum=mk(ck, 32 * k, np.uint8).reshape(k, 32), compressed=self._compressed,
-                    blob_bytes=int(total.value))
+                    checksum=mk(ck, 32 * k, np.uint8).reshape(k, 32), compressed=comp, blob_bytes=int(total.value))
 
     def encode_hash(self, d_src, d_blob_out, blob_cap=None):
         self.encode_hash_async(d_src, d_blob_out, blob_cap)
