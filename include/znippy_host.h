@@ -8,6 +8,9 @@
  *        compress_stream(&PathBuf, no_skip) -> StreamCompressor{sender(), finish()}
  *        znippy-compress/src/stream_packer.rs:L58-87, pipeline L127-372 (reader chunking L146-206,
  *        writer L255-284, finalizer L293-346)
+ *   znippy_compress_dir            compress_dir(&input_dir, &output, no_skip, plugin = None, repo) -> CompressionReport
+ *        znippy-compress/src/slot_packer.rs:L55-209 (walk L63-78, partition L92-101, big pass rounds L265-280,
+ *        small pass rounds L499, one sub-index of both passes L141-189)
  *   znippy_decompress_archive      decompress_archive(index_path, save_data, out_dir) -> VerifyReport
  *        znippy-common/src/decompress.rs:L39-222
  *   znippy_archive_*               ZnippyArchive::{open,file_count,contains/file_size,extract_file}
@@ -50,11 +53,17 @@ const char *znippy_host_last_error(void);
 
 /* ---- write side ---- */
 int znippy_compress_stream(const char *output, int no_skip, int device, znippy_stream **out);
-/* pkg_type < 0 = None, repo NULL = None (ArchiveEntry, stream_packer.rs:L34-44). Data is copied. */
+/* pkg_type < 0 = None, repo NULL = None (ArchiveEntry, stream_packer.rs:L34-44). Data is copied (once, into
+ * page-locked staging); full staging slots are encoded while the caller keeps sending. */
 int znippy_stream_send(znippy_stream *s, const char *relative_path, const void *data, size_t len,
                        int pkg_type, const char *repo);
-/* Runs the pipeline, writes `<output>.znippy`, fills the report and frees the handle. */
+/* Drains the pipeline, writes the metadata layer of `<output>.znippy`, fills the report and frees the handle. */
 int znippy_stream_finish(znippy_stream *s, znippy_compression_report *report);
+
+/* Directory ingest.  repo NULL = None.  Files are read by a few host threads straight into page-locked staging;
+ * metadata plugins are outside this path. */
+int znippy_compress_dir(const char *input_dir, const char *output, int no_skip, const char *repo, int device,
+                        znippy_compression_report *report);
 
 /* ---- read side ---- */
 /* rank/world split the row cursor into contiguous ranges balanced by uncompressed bytes (world = 1:

@@ -153,3 +153,111 @@ def test_cpp_reads_python_written_archive_and_random_access(tmp_path):
     (tmp_path / "bad.znippy").write_bytes(bytes(raw))
     bad = host.decompress_archive(tmp_path / "bad.znippy", True, tmp_path / "o2")
     assert (bad.corrupt_files, bad.verified_files, bad.corrupt_bytes) == (1, 3, 70000) and len(bad.corrupt_rows) == 1
+
+
+def _tree(root, files):
+    for rel, data in files.items():
+        p = root / rel
+        p.parent.mkdir(parents=True, exist_ok=True)
+        p.write_bytes(data)
+
+
+@gpu
+def test_cpp_pipeline_many_slots_ranges_and_files(tmp_path, monkeypatch):
+    """Small staging slots / decoded ranges force every pipeline hand-off: rounds spilling across slots, a
+    multi-chunk file continuing across ranges (first-touch create before later rows), thousands of output
+    files with one cached descriptor per writer, and a duplicated relative path (single-writer fallback)."""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from znippy_amd import host
+    from znippy_amd.stream_packer import ArchiveEntry, compress_stream as py_compress_stream
+    monkeypatch.setenv("ZNIPPY_HOST_SLOT_MB", "1")      # slots grow to one 8 MiB round at most
+    monkeypatch.setenv("ZNIPPY_HOST_RANGE_MB", "1")
+    rng = np.random.default_rng(5)
+    data = {f"d{i % 7}/f{i:05}.txt": gen.pseudo_text(int(rng.integers(0, 3000)), seed=i) for i in range(3000)}
+    data["big/a.bin"] = gen.binary(20 * 1024 * 1024 + 17)       # 3 rounds of <= 8 MiB
+    data["big/b.jar"] = gen.incompressible(3, 9 * 1024 * 1024)  # stored, 2 rounds
+    data["zz/last.txt"] = gen.text(10240)
+    ents = [ArchiveEntry(k, v) for k, v in data.items()]
+    c = host.compress_stream(tmp_path / "a.znippy", False)
+    for e in ents:
+        c.send(e)
+    rep = c.finish()
+    cp = py_compress_stream(tmp_path / "p.znippy", False)
+    for e in ents:
+        cp.sender().send(e)
+    rep_py = cp.finish()
+    # slot boundaries do not show in the archive: byte-identical blob region + rows vs the one-batch Python mirror
+    assert rep.chunks == rep_py.chunks == 3000 + 3 + 2 + 1
+    a, p = (tmp_path / "a.znippy").read_bytes(), (tmp_path / "p.znippy").read_bytes()
+    ia, ip = host.read_index(tmp_path / "a.znippy")[0], host.read_index(tmp_path / "p.znippy")[0]
+    end = max(r["blob_offset"] + r["blob_size"] for r in ia)
+    assert a[:end] == p[:end]
+    assert ia == ip
+    out = tmp_path / "out"
+    v = host.decompress_archive(tmp_path / "a.znippy", True, out)
+    assert (v.total_files, v.corrupt_files, v.chunks) == (len(data), 0, rep.chunks)
+    for k, want in data.items():
+        assert (out / k).read_bytes() == want, k
+    # pre-existing longer files are truncated on first touch (File::create, decompress.rs:L86)
+    (out / "zz/last.txt").write_bytes(b"x" * 50000)
+    host.decompress_archive(tmp_path / "a.znippy", True, out)
+    assert (out / "zz/last.txt").read_bytes() == data["zz/last.txt"]
+    # duplicated relative path: later entry overlays the earlier one, as positioned writes into one file do
+    c = host.compress_stream(tmp_path / "dup.znippy", False)
+    for k, vbytes in (("x.txt", b"A" * 5000), ("y.txt", b"yy"), ("x.txt", b"B" * 100)):
+        c.send(ArchiveEntry(k, vbytes))
+    c.finish()
+    host.decompress_archive(tmp_path / "dup.znippy", True, tmp_path / "dup")
+    assert (tmp_path / "dup/x.txt").read_bytes() == b"B" * 100 + b"A" * 4900
+
+
+@gpu
+def test_cpp_compress_dir_matches_python_mirror(tmp_path, monkeypatch):
+    """compress_dir (slot_packer.rs:L55-209) on the compiled host: same rows, blob bytes and report as the
+    Python mirror; archive restores the tree."""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from znippy_amd import host
+    from znippy_amd.slot_packer import compress_dir as py_compress_dir, SLOT_SIZE
+    monkeypatch.setenv("ZNIPPY_HOST_SLOT_MB", "4")
+    slice_size = SLOT_SIZE // max(ix.CONFIG.max_core_in_flight, 1)
+    files = {f"src/m{i % 5}/f{i:04}.rs": gen.pseudo_text(200 + 37 * i, seed=i) for i in range(400)}
+    files.update({"README.md": gen.text(10240), "empty.txt": b"", "assets/logo.png": gen.incompressible(1, 40000),
+                  "assets/deep/er/data.bin": gen.binary(2 * slice_size + 12345),      # big pass: 3 rounds
+                  "assets/pack.zip": gen.incompressible(9, slice_size + 5)})         # big + stored: 2 rounds
+    root = tmp_path / "tree"
+    _tree(root, files)
+    (root / "emptydir").mkdir()
+    rep = host.compress_dir(root, tmp_path / "c.znippy", False, repo="myrepo")
+    rep_py = py_compress_dir(root, tmp_path / "p.znippy", False, repo="myrepo")
+    import dataclasses
+    da, dp = dataclasses.asdict(rep), dataclasses.asdict(rep_py)
+    for k in da:   # the metadata layer is written by two Arrow IPC writers (64- vs 8-byte buffer alignment); ratio is f32 here
+        if k not in ("total_bytes_out", "compression_ratio"):
+            assert da[k] == dp[k], k
+    assert abs(rep.compression_ratio - rep_py.compression_ratio) < 1e-3 * max(rep_py.compression_ratio, 1)
+    assert rep.total_files == len(files) and rep.chunks == len(files) + 2 + 1 and rep.total_dirs == rep_py.total_dirs
+    a, p = (tmp_path / "c.znippy").read_bytes(), (tmp_path / "p.znippy").read_bytes()
+    assert len(a) == rep.total_bytes_out and len(p) == rep_py.total_bytes_out
+    ia, ip = host.read_index(tmp_path / "c.znippy")[0], host.read_index(tmp_path / "p.znippy")[0]
+    assert ia == ip
+    end = max(r["blob_offset"] + r["blob_size"] for r in ia)
+    assert a[:end] == p[:end]
+    m = ix.read_znippy_manifest(str(tmp_path / "c.znippy"))
+    assert [(e.pkg_type, e.repo, e.row_count) for e in m] == [(0, "myrepo", rep.chunks)]
+    # pyarrow sees two record batches (big pass, small pass) in the one sub-index
+    sub = a[m[0].index_offset:m[0].index_offset + m[0].index_len]
+    assert [b.num_rows for b in pa.ipc.open_stream(sub)] == [1 + 3 + 2, len(files) - 3]
+    out = tmp_path / "out"
+    v = host.decompress_archive(tmp_path / "c.znippy", True, out)
+    assert (v.total_files, v.corrupt_files) == (len(files), 0)
+    for k, want in files.items():
+        assert (out / k).read_bytes() == want, k
+    # an empty directory still yields a readable archive with zero rows
+    (tmp_path / "nothing").mkdir()
+    r0 = host.compress_dir(tmp_path / "nothing", tmp_path / "n.znippy")
+    assert (r0.total_files, r0.chunks, r0.total_dirs) == (0, 0, 1)
+    assert host.decompress_archive(tmp_path / "n.znippy", False, "/dev/null").total_files == 0

@@ -160,7 +160,11 @@ struct znippy_rounds {
     // encoder plan: one item per output piece
     EncItem *items = nullptr;
     uint32_t n_items = 0;
-    bool small_blocks = true;  // every encoded block <= 16 KiB: small-table encoder variant, more waves
+    // Encoder variant per block, by the block's own length (so a round's frame does not depend on what else is
+    // in the batch): blocks <= 16 KiB go to the small-table variant (more waves), the rest to the wide one.
+    // order_*: item indices of each share; NULL when the whole plan is of one kind.
+    uint32_t *order_small = nullptr, *order_wide = nullptr;
+    uint32_t n_small = 0, n_wide = 0;
     uint64_t prov_bytes = 0;
     uint32_t *piece_len = nullptr, *piece_len_init = nullptr;
     uint64_t *piece_start = nullptr, *local_excl = nullptr, *block_tot = nullptr;
@@ -522,7 +526,7 @@ void znippy_rounds_destroy(znippy_rounds *r) {
     if (!r) return;
     (void)hipSetDevice(r->ctx->device);
     void *ptrs[] = {r->src_off, r->len, r->skip, r->res, r->items, r->piece_len, r->piece_len_init,
-                    r->piece_start, r->local_excl, r->block_tot, r->first_item, r->stored};
+                    r->piece_start, r->local_excl, r->block_tot, r->first_item, r->stored, r->order_small, r->order_wide};
     if (r->h_res) (void)hipHostFree(r->h_res);
     if (r->h_stored) (void)hipHostFree(r->h_stored);
     for (void *p : ptrs)
@@ -567,7 +571,7 @@ int znippy_rounds_create(znippy_ctx *ctx, const uint64_t *src_offset, const uint
     }
     // encoder plan: one item per output piece, in round order
     std::vector<EncItem> items;
-    std::vector<uint32_t> plen, first_item(n, 0);
+    std::vector<uint32_t> plen, first_item(n, 0), ord_small, ord_wide;
     for (uint64_t i = 0; i < n; i++) {
         first_item[i] = (uint32_t)items.size();
         if (r->h_skip[i]) {
@@ -583,7 +587,7 @@ int znippy_rounds_create(znippy_ctx *ctx, const uint64_t *src_offset, const uint
             uint32_t nb = (uint32_t)std::max<uint64_t>(1, (L + BLOCK_BYTES - 1) / BLOCK_BYTES);
             for (uint32_t k = 0; k < nb; k++) {
                 uint32_t bl = (uint32_t)std::min<uint64_t>(BLOCK_BYTES, L - (uint64_t)k * BLOCK_BYTES);
-                if (bl > 16 * 1024) r->small_blocks = false;
+                (bl > 16 * 1024 ? ord_wide : ord_small).push_back((uint32_t)items.size());
                 items.push_back(EncItem{(uint32_t)i, k, nb, k == 0 ? ITEM_FIRST : 0u, r->prov_bytes});
                 plen.push_back(0);
                 r->prov_bytes += enc_slot_bytes(bl);
@@ -592,6 +596,13 @@ int znippy_rounds_create(znippy_ctx *ctx, const uint64_t *src_offset, const uint
     }
     if (items.size() >= 0xFFFFFFF0ull) { znippy_rounds_destroy(r); return ZNIPPY_E_INVAL; }
     r->n_items = (uint32_t)items.size();
+    r->n_small = (uint32_t)ord_small.size();
+    r->n_wide = (uint32_t)ord_wide.size();
+    if ((rc = dev_upload(ctx, &r->order_small, ord_small.data(), ord_small.size())) ||
+        (rc = dev_upload(ctx, &r->order_wide, ord_wide.data(), ord_wide.size()))) {
+        znippy_rounds_destroy(r);
+        return rc;
+    }
     const size_t ni = std::max<size_t>(r->n_items, 1), nsb = (ni + 1023) / 1024;
     if ((rc = dev_upload(ctx, &r->first_item, first_item.data(), first_item.size())) ||
         hipMalloc(&r->stored, std::max<size_t>(n, 16)) != hipSuccess || hipHostMalloc(&r->h_stored, std::max<size_t>(n, 16)) != hipSuccess) {
@@ -729,17 +740,20 @@ extern "C" int znippy_encode_hash_rounds_async(znippy_ctx *ctx, znippy_rounds *r
     r->h_valid = false;
     HIPCHK(ctx, hipMemsetAsync(ctx->cursor, 0, 64, s));
     EncodeArgs a{};
-    a.items = r->items; a.n_items = r->n_items; a.cursor = ctx->cursor;
-    {
-        const int g = r->small_blocks ? ctx->encode_grid_small : ctx->encode_grid;
-        a.batch = std::max<uint32_t>(1, std::min<uint32_t>(16, r->n_items / (uint32_t)(g * 2)));
-    }
+    a.items = r->items;
     a.src = (const uint8_t *)d_src; a.src_off = r->src_off; a.len = r->len;
     a.prov = ctx->enc_prov; a.seq_scratch = ctx->enc_seq;
     a.piece_len = r->piece_len; a.piece_start = r->piece_start; a.tabs = ctx->enc_tabs;
     ktime_begin(ctx, "zstd_encode");
-    launch_encode(a, std::min<int>(r->small_blocks ? ctx->encode_grid_small : ctx->encode_grid, (int)r->n_items),
-                  r->small_blocks, s);
+    for (int wide = 1; wide >= 0; wide--) {  // the wide share first: its blocks are the long ones
+        a.n_items = wide ? r->n_wide : r->n_small;
+        if (!a.n_items) continue;
+        a.order = a.n_items == r->n_items ? nullptr : (wide ? r->order_wide : r->order_small);  // all of one kind: no indirection
+        a.cursor = ctx->cursor + (wide ? 8 : 0);
+        const int g = wide ? ctx->encode_grid : ctx->encode_grid_small;
+        a.batch = std::max<uint32_t>(1, std::min<uint32_t>(16, a.n_items / (uint32_t)(g * 2)));
+        launch_encode(a, std::min<int>(g, (int)a.n_items), !wide, s);
+    }
     ktime_end(ctx);
     // checksum over the ORIGINAL bytes (stream_packer.rs:L219): VALU-bound, submitted to the
     // auxiliary stream right after the persistent (latency-bound) encoder so both share the CUs

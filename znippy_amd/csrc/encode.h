@@ -38,7 +38,8 @@ inline uint64_t enc_slot_bytes(uint32_t n) { return ((HDR_ROOM + 16 + (uint64_t)
 
 struct EncodeArgs {
     const EncItem *items;
-    uint32_t n_items;
+    const uint32_t *order;  // optional: indices into items[] this launch works through (NULL = 0..n_items-1)
+    uint32_t n_items;       // entries in order[] (or in items[])
     uint32_t *cursor;
     uint32_t batch;  // items per cursor dequeue
     const uint8_t *src;

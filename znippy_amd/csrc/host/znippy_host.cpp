@@ -9,7 +9,13 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
+#include <chrono>
 #include <cmath>
+#include <condition_variable>
+#include <deque>
+#include <dirent.h>
+#include <mutex>
 #include <cstdio>
 #include <cstring>
 #include <fcntl.h>
@@ -33,8 +39,29 @@ int fail(int code, const std::string &msg) {
 }
 
 constexpr uint64_t SLICE_SIZE = 8ull * 1024 * 1024;  // stream_packer.rs:L31
-constexpr uint64_t BATCH_BYTES = 1ull << 30;          // staging handed to the GPU at once
-constexpr uint64_t RANGE_BYTES = 4ull << 30;          // decoded bytes per GPU hand-off on the read side
+constexpr uint64_t SLOT_SIZE = 200ull * 1024 * 1024;  // slot_packer.rs:L30
+constexpr int N_STAGE = 3;                            // pinned staging slots in flight on the write side
+constexpr size_t MAX_SLOT_ROUNDS = 1u << 20;
+
+uint64_t env_mb(const char *name, uint64_t dflt_mb) {
+    const char *v = getenv(name);
+    const uint64_t mb = v && *v ? strtoull(v, nullptr, 10) : 0;
+    return (mb ? mb : dflt_mb) << 20;
+}
+// Bytes per GPU hand-off: one pinned staging slot on the write side, one decoded range on the read side.
+uint64_t stage_bytes() { return env_mb("ZNIPPY_HOST_SLOT_MB", 128); }
+uint64_t range_bytes(bool save) { return env_mb("ZNIPPY_HOST_RANGE_MB", save ? 256 : 1024); }
+unsigned io_threads() {
+    unsigned hw = std::thread::hardware_concurrency();
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof set, &set) == 0) hw = (unsigned)CPU_COUNT(&set);
+    const char *v = getenv("ZNIPPY_HOST_IO_THREADS");
+    unsigned want = v && *v ? (unsigned)strtoul(v, nullptr, 10) : 8;
+    return std::max(1u, std::min(want, hw ? hw : 1u));
+}
+
+double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+bool trace_on() { const char *v = getenv("ZNIPPY_HOST_TRACE"); return v && *v && *v != '0'; }
 const char MAGIC[8] = {'Z', 'N', 'P', 'Y', 'M', 'I', 'D', 'X'};  // index.rs:L245
 
 // is_probably_compressed, index.rs:L470-484 — last extension, case-insensitive
@@ -146,6 +173,23 @@ struct DevBuf {
         return true;
     }
     ~DevBuf() { if (p) (void)hipFree(p); }
+};
+
+// ---- page-locked host buffer (grow-only): DMA source/target, faulted in once and reused ----
+struct PinBuf {
+    uint8_t *p = nullptr;
+    size_t cap = 0;
+    bool reserve(size_t n) {
+        if (n <= cap && p) return true;
+        if (p) (void)hipHostFree(p);
+        p = nullptr;
+        cap = 0;
+        size_t want = std::max<size_t>(n, 1 << 20);
+        if (hipHostMalloc((void **)&p, want, hipHostMallocDefault) != hipSuccess) { p = nullptr; return false; }
+        cap = want;
+        return true;
+    }
+    ~PinBuf() { if (p) (void)hipHostFree(p); }
 };
 
 bool pread_all(int fd, void *dst, size_t n, uint64_t off) {
@@ -261,35 +305,249 @@ static int load_index(const char *path, znippy_index *ix) {
     return ZNIPPY_OK;
 }
 
+namespace {
+
 // ---------------------------------------------------------------------------------------------------
-struct Entry {
-    std::string path;
-    std::vector<uint8_t> data;
-    int pkg_type;       // < 0 = None
-    bool has_repo;
-    std::string repo;
-};
-
-struct znippy_stream {
-    std::string output;
-    bool no_skip;
-    int device;
-    std::vector<Entry> entries;
-};
-
-struct Round {
-    uint32_t file_index;
-    uint64_t start, len;
+// Write side.  Rounds are laid into page-locked staging slots in reservation order; a device thread takes
+// full slots (H2D -> encode+hash kernels -> D2H of the packed blobs -> pwrite) while the producer fills the
+// next one.  Stands for the reader -> barrel -> writer channel chain of stream_packer.rs:L146-284 and the
+// Magazine of slot_packer.rs:L222-330: the channels carry slots instead of Rounds, the barrels are kernels.
+struct RoundRec {
+    uint32_t file_index, chunk_seq;
+    uint64_t fdata_offset, len, pos;  // pos = byte position in the slot
     bool skip;
-    uint64_t fdata_offset;
-    uint32_t chunk_seq;
+    uint8_t pass;                     // compress_dir: 0 = big pass, 1 = small pass
 };
 
 struct RowMeta {  // BlobMeta + ChunkMeta, meta.rs:L4-21
     uint32_t file_index, chunk_seq;
     uint64_t fdata_offset, usize, blob_offset, blob_size;
     bool compressed;
+    uint8_t pass;
     uint8_t checksum[32];
+};
+
+struct StageSlot {
+    PinBuf buf;
+    size_t used = 0;
+    std::vector<RoundRec> rounds;
+    std::atomic<int> pending{0};  // asynchronous reads still landing in this slot
+};
+
+class Packer {
+public:
+    Packer(int fd, int device, uint64_t max_round) : fd_(fd), device_(device), slot_cap_(std::max(stage_bytes(), max_round)) {}
+    ~Packer() {
+        if (thread_.joinable()) { push_full(nullptr); thread_.join(); }
+        if (ctx_) znippy_ctx_destroy(ctx_);
+    }
+    int start() {
+        hipError_t e = hipSetDevice(device_);
+        if (e != hipSuccess) return fail(ZNIPPY_E_HIP, std::string("hipSetDevice failed: ") + hipGetErrorString(e));
+        int rc = znippy_ctx_create(device_, nullptr, &ctx_);
+        if (rc) return fail(rc, "znippy_ctx_create failed: no usable GPU (the codec/hash path has no CPU fallback)");
+        for (auto &s : slots_) free_.push_back(&s);
+        thread_ = std::thread([this] { run(); });
+        return ZNIPPY_OK;
+    }
+    // Reserve r.len bytes for the next round.  async = the bytes arrive later (reader threads call landed()).
+    uint8_t *reserve(RoundRec r, bool async, StageSlot **slot_out = nullptr) {
+        if (!cur_ || cur_->used + r.len > cur_->buf.cap || cur_->rounds.size() >= MAX_SLOT_ROUNDS) {
+            if (cur_) push_full(cur_);
+            cur_ = pop_free();
+            if (!cur_->buf.reserve(slot_cap_)) { set_error(ZNIPPY_E_NOMEM, "page-locked staging allocation failed"); return nullptr; }
+        }
+        r.pos = cur_->used;
+        cur_->rounds.push_back(r);
+        cur_->used += r.len;
+        if (async && r.len) cur_->pending.fetch_add(1, std::memory_order_relaxed);
+        if (slot_out) *slot_out = cur_;
+        return cur_->buf.p + r.pos;
+    }
+    // True when the next reserve(len) has to hand the current slot over (and may wait for a free one).
+    bool would_switch(uint64_t len) const { return !cur_ || cur_->used + len > cur_->buf.cap || cur_->rounds.size() >= MAX_SLOT_ROUNDS; }
+    void landed(StageSlot *s) {
+        if (s->pending.fetch_sub(1, std::memory_order_acq_rel) == 1) {  // lock so that the wake cannot slip past the waiter's check
+            std::lock_guard<std::mutex> g(mu_);
+            cv_.notify_all();
+        }
+    }
+    void set_error(int rc, const std::string &msg) {
+        std::lock_guard<std::mutex> g(mu_);
+        if (!rc_) { rc_ = rc; err_ = msg; }
+    }
+    int error() { std::lock_guard<std::mutex> g(mu_); return rc_; }
+    // Flush, wait for the device thread, return the pipeline status (message via fail()).
+    int finish() {
+        if (cur_) { push_full(cur_); cur_ = nullptr; }
+        push_full(nullptr);
+        thread_.join();
+        if (trace_on())
+            fprintf(stderr, "[host] write: slots %d  wait %.1f ms  h2d %.1f ms  kernels %.1f ms  d2h %.1f ms  pwrite %.1f ms\n", n_slots_,
+                    t_wait_ * 1e3, t_h2d_ * 1e3, t_kern_ * 1e3, t_d2h_ * 1e3, t_write_ * 1e3);
+        return rc_ ? fail(rc_, "compress pipeline failed: " + err_) : ZNIPPY_OK;
+    }
+    std::vector<RowMeta> rows;
+    uint64_t out_cursor = 0;  // blob region starts at 0 (stream_packer.rs:L134)
+
+private:
+    void push_full(StageSlot *s) {
+        std::lock_guard<std::mutex> g(mu_);
+        full_.push_back(s);
+        cv_.notify_all();
+    }
+    StageSlot *pop_free() {
+        std::unique_lock<std::mutex> g(mu_);
+        cv_.wait(g, [this] { return !free_.empty(); });
+        StageSlot *s = free_.front();
+        free_.pop_front();
+        return s;
+    }
+    void run() {
+        (void)hipSetDevice(device_);
+        for (;;) {
+            StageSlot *s;
+            const double t0 = now_s();
+            {
+                std::unique_lock<std::mutex> g(mu_);
+                cv_.wait(g, [this] { return !full_.empty(); });
+                s = full_.front();
+                full_.pop_front();
+                if (s) cv_.wait(g, [s] { return s->pending.load(std::memory_order_acquire) == 0; });
+            }
+            t_wait_ += now_s() - t0;
+            if (!s) return;
+            if (!error()) {
+                std::string msg;
+                int rc = process(*s, &msg);
+                if (rc) set_error(rc, msg);
+            }
+            s->used = 0;
+            s->rounds.clear();
+            std::lock_guard<std::mutex> g(mu_);
+            free_.push_back(s);
+            cv_.notify_all();
+        }
+    }
+    int process(StageSlot &s, std::string *msg) {
+        const size_t nb = s.rounds.size();
+        if (!nb) return ZNIPPY_OK;
+        n_slots_++;
+        std::vector<uint64_t> off(nb), len(nb), boff(nb), bsz(nb);
+        std::vector<uint8_t> skip(nb), comp(nb), ck(32 * nb);
+        for (size_t k = 0; k < nb; k++) { off[k] = s.rounds[k].pos; len[k] = s.rounds[k].len; skip[k] = s.rounds[k].skip; }
+        double t = now_s();
+        if (!d_src_.reserve(s.buf.cap + 64)) { *msg = "device staging allocation failed"; return ZNIPPY_E_NOMEM; }
+        if (s.used && hipMemcpy(d_src_.p, s.buf.p, s.used, hipMemcpyHostToDevice) != hipSuccess) { *msg = "H2D failed"; return ZNIPPY_E_HIP; }
+        t_h2d_ += now_s() - t; t = now_s();
+        znippy_rounds *rt = nullptr;
+        uint64_t blob_bytes = 0;
+        int rc = znippy_rounds_create(ctx_, off.data(), len.data(), skip.data(), nb, &rt);
+        if (!rc && !d_blob_.reserve(znippy_rounds_blob_bound(rt) + 64)) rc = ZNIPPY_E_NOMEM;
+        if (!rc) rc = znippy_encode_hash_rounds(ctx_, rt, d_src_.p, d_blob_.p, d_blob_.cap, boff.data(), bsz.data(), ck.data(), comp.data(), &blob_bytes);
+        if (rt) znippy_rounds_destroy(rt);
+        if (rc) { *msg = znippy_last_error(ctx_); return rc; }
+        t_kern_ += now_s() - t; t = now_s();
+        if (!blob_pin_.reserve(blob_bytes)) { *msg = "page-locked blob allocation failed"; return ZNIPPY_E_NOMEM; }
+        if (blob_bytes && hipMemcpy(blob_pin_.p, d_blob_.p, blob_bytes, hipMemcpyDeviceToHost) != hipSuccess) { *msg = "D2H failed"; return ZNIPPY_E_HIP; }
+        t_d2h_ += now_s() - t; t = now_s();
+        if (!pwrite_all(fd_, blob_pin_.p, blob_bytes, out_cursor)) { *msg = "archive write failed"; return ZNIPPY_E_INVAL; }  // the writer, L255-284
+        t_write_ += now_s() - t;
+        for (size_t k = 0; k < nb; k++) {
+            const RoundRec &r = s.rounds[k];
+            RowMeta m{r.file_index, r.chunk_seq, r.fdata_offset, r.len, out_cursor + boff[k], bsz[k], comp[k] != 0, r.pass, {0}};
+            std::memcpy(m.checksum, &ck[32 * k], 32);
+            rows.push_back(m);
+        }
+        out_cursor += blob_bytes;
+        return ZNIPPY_OK;
+    }
+
+    int fd_, device_;
+    uint64_t slot_cap_;
+    znippy_ctx *ctx_ = nullptr;
+    StageSlot slots_[N_STAGE];
+    StageSlot *cur_ = nullptr;
+    std::deque<StageSlot *> free_, full_;
+    std::mutex mu_;
+    std::condition_variable cv_;
+    std::thread thread_;
+    int rc_ = 0;
+    std::string err_;
+    DevBuf d_src_, d_blob_;
+    PinBuf blob_pin_;
+    int n_slots_ = 0;
+    double t_wait_ = 0, t_h2d_ = 0, t_kern_ = 0, t_d2h_ = 0, t_write_ = 0;
+};
+
+// The metadata layer: one Arrow-IPC sub-index stream per group, then manifest + footer (ArrowIpcSink,
+// meta_sink.rs:L71-118).  Returns total_bytes_out.
+struct SubIndex {
+    int8_t pkg_type;
+    std::string repo;
+    std::vector<std::vector<size_t>> batches;  // row numbers per record batch
+};
+
+template <class PathOf>
+uint64_t write_metadata(int fd, uint64_t blob_end, const std::vector<RowMeta> &rows, PathOf path_of, const std::vector<SubIndex> &subs) {
+    const auto meta = config_metadata();
+    uint64_t cursor = blob_end;
+    std::vector<Manifest> manifest;
+    for (const auto &g : subs) {
+        std::vector<aipc::Batch> bs;
+        uint64_t n_rows = 0;
+        for (const auto &ids : g.batches) {
+            aipc::Batch b = index_schema();
+            for (size_t k : ids) {
+                const RowMeta &m = rows[k];
+                b.cols[0].str.push_back(path_of(m.file_index));
+                b.cols[1].u32.push_back(m.chunk_seq);
+                b.cols[2].u64.push_back(m.fdata_offset);
+                b.cols[3].u8.push_back(m.compressed);
+                b.cols[4].u64.push_back(m.usize);
+                b.cols[5].u64.push_back(m.blob_offset);
+                b.cols[6].u64.push_back(m.blob_size);
+                b.cols[7].u8.insert(b.cols[7].u8.end(), m.checksum, m.checksum + 32);
+            }
+            n_rows += ids.size();
+            bs.push_back(std::move(b));
+        }
+        std::vector<uint8_t> sub = aipc::write_stream(bs, index_schema(), meta);
+        pwrite_all(fd, sub.data(), sub.size(), cursor);  // push_subindex, meta_sink.rs:L71-101
+        manifest.push_back({g.pkg_type, g.repo, "", cursor, sub.size(), n_rows});
+        cursor += sub.size();
+    }
+    const uint64_t manifest_offset = cursor;  // finish, meta_sink.rs:L103-118
+    std::vector<uint8_t> mb = manifest_bytes(manifest);
+    pwrite_all(fd, mb.data(), mb.size(), cursor);
+    cursor += mb.size();
+    pwrite_all(fd, MAGIC, 8, cursor);
+    pwrite_all(fd, &manifest_offset, 8, cursor + 8);
+    fsync(fd);
+    return cursor + 16;
+}
+
+struct FileMeta {
+    std::string path;
+    int pkg_type;  // < 0 = None
+    bool has_repo;
+    std::string repo;
+};
+
+}  // namespace
+
+struct znippy_stream {
+    std::string out_path;
+    bool no_skip = false;
+    int fd = -1;
+    std::unique_ptr<Packer> packer;
+    std::vector<FileMeta> files;
+    uint64_t uf = 0, ub = 0, cf = 0, cb = 0;
+    double t_open = 0, t_send = 0;
+    ~znippy_stream() {
+        packer.reset();
+        if (fd >= 0) close(fd);
+    }
 };
 
 extern "C" {
@@ -312,224 +570,418 @@ size_t znippy_write_manifest_bytes(const znippy_manifest_entry *entries, size_t 
     return b.size();
 }
 
-// ---- write side -------------------------------------------------------------------------------
+// ---- write side: compress_stream --------------------------------------------------------------
 int znippy_compress_stream(const char *output, int no_skip, int device, znippy_stream **out) {
     if (!output || !out) return fail(ZNIPPY_E_INVAL, "null argument");
-    znippy_stream *s = new znippy_stream();
-    s->output = output;
+    std::unique_ptr<znippy_stream> s(new znippy_stream());
+    s->t_open = now_s();
+    s->out_path = with_extension(output, "znippy");  // stream_packer.rs:L132
     s->no_skip = no_skip != 0;
-    s->device = device;
-    *out = s;
+    s->fd = open(s->out_path.c_str(), O_CREAT | O_TRUNC | O_RDWR, 0644);
+    if (s->fd < 0) return fail(ZNIPPY_E_INVAL, "cannot create " + s->out_path);
+    s->packer.reset(new Packer(s->fd, device, SLICE_SIZE));
+    int rc = s->packer->start();
+    if (rc) return rc;
+    *out = s.release();
     return ZNIPPY_OK;
 }
 
+// The reader's chunking (stream_packer.rs:L146-206) runs on the caller's thread: each entry is cut into
+// Rounds and copied once, straight into page-locked staging.
 int znippy_stream_send(znippy_stream *s, const char *relative_path, const void *data, size_t len, int pkg_type,
                        const char *repo) {
     if (!s || !relative_path || (len && !data)) return fail(ZNIPPY_E_INVAL, "null argument");
-    Entry e;
-    e.path = relative_path;
-    e.data.assign((const uint8_t *)data, (const uint8_t *)data + len);
-    e.pkg_type = pkg_type;
-    e.has_repo = repo != nullptr;
-    if (repo) e.repo = repo;
-    s->entries.push_back(std::move(e));
+    const double t0 = now_s();
+    const uint32_t fi = (uint32_t)s->files.size();
+    s->files.push_back({relative_path, pkg_type, repo != nullptr, repo ? repo : ""});
+    const bool skip = !s->no_skip && should_skip_compression(s->files.back().path);
+    if (skip) { s->uf++; s->ub += len; } else { s->cf++; s->cb += len; }
+    if (len == 0) {  // L169-183: one zero-length row
+        if (!s->packer->reserve({fi, 0, 0, 0, 0, skip, 0}, false)) return fail(ZNIPPY_E_NOMEM, "staging allocation failed");
+    } else {
+        const bool small = len <= SLICE_SIZE;
+        uint64_t off = 0;
+        uint32_t seq = 0;
+        while (off < len) {
+            const uint64_t n = small ? len : std::min<uint64_t>(SLICE_SIZE, len - off);
+            uint8_t *dst = s->packer->reserve({fi, seq, off, n, 0, skip, 0}, false);
+            if (!dst) return fail(ZNIPPY_E_NOMEM, "staging allocation failed");
+            std::memcpy(dst, (const uint8_t *)data + off, n);
+            off += n;
+            seq++;
+        }
+    }
+    s->t_send += now_s() - t0;
     return ZNIPPY_OK;
 }
 
 int znippy_stream_finish(znippy_stream *sp, znippy_compression_report *report) {
     if (!sp) return fail(ZNIPPY_E_INVAL, "null stream");
     std::unique_ptr<znippy_stream> s(sp);
-    const std::string out_path = with_extension(s->output, "znippy");  // stream_packer.rs:L132
-    // the reader: entries -> Rounds (stream_packer.rs:L146-206)
-    std::vector<Round> rounds;
-    uint64_t uf = 0, ub = 0, cf = 0, cb = 0;
-    for (uint32_t fi = 0; fi < s->entries.size(); fi++) {
-        const Entry &e = s->entries[fi];
-        const bool skip = !s->no_skip && should_skip_compression(e.path);
-        const uint64_t total = e.data.size();
-        if (skip) { uf++; ub += total; } else { cf++; cb += total; }
-        if (total == 0) { rounds.push_back({fi, 0, 0, skip, 0, 0}); continue; }  // L169-183
-        const bool small = total <= SLICE_SIZE;
-        uint64_t off = 0;
-        uint32_t seq = 0;
-        while (off < total) {
-            const uint64_t len = small ? total : std::min(SLICE_SIZE, total - off);
-            rounds.push_back({fi, off, len, skip, off, seq});
-            off += len;
-            seq++;
-        }
-    }
-    int fd = open(out_path.c_str(), O_CREAT | O_TRUNC | O_RDWR, 0644);
-    if (fd < 0) return fail(ZNIPPY_E_INVAL, "cannot create " + out_path);
-    {
-        hipError_t e = hipSetDevice(s->device);
-        if (e != hipSuccess) { close(fd); return fail(ZNIPPY_E_HIP, std::string("hipSetDevice failed: ") + hipGetErrorString(e)); }
-    }
-    znippy_ctx *ctx = nullptr;
-    int rc = znippy_ctx_create(s->device, nullptr, &ctx);
-    if (rc) { close(fd); return fail(rc, "znippy_ctx_create failed"); }
-    std::vector<RowMeta> rows;
-    rows.reserve(rounds.size());
-    uint64_t out_cursor = 0;  // blob region starts at 0 (L134)
-    DevBuf d_src, d_blob;
-    std::vector<uint8_t> staging, blob;
-    size_t i = 0;
-    while (i < rounds.size() && rc == ZNIPPY_OK) {
-        size_t j = i;
-        uint64_t nbytes = 0;
-        while (j < rounds.size() && (j == i || nbytes + rounds[j].len <= BATCH_BYTES)) nbytes += rounds[j++].len;
-        const size_t nb = j - i;
-        staging.resize(nbytes);
-        std::vector<uint64_t> off(nb), len(nb), boff(nb), bsz(nb);
-        std::vector<uint8_t> skip(nb), comp(nb), ck(32 * nb);
-        uint64_t pos = 0;
-        for (size_t k = 0; k < nb; k++) {
-            const Round &r = rounds[i + k];
-            if (r.len) std::memcpy(&staging[pos], s->entries[r.file_index].data.data() + r.start, r.len);
-            off[k] = pos; len[k] = r.len; skip[k] = r.skip;
-            pos += r.len;
-        }
-        znippy_rounds *rt = nullptr;
-        uint64_t blob_bytes = 0;
-        if (!d_src.reserve(nbytes + 64)) rc = ZNIPPY_E_NOMEM;
-        if (!rc && nbytes && hipMemcpy(d_src.p, staging.data(), nbytes, hipMemcpyHostToDevice) != hipSuccess) rc = ZNIPPY_E_HIP;
-        if (!rc) rc = znippy_rounds_create(ctx, off.data(), len.data(), skip.data(), nb, &rt);
-        if (!rc && !d_blob.reserve(znippy_rounds_blob_bound(rt) + 64)) rc = ZNIPPY_E_NOMEM;
-        if (!rc) rc = znippy_encode_hash_rounds(ctx, rt, d_src.p, d_blob.p, d_blob.cap, boff.data(), bsz.data(), ck.data(),
-                                                comp.data(), &blob_bytes);
-        if (rt) znippy_rounds_destroy(rt);
-        if (rc) break;
-        blob.resize(blob_bytes);
-        if (blob_bytes && hipMemcpy(blob.data(), d_blob.p, blob_bytes, hipMemcpyDeviceToHost) != hipSuccess) { rc = ZNIPPY_E_HIP; break; }
-        if (!pwrite_all(fd, blob.data(), blob_bytes, out_cursor)) { rc = ZNIPPY_E_INVAL; break; }  // the writer, L255-284
-        for (size_t k = 0; k < nb; k++) {
-            const Round &r = rounds[i + k];
-            RowMeta m{r.file_index, r.chunk_seq, r.fdata_offset, r.len, out_cursor + boff[k], bsz[k], comp[k] != 0, {0}};
-            std::memcpy(m.checksum, &ck[32 * k], 32);
-            rows.push_back(m);
-        }
-        out_cursor += blob_bytes;
-        i = j;
-    }
-    if (rc) {
-        std::string e = znippy_last_error(ctx);
-        znippy_ctx_destroy(ctx);
-        close(fd);
-        return fail(rc, "compress pipeline failed: " + e);
-    }
-    znippy_ctx_destroy(ctx);
+    const double t0 = now_s();
+    int rc = s->packer->finish();
+    if (rc) return rc;
+    const double t1 = now_s();
+    std::vector<RowMeta> &rows = s->packer->rows;
     // finalizer (L293-346): rows sorted by (file_index, chunk_seq), grouped by (pkg_type, repo) in BTreeMap order
     std::stable_sort(rows.begin(), rows.end(), [](const RowMeta &a, const RowMeta &b) {
         return a.file_index != b.file_index ? a.file_index < b.file_index : a.chunk_seq < b.chunk_seq;
     });
     std::map<std::pair<int8_t, std::string>, std::vector<size_t>> groups;
     for (size_t k = 0; k < rows.size(); k++) {
-        const Entry &e = s->entries[rows[k].file_index];
+        const FileMeta &e = s->files[rows[k].file_index];
         groups[{(int8_t)(e.pkg_type < 0 ? 0 : e.pkg_type), e.has_repo ? e.repo : std::string()}].push_back(k);
     }
-    const auto meta = config_metadata();
-    uint64_t cursor = out_cursor;
-    std::vector<Manifest> manifest;
-    for (const auto &g : groups) {
-        aipc::Batch b = index_schema();
-        for (size_t k : g.second) {
-            const RowMeta &m = rows[k];
-            b.cols[0].str.push_back(s->entries[m.file_index].path);
-            b.cols[1].u32.push_back(m.chunk_seq);
-            b.cols[2].u64.push_back(m.fdata_offset);
-            b.cols[3].u8.push_back(m.compressed);
-            b.cols[4].u64.push_back(m.usize);
-            b.cols[5].u64.push_back(m.blob_offset);
-            b.cols[6].u64.push_back(m.blob_size);
-            b.cols[7].u8.insert(b.cols[7].u8.end(), m.checksum, m.checksum + 32);
-        }
-        std::vector<uint8_t> sub = aipc::write_stream({b}, index_schema(), meta);
-        pwrite_all(fd, sub.data(), sub.size(), cursor);  // ArrowIpcSink::push_subindex, meta_sink.rs:L71-101
-        manifest.push_back({g.first.first, g.first.second, "", cursor, sub.size(), g.second.size()});
-        cursor += sub.size();
-    }
-    const uint64_t manifest_offset = cursor;  // ArrowIpcSink::finish, meta_sink.rs:L103-118
-    std::vector<uint8_t> mb = manifest_bytes(manifest);
-    pwrite_all(fd, mb.data(), mb.size(), cursor);
-    cursor += mb.size();
-    pwrite_all(fd, MAGIC, 8, cursor);
-    pwrite_all(fd, &manifest_offset, 8, cursor + 8);
-    fsync(fd);
-    close(fd);
-    const uint64_t total_bytes_out = cursor + 16;
+    std::vector<SubIndex> subs;
+    for (auto &g : groups) subs.push_back({g.first.first, g.first.second, {std::move(g.second)}});
+    const uint64_t total_bytes_out =
+        write_metadata(s->fd, s->packer->out_cursor, rows, [&](uint32_t fi) -> const std::string & { return s->files[fi].path; }, subs);
+    if (trace_on())
+        fprintf(stderr, "[host] compress_stream: open->finish %.1f ms (send calls %.1f ms)  drain %.1f ms  metadata %.1f ms\n",
+                (t0 - s->t_open) * 1e3, s->t_send * 1e3, (t1 - t0) * 1e3, (now_s() - t1) * 1e3);
     if (report) {
-        *report = znippy_compression_report{uf + cf, cf, uf, 0, cb + ub, total_bytes_out, cb, ub, (uint64_t)rows.size(),
-                                            (cb > 0 && total_bytes_out > ub) ? (float)cb / (float)(total_bytes_out - ub) * 100.0f : 0.0f};
+        *report = znippy_compression_report{s->uf + s->cf, s->cf, s->uf, 0, s->cb + s->ub, total_bytes_out, s->cb, s->ub, (uint64_t)rows.size(),
+                                            (s->cb > 0 && total_bytes_out > s->ub) ? (float)s->cb / (float)(total_bytes_out - s->ub) * 100.0f : 0.0f};
+    }
+    return ZNIPPY_OK;
+}
+
+// ---- write side: compress_dir (slot_packer.rs:L55-209) ------------------------------------------
+}  // extern "C"
+
+namespace {
+
+// WalkDir order (L63-78): a directory's files, then its sub-directories, both in name order; only regular
+// files are ingested, every directory (the root too) is counted.
+void walk_dir(const std::string &dir, std::vector<std::string> *files, std::vector<uint64_t> *sizes, uint64_t *n_dirs) {
+    DIR *d = opendir(dir.c_str());
+    if (!d) return;
+    (*n_dirs)++;
+    std::vector<std::pair<std::string, uint64_t>> fs;
+    std::vector<std::string> ds;
+    while (struct dirent *e = readdir(d)) {
+        const std::string name = e->d_name;
+        if (name == "." || name == "..") continue;
+        if (e->d_type == DT_DIR) { ds.push_back(name); continue; }
+        if (e->d_type != DT_REG && e->d_type != DT_UNKNOWN) continue;
+        struct stat st;
+        if (lstat((dir + "/" + name).c_str(), &st) != 0) continue;
+        if (S_ISDIR(st.st_mode)) ds.push_back(name);
+        else if (S_ISREG(st.st_mode)) fs.emplace_back(name, (uint64_t)st.st_size);
+    }
+    closedir(d);
+    std::sort(fs.begin(), fs.end());
+    std::sort(ds.begin(), ds.end());
+    for (const auto &f : fs) {
+        files->push_back(dir + "/" + f.first);
+        sizes->push_back(f.second);
+    }
+    for (const auto &sub : ds) walk_dir(dir + "/" + sub, files, sizes, n_dirs);
+}
+
+struct ReadTask {
+    uint32_t file_index;
+    uint64_t off, len;
+    uint8_t *dst;
+    StageSlot *slot;
+};
+
+// File readers feeding the staging slots (the io_uring reader's job, slot_packer.rs:L236-330, as plain
+// positional reads on a few threads — the device path downstream is what this library is about).
+class ReaderPool {
+public:
+    ReaderPool(Packer *pk, const std::vector<std::string> *files, unsigned n) : pk_(pk), files_(files) {
+        for (unsigned i = 0; i < n; i++) th_.emplace_back([this] { run(); });
+    }
+    // Tasks are handed over in batches (one lock + wake per batch, not per file); flush() before anything that
+    // may wait for a slot to drain.
+    void push(const ReadTask &t) {
+        batch_.push_back(t);
+        if (batch_.size() >= 256) flush();
+    }
+    void flush() {
+        if (batch_.empty()) return;
+        std::lock_guard<std::mutex> g(mu_);
+        q_.insert(q_.end(), batch_.begin(), batch_.end());
+        batch_.clear();
+        cv_.notify_all();
+    }
+    void join() {
+        flush();
+        {
+            std::lock_guard<std::mutex> g(mu_);
+            done_ = true;
+            cv_.notify_all();
+        }
+        for (auto &t : th_) t.join();
+        th_.clear();
+    }
+    ~ReaderPool() { if (!th_.empty()) join(); }
+
+private:
+    void run() {
+        int fd = -1;
+        uint32_t cur = UINT32_MAX;
+        for (;;) {
+            ReadTask ts[16];
+            int nt = 0;
+            {
+                std::unique_lock<std::mutex> g(mu_);
+                cv_.wait(g, [this] { return done_ || !q_.empty(); });
+                if (q_.empty()) break;
+                while (nt < 16 && !q_.empty()) { ts[nt++] = q_.front(); q_.pop_front(); }
+            }
+            for (int i = 0; i < nt; i++) {
+                const ReadTask &t = ts[i];
+                if (t.file_index != cur) {
+                    if (fd >= 0) close(fd);
+                    fd = open((*files_)[t.file_index].c_str(), O_RDONLY);
+                    cur = t.file_index;
+                }
+                if (fd < 0 || !pread_all(fd, t.dst, t.len, t.off)) pk_->set_error(ZNIPPY_E_INVAL, "failed to read " + (*files_)[t.file_index]);
+                pk_->landed(t.slot);
+            }
+        }
+        if (fd >= 0) close(fd);
+    }
+    Packer *pk_;
+    const std::vector<std::string> *files_;
+    std::vector<std::thread> th_;
+    std::deque<ReadTask> q_;
+    std::vector<ReadTask> batch_;
+    std::mutex mu_;
+    std::condition_variable cv_;
+    bool done_ = false;
+};
+
+}  // namespace
+
+extern "C" {
+
+int znippy_compress_dir(const char *input_dir, const char *output, int no_skip, const char *repo, int device,
+                        znippy_compression_report *report) {
+    if (!input_dir || !output) return fail(ZNIPPY_E_INVAL, "null argument");
+    const double t_begin = now_s();
+    std::string root = input_dir;
+    while (root.size() > 1 && root.back() == '/') root.pop_back();
+    std::vector<std::string> files;
+    std::vector<uint64_t> sizes;
+    uint64_t total_dirs = 0;
+    walk_dir(root, &files, &sizes, &total_dirs);
+    const double t_walk = now_s();
+    unsigned cores = std::thread::hardware_concurrency();
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof set, &set) == 0) cores = (unsigned)CPU_COUNT(&set);
+    const uint64_t num_workers = std::max<uint64_t>((uint64_t)std::ceil(std::max(cores, 1u) * 0.90), 1);  // CONFIG.max_core_in_flight
+    const uint64_t slice_size = SLOT_SIZE / num_workers;  // L89
+    const std::string out_path = with_extension(output, "znippy");
+    int fd = open(out_path.c_str(), O_CREAT | O_TRUNC | O_RDWR, 0644);
+    if (fd < 0) return fail(ZNIPPY_E_INVAL, "cannot create " + out_path);
+    uint64_t uf = 0, ub = 0, cf = 0, cb = 0;
+    std::vector<RowMeta> rows;
+    uint64_t blob_bytes = 0;
+    {
+        Packer pk(fd, device, std::max<uint64_t>(slice_size, 1));
+        int rc = pk.start();
+        if (rc) { close(fd); return rc; }
+        ReaderPool readers(&pk, &files, io_threads());
+        bool ok = true;
+        for (int pass = 0; pass < 2 && ok; pass++) {  // partition L92-101: pass 0 = big (or empty) files, pass 1 = small
+            for (uint32_t i = 0; i < files.size() && ok; i++) {
+                const uint64_t size = sizes[i];
+                const bool big = size > slice_size || size == 0;
+                if (big != (pass == 0)) continue;
+                const bool skip = !no_skip && should_skip_compression(files[i]);
+                if (skip) { uf++; ub += size; } else { cf++; cb += size; }
+                uint64_t off = 0;
+                uint32_t seq = 0;
+                do {  // big: slice_size rounds with fdata_offset/chunk_seq (L265-280); small: one round (L499)
+                    const uint64_t n = std::min(slice_size, size - off);
+                    StageSlot *slot = nullptr;
+                    if (pk.would_switch(n)) readers.flush();
+                    uint8_t *dst = pk.reserve({i, seq, off, n, 0, skip, (uint8_t)pass}, true, &slot);
+                    if (!dst) { ok = false; break; }
+                    if (n) readers.push({i, off, n, dst, slot});
+                    off += n;
+                    seq++;
+                } while (off < size);
+            }
+        }
+        readers.join();
+        rc = pk.finish();
+        if (rc) { close(fd); return rc; }
+        rows = std::move(pk.rows);
+        blob_bytes = pk.out_cursor;
+    }
+    const double t_pack = now_s();
+    // one sub-index, one record batch per non-empty pass, rows in round order (L141-189)
+    SubIndex sub{0, repo ? repo : "", {}};
+    for (uint8_t pass = 0; pass < 2; pass++) {
+        std::vector<size_t> ids;
+        for (size_t k = 0; k < rows.size(); k++)
+            if (rows[k].pass == pass) ids.push_back(k);
+        if (!ids.empty()) sub.batches.push_back(std::move(ids));
+    }
+    std::vector<std::string> rel(files.size());
+    for (size_t i = 0; i < files.size(); i++) rel[i] = files[i].compare(0, root.size() + 1, root + "/") == 0 ? files[i].substr(root.size() + 1) : files[i];
+    const uint64_t total_bytes_out = write_metadata(fd, blob_bytes, rows, [&](uint32_t fi) -> const std::string & { return rel[fi]; }, {sub});
+    close(fd);
+    if (trace_on())
+        fprintf(stderr, "[host] compress_dir: walk %.1f ms  pack %.1f ms  metadata %.1f ms\n", (t_walk - t_begin) * 1e3, (t_pack - t_walk) * 1e3,
+                (now_s() - t_pack) * 1e3);
+    if (report) {
+        *report = znippy_compression_report{(uint64_t)files.size(), cf, uf, total_dirs, cb + ub, total_bytes_out, cb, ub, (uint64_t)rows.size(),
+                                            ub > 0 ? (float)cb / (float)std::max<uint64_t>(blob_bytes, 1) * 100.0f : 0.0f};
     }
     return ZNIPPY_OK;
 }
 
 // ---- read side --------------------------------------------------------------------------------
-static int decode_rows(znippy_ctx *ctx, int arc_fd, const znippy_index &ix, const std::vector<uint64_t> &row_ids, bool verify,
-                       DevBuf &d_blobs, DevBuf &d_out, std::vector<uint8_t> &out, std::vector<uint64_t> &out_off,
-                       znippy_verify_counters *cnt, std::vector<uint64_t> *corrupt, std::vector<int32_t> *status) {
-    const size_t n = row_ids.size();
+}  // extern "C"
+
+namespace {
+
+struct DecodedRange {
+    std::vector<uint64_t> out_off;  // position of each row's bytes in the decoded region
+    uint64_t total = 0;
+    std::vector<int32_t> status;
+    znippy_verify_counters cnt{};
+    std::vector<uint64_t> corrupt;  // absolute row numbers
+};
+
+struct ReadBufs {
+    DevBuf d_blobs, d_out;
+    PinBuf blob_pin;
+    double t_read = 0, t_h2d = 0, t_kern = 0;
+};
+
+// Blob bytes -> HBM -> decode+verify kernels; the decoded rows stay in bufs.d_out (the caller decides whether
+// they cross PCIe at all).  Stands for the worker loop body, decompress.rs:L135-190.
+int decode_range(znippy_ctx *ctx, int arc_fd, const znippy_index &ix, const uint64_t *row_ids, size_t n, bool verify, ReadBufs &bufs,
+                 DecodedRange *dr) {
     std::vector<uint64_t> bo(n), bs(n), us(n);
     std::vector<uint8_t> bitmap((n + 7) / 8, 0), ck(verify ? 32 * n : 0);
-    out_off.assign(n, 0);
-    uint64_t lo = UINT64_MAX, hi = 0, total = 0;
+    dr->out_off.assign(n, 0);
+    dr->status.assign(n, 0);
+    dr->total = 0;
+    dr->cnt = znippy_verify_counters{};
+    uint64_t lo = UINT64_MAX, hi = 0, sum = 0;
     for (size_t k = 0; k < n; k++) {
         const uint64_t r = row_ids[k];
         bo[k] = ix.rows.cols[5].u64[r]; bs[k] = ix.rows.cols[6].u64[r]; us[k] = ix.rows.cols[4].u64[r];
         if (ix.rows.cols[3].u8[r]) bitmap[k >> 3] |= (uint8_t)(1u << (k & 7));
         if (verify) std::memcpy(&ck[32 * k], &ix.rows.cols[7].u8[32 * r], 32);
-        out_off[k] = total;
-        total += us[k];
+        dr->out_off[k] = dr->total;
+        dr->total += us[k];
+        if (bo[k] > ix.file_size || bs[k] > ix.file_size - bo[k]) return fail(ZNIPPY_E_CORRUPT, "blob range outside the archive");
         lo = std::min(lo, bo[k]);
         hi = std::max(hi, bo[k] + bs[k]);
+        sum += bs[k];
     }
-    if (!n) { out.clear(); return ZNIPPY_OK; }
-    if (hi > ix.file_size) return fail(ZNIPPY_E_CORRUPT, "blob range outside the archive");
-    std::vector<uint8_t> blobs(hi - lo);
-    if (!pread_all(arc_fd, blobs.data(), blobs.size(), lo)) return fail(ZNIPPY_E_INVAL, "failed to read blob from archive");
-    if (!d_blobs.reserve(blobs.size() + 64) || !d_out.reserve(total + 64)) return fail(ZNIPPY_E_NOMEM, "device allocation failed");
-    if (!blobs.empty() && hipMemcpy(d_blobs.p, blobs.data(), blobs.size(), hipMemcpyHostToDevice) != hipSuccess)
-        return fail(ZNIPPY_E_HIP, "H2D failed");
+    if (!n) return ZNIPPY_OK;
+    double t = now_s();
+    uint64_t base = lo, nblob = hi - lo;
+    if (nblob > 2 * sum + (1u << 20)) {  // scattered rows: pack them instead of reading the span between them
+        if (!bufs.blob_pin.reserve(sum + 64)) return fail(ZNIPPY_E_NOMEM, "page-locked allocation failed");
+        uint64_t pos = 0;
+        for (size_t k = 0; k < n; k++) {
+            if (bs[k] && !pread_all(arc_fd, bufs.blob_pin.p + pos, bs[k], bo[k])) return fail(ZNIPPY_E_INVAL, "failed to read blob from archive");
+            bo[k] = pos;
+            pos += bs[k];
+        }
+        base = 0;
+        nblob = sum;
+    } else {
+        if (!bufs.blob_pin.reserve(nblob + 64)) return fail(ZNIPPY_E_NOMEM, "page-locked allocation failed");
+        if (nblob && !pread_all(arc_fd, bufs.blob_pin.p, nblob, lo)) return fail(ZNIPPY_E_INVAL, "failed to read blob from archive");
+    }
+    bufs.t_read += now_s() - t; t = now_s();
+    if (!bufs.d_blobs.reserve(nblob + 64) || !bufs.d_out.reserve(dr->total + 64)) return fail(ZNIPPY_E_NOMEM, "device allocation failed");
+    if (nblob && hipMemcpy(bufs.d_blobs.p, bufs.blob_pin.p, nblob, hipMemcpyHostToDevice) != hipSuccess) return fail(ZNIPPY_E_HIP, "H2D failed");
+    bufs.t_h2d += now_s() - t; t = now_s();
     znippy_rows *rt = nullptr;
-    int rc = znippy_rows_create(ctx, bo.data(), bs.data(), bitmap.data(), us.data(), out_off.data(), verify ? ck.data() : nullptr, 0, n, &rt);
+    int rc = znippy_rows_create(ctx, bo.data(), bs.data(), bitmap.data(), us.data(), dr->out_off.data(), verify ? ck.data() : nullptr, 0, n, &rt);
     if (rc) return fail(rc, "znippy_rows_create failed");
     std::vector<uint64_t> cr(n);
-    status->assign(n, 0);
-    rc = znippy_decode_verify_rows(ctx, rt, d_blobs.p, lo, d_out.p, total, cnt, cr.data(), n, status->data());
+    rc = znippy_decode_verify_rows(ctx, rt, bufs.d_blobs.p, base, bufs.d_out.p, dr->total, &dr->cnt, cr.data(), n, dr->status.data());
     znippy_rows_destroy(rt);
     if (rc) return fail(rc, std::string("decode failed: ") + znippy_last_error(ctx));
-    out.resize(total);
-    if (total && hipMemcpy(out.data(), d_out.p, total, hipMemcpyDeviceToHost) != hipSuccess) return fail(ZNIPPY_E_HIP, "D2H failed");
-    if (corrupt)
-        for (uint64_t k = 0; k < cnt->corrupt_rows && k < n; k++) corrupt->push_back(row_ids[cr[k]]);
+    bufs.t_kern += now_s() - t;
+    for (uint64_t k = 0; k < dr->cnt.corrupt_rows && k < n; k++) dr->corrupt.push_back(row_ids[cr[k]]);
     return ZNIPPY_OK;
 }
+
+// Positioned writes of decoded rows [k0,k1) of one range (decompress.rs:L186-189).  A file is created (and,
+// when this rank owns the whole archive, truncated) at its first row; rows of one file are adjacent, so one
+// cached descriptor per writer replaces the reference's table of open files.
+struct RowWriter {
+    const znippy_index *ix;
+    const char *out_dir;
+    const std::vector<uint8_t> *first_touch;
+    bool truncate;
+    std::atomic<int> *err;
+    void operator()(const uint8_t *bytes, const DecodedRange *dr, uint64_t row0, uint64_t k0, uint64_t k1) const {
+        std::string cur_dir;
+        const std::string *cur_path = nullptr;
+        int fd = -1;
+        for (uint64_t k = k0; k < k1; k++) {
+            const uint64_t r = row0 + k;
+            if (dr->status[k] < 0) {  // decode error: logged + skipped (L159-162)
+                fprintf(stderr, "[decomp] row %llu error=%d\n", (unsigned long long)r, dr->status[k]);
+                continue;
+            }
+            const std::string &p = ix->rows.cols[0].str[r];
+            if (!cur_path || *cur_path != p) {
+                if (fd >= 0) close(fd);
+                const std::string full = std::string(out_dir) + "/" + p;
+                const bool first = (*first_touch)[r] != 0;
+                if (first) {
+                    const std::string dir = full.substr(0, full.find_last_of('/'));
+                    if (dir != cur_dir) { mkdirs(dir); cur_dir = dir; }
+                }
+                fd = open(full.c_str(), O_CREAT | O_WRONLY | ((first && truncate) ? O_TRUNC : 0), 0644);
+                cur_path = &p;
+                if (fd < 0) { err->store(1); g_open_failed(p); return; }
+            }
+            if (!pwrite_all(fd, bytes + dr->out_off[k], ix->rows.cols[4].u64[r], ix->rows.cols[2].u64[r])) err->store(2);
+        }
+        if (fd >= 0) close(fd);
+    }
+    static void g_open_failed(const std::string &p) { fprintf(stderr, "[decomp] failed to open output file %s\n", p.c_str()); }
+};
+
+}  // namespace
+
+extern "C" {
 
 int znippy_decompress_archive(const char *index_path, int save_data, const char *out_dir, int device, uint32_t rank,
                               uint32_t world, znippy_verify_report *report, uint64_t *corrupt_rows, uint64_t corrupt_cap,
                               uint64_t *n_corrupt) {
     if (!index_path || !report || (save_data && !out_dir) || world == 0 || rank >= world) return fail(ZNIPPY_E_INVAL, "bad argument");
+    const double t_begin = now_s();
     znippy_index ix;
     int rc = load_index(index_path, &ix);
     if (rc) return rc;
-    const size_t total_rows = ix.n();
-    std::unordered_set<std::string> uniq(ix.rows.cols[0].str.begin(), ix.rows.cols[0].str.end());  // L64-69
-    const auto range = split_rows(ix.rows.cols[4].u64, rank, world);
-    (void)total_rows;
-    // pre-create output files (L74-101)
-    std::unordered_map<std::string, int> fds;
-    if (save_data) {
-        for (uint64_t r = range.first; r < range.second; r++) {
-            const std::string &p = ix.rows.cols[0].str[r];
-            if (fds.count(p)) continue;
-            std::string full = std::string(out_dir) + "/" + p;
-            size_t slash = full.find_last_of('/');
-            mkdirs(full.substr(0, slash));
-            int fd = open(full.c_str(), O_CREAT | O_WRONLY | (world > 1 ? 0 : O_TRUNC), 0644);
-            if (fd < 0) return fail(ZNIPPY_E_INVAL, "failed to open output file " + full);
-            fds[p] = fd;
+    const double t_index = now_s();
+    const uint64_t n_rows = ix.n();
+    const auto &paths = ix.rows.cols[0].str;
+    // unique paths (L64-69) + the first row of every path; rows of a path that are not adjacent (duplicate entries)
+    // force a single writer so that the first-touch truncate cannot race with a later row's write
+    std::vector<uint8_t> first_touch(n_rows, 0);
+    bool adjacent = true;
+    size_t n_unique = 0;
+    {
+        std::unordered_set<std::string> uniq;
+        uniq.reserve(n_rows * 2);
+        for (uint64_t r = 0; r < n_rows; r++) {
+            if (r && paths[r] == paths[r - 1]) continue;
+            if (uniq.insert(paths[r]).second) first_touch[r] = 1;
+            else adjacent = false;
         }
+        n_unique = uniq.size();
     }
+    const auto range = split_rows(ix.rows.cols[4].u64, rank, world);
+    if (save_data) mkdirs(out_dir);
     int arc = open(index_path, O_RDONLY);
     if (arc < 0) return fail(ZNIPPY_E_INVAL, "cannot open archive");
     znippy_ctx *ctx = nullptr;
@@ -539,44 +991,90 @@ int znippy_decompress_archive(const char *index_path, int save_data, const char 
             return fail(rc ? rc : ZNIPPY_E_HIP, "no usable GPU: the codec/hash path has no CPU fallback");
         }
     }
+    const double t_ctx = now_s();
     znippy_verify_counters tot{};
     std::vector<uint64_t> corrupt;
-    DevBuf d_blobs, d_out;
-    std::vector<uint8_t> out;
+    ReadBufs bufs;
+    // save_data: the decoded range crosses PCIe into one of two page-locked slabs and a few writer threads
+    // scatter it into the output files while the GPU works on the next range.  verify-only: nothing is copied back.
+    struct OutSlab {
+        PinBuf pin;
+        DecodedRange dr;
+        std::vector<std::thread> writers;
+        uint64_t last_row = 0;
+        void join() { for (auto &t : writers) t.join(); writers.clear(); }
+    } slabs[2];
+    std::atomic<int> werr{0};
+    const RowWriter writer{&ix, out_dir, &first_touch, world == 1, &werr};
+    const unsigned n_writers = adjacent ? io_threads() : 1;
+    const uint64_t batch_bytes = range_bytes(save_data != 0);
+    double t_d2h = 0, t_wjoin = 0;
+    int which = 0, n_ranges = 0;
     uint64_t i = range.first;
-    while (i < range.second && rc == ZNIPPY_OK) {
+    std::vector<uint64_t> ids;
+    while (i < range.second && rc == ZNIPPY_OK && !werr.load()) {
         uint64_t j = i, nbytes = 0;
-        while (j < range.second && (j == i || nbytes + ix.rows.cols[4].u64[j] <= RANGE_BYTES)) nbytes += ix.rows.cols[4].u64[j++];
-        std::vector<uint64_t> ids(j - i), out_off;
+        while (j < range.second && (j == i || nbytes + ix.rows.cols[4].u64[j] <= batch_bytes)) nbytes += ix.rows.cols[4].u64[j++];
+        ids.resize(j - i);
         for (uint64_t k = i; k < j; k++) ids[k - i] = k;
-        znippy_verify_counters c{};
-        std::vector<int32_t> status;
-        rc = decode_rows(ctx, arc, ix, ids, true, d_blobs, d_out, out, out_off, &c, &corrupt, &status);
+        OutSlab &sl = slabs[which];
+        double t = now_s();
+        sl.join();  // the slab's previous range has been written out
+        // a file continuing from the range still being written must see its first-touch create/truncate first
+        OutSlab &other = slabs[which ^ 1];
+        if (!other.writers.empty() && i && paths[i] == paths[i - 1]) other.join();
+        t_wjoin += now_s() - t;
+        sl.dr.corrupt.clear();
+        rc = decode_range(ctx, arc, ix, ids.data(), ids.size(), true, bufs, &sl.dr);
         if (rc) break;
+        n_ranges++;
+        const znippy_verify_counters &c = sl.dr.cnt;
         tot.total_chunks += c.total_chunks; tot.total_written_bytes += c.total_written_bytes;
         tot.verified_bytes += c.verified_bytes; tot.corrupt_bytes += c.corrupt_bytes;
         tot.corrupt_rows += c.corrupt_rows; tot.decode_errors += c.decode_errors;
+        corrupt.insert(corrupt.end(), sl.dr.corrupt.begin(), sl.dr.corrupt.end());
         if (save_data) {
-            for (uint64_t k = i; k < j; k++) {
-                if (status[k - i] < 0) {  // decode error: logged + skipped (L159-162)
-                    fprintf(stderr, "[decomp] row %llu error=%d\n", (unsigned long long)k, status[k - i]);
-                    continue;
+            t = now_s();
+            if (!sl.pin.reserve(sl.dr.total + 64)) { rc = fail(ZNIPPY_E_NOMEM, "page-locked allocation failed"); break; }
+            if (sl.dr.total && hipMemcpy(sl.pin.p, bufs.d_out.p, sl.dr.total, hipMemcpyDeviceToHost) != hipSuccess) { rc = fail(ZNIPPY_E_HIP, "D2H failed"); break; }
+            t_d2h += now_s() - t;
+            // split [i,j) into contiguous parts of about equal bytes, cut only where the path changes
+            const uint64_t n = j - i;
+            uint64_t k0 = 0;
+            for (unsigned w = 0; w < n_writers && k0 < n; w++) {
+                uint64_t k1 = n;
+                if (w + 1 < n_writers) {
+                    const uint64_t target = sl.dr.total / n_writers * (w + 1);
+                    k1 = (uint64_t)(std::lower_bound(sl.dr.out_off.begin() + k0, sl.dr.out_off.end(), target) - sl.dr.out_off.begin());
+                    k1 = std::max(k1, k0 + 1);
+                    while (k1 < n && paths[i + k1] == paths[i + k1 - 1]) k1++;
                 }
-                pwrite_all(fds[ix.rows.cols[0].str[k]], out.data() + out_off[k - i], ix.rows.cols[4].u64[k], ix.rows.cols[2].u64[k]);
+                sl.writers.emplace_back(writer, sl.pin.p, &sl.dr, i, k0, k1);
+                k0 = k1;
             }
+            which ^= 1;
         }
         i = j;
     }
-    for (auto &kv : fds) close(kv.second);
+    double t = now_s();
+    slabs[0].join();
+    slabs[1].join();
+    t_wjoin += now_s() - t;
     close(arc);
     if (ctx) znippy_ctx_destroy(ctx);
     if (rc) return rc;
+    if (werr.load()) return fail(ZNIPPY_E_INVAL, werr.load() == 1 ? "failed to open output file" : "failed to write output file");
+    if (trace_on())
+        fprintf(stderr, "[host] decompress_archive: index %.1f ms  ctx %.1f ms  ranges %d  pread %.1f ms  h2d %.1f ms  kernels %.1f ms  d2h %.1f ms  "
+                        "writer-wait %.1f ms  total %.1f ms\n",
+                (t_index - t_begin) * 1e3, (t_ctx - t_index) * 1e3, n_ranges, bufs.t_read * 1e3, bufs.t_h2d * 1e3, bufs.t_kern * 1e3, t_d2h * 1e3,
+                t_wjoin * 1e3, (now_s() - t_begin) * 1e3);
     std::sort(corrupt.begin(), corrupt.end());
     for (uint64_t r : corrupt) fprintf(stderr, "[verify] MISMATCH row=%llu\n", (unsigned long long)r);
     const uint64_t corrupt_files = corrupt.size();  // number of corrupt ROWS (L210)
-    report->total_files = uniq.size();
+    report->total_files = n_unique;
     report->corrupt_files = corrupt_files;
-    report->verified_files = uniq.size() > corrupt_files ? uniq.size() - corrupt_files : 0;
+    report->verified_files = n_unique > corrupt_files ? n_unique - corrupt_files : 0;
     report->total_bytes = tot.total_written_bytes;
     report->verified_bytes = tot.verified_bytes;
     report->corrupt_bytes = tot.corrupt_bytes;
@@ -597,7 +1095,7 @@ struct znippy_archive {
     std::unordered_map<std::string, std::vector<uint64_t>> files;  // rows sorted by fdata_offset (archive.rs:L131-133)
     znippy_ctx *ctx = nullptr;
     int fd = -1;
-    DevBuf d_blobs, d_out;
+    ReadBufs bufs;
 };
 
 extern "C" {
@@ -640,17 +1138,14 @@ int znippy_archive_extract_file(znippy_archive *a, const char *rel, void *dst, s
         int rc = znippy_ctx_create(a->device, nullptr, &a->ctx);
         if (rc) return fail(rc, "no usable GPU: the codec/hash path has no CPU fallback");
     }
-    std::vector<uint8_t> out;
-    std::vector<uint64_t> out_off;
-    std::vector<int32_t> status;
-    znippy_verify_counters c{};
-    int rc = decode_rows(a->ctx, a->fd, a->ix, it->second, false, a->d_blobs, a->d_out, out, out_off, &c, nullptr, &status);
+    DecodedRange dr;
+    int rc = decode_range(a->ctx, a->fd, a->ix, it->second.data(), it->second.size(), false, a->bufs, &dr);
     if (rc) return rc;
-    for (int32_t st : status)
+    for (int32_t st : dr.status)
         if (st < 0) return fail(st, "OpenZL-equivalent decompress failed");  // propagates (archive.rs:L160)
-    if (out.size() > cap) return fail(ZNIPPY_E_DST_SMALL, "destination too small");
-    if (!out.empty()) std::memcpy(dst, out.data(), out.size());
-    *written = out.size();
+    if (dr.total > cap) return fail(ZNIPPY_E_DST_SMALL, "destination too small");
+    if (dr.total && hipMemcpy(dst, a->bufs.d_out.p, dr.total, hipMemcpyDeviceToHost) != hipSuccess) return fail(ZNIPPY_E_HIP, "D2H failed");
+    *written = dr.total;
     return ZNIPPY_OK;
 }
 

@@ -151,7 +151,7 @@ __global__ __launch_bounds__(64) void k_zstd_encode(EncodeArgs a) {
     uint32_t next = 0, lim = 0, first = 0;
     // descriptors of the dequeued batch, one item per lane (loaded together: one memory round trip
     // per batch instead of three dependent ones per item)
-    uint32_t d_round = 0, d_block = 0, d_nblocks = 0, d_flags = ITEM_SKIP;
+    uint32_t d_round = 0, d_block = 0, d_nblocks = 0, d_flags = ITEM_SKIP, d_id = 0;
     uint64_t d_prov = 0, d_rlen = 0, d_soff = 0;
     for (;;) {
         if (next == lim) {
@@ -163,7 +163,8 @@ __global__ __launch_bounds__(64) void k_zstd_encode(EncodeArgs a) {
             const uint32_t mine = first + lane;
             d_flags = ITEM_SKIP;
             if (lane < a.batch && mine < a.n_items) {
-                const EncItem e = a.items[mine];
+                d_id = a.order ? a.order[mine] : mine;  // this variant's share of the plan (or all of it)
+                const EncItem e = a.items[d_id];
                 d_round = e.round; d_block = e.block; d_nblocks = e.n_blocks; d_flags = e.flags; d_prov = e.prov;
                 d_rlen = a.len[e.round];
                 d_soff = a.src_off[e.round];
@@ -176,6 +177,7 @@ __global__ __launch_bounds__(64) void k_zstd_encode(EncodeArgs a) {
         EncItem it;
         it.round = __shfl(d_round, bl); it.block = __shfl(d_block, bl); it.n_blocks = __shfl(d_nblocks, bl);
         it.flags = __shfl(d_flags, bl); it.prov = __shfl(d_prov, bl);
+        const uint32_t item_id = __shfl(d_id, bl);
         if (it.flags & ITEM_SKIP) continue;  // store path: the gather pass copies it from the staging buffer
         const uint64_t rlen = __shfl(d_rlen, bl);
         const uint8_t *const rsrc = a.src + __shfl(d_soff, bl);
@@ -352,8 +354,8 @@ __global__ __launch_bounds__(64) void k_zstd_encode(EncodeArgs a) {
                 for (uint32_t i = 0; i < k; i++) blk[(int32_t)i - (int32_t)k] = h[i];
             }
             s_raw = raw ? 1u : 0u;
-            a.piece_len[item] = piece_len + hdr_len;
-            a.piece_start[item] = it.prov + HDR_ROOM - hdr_len;
+            a.piece_len[item_id] = piece_len + hdr_len;
+            a.piece_start[item_id] = it.prov + HDR_ROOM - hdr_len;
         }
         __syncthreads();
         if (s_raw) wave_copy(blk + 3, in, n, lane);  // raw block: the input bytes after the header

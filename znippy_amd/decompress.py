@@ -56,16 +56,23 @@ def decompress_archive(index_path, save_data: bool, out_dir, backend=None, group
         pass
     r0, r1 = split_rows(c["usize"], world)[rank]
 
-    # pre-create output files (L74-101); rows sharing a path share one fd, pwrite is positioned
-    fds = {}
-    if save_data:
-        for p in dict.fromkeys(c["paths"][r0:r1]):
-            full = os.path.join(out_dir, p)
+    # output files (L74-101): created/truncated on first touch, one cached descriptor (rows of a file are
+    # adjacent) instead of the reference's table of open files
+    created, cur = set(), [None, -1]
+
+    def out_fd(p):
+        if cur[0] == p:
+            return cur[1]
+        if cur[1] >= 0:
+            os.close(cur[1])
+        full = os.path.join(out_dir, p)
+        first = p not in created
+        if first:
+            created.add(p)
             os.makedirs(os.path.dirname(full) or ".", exist_ok=True)
-            if world > 1:  # several ranks may own chunks of one file: never truncate each other
-                fds[p] = os.open(full, os.O_CREAT | os.O_WRONLY, 0o644)
-            else:
-                fds[p] = os.open(full, os.O_CREAT | os.O_WRONLY | os.O_TRUNC, 0o644)
+        flags = os.O_CREAT | os.O_WRONLY | (os.O_TRUNC if (first and world == 1) else 0)
+        cur[0], cur[1] = p, os.open(full, flags, 0o644)
+        return cur[1]
 
     backend = backend or (default_backend() if r1 > r0 else None)
     counters = dict(total_chunks=0, total_written_bytes=0, verified_bytes=0, corrupt_bytes=0, corrupt_rows=0,
@@ -99,10 +106,10 @@ def decompress_archive(index_path, save_data: bool, out_dir, backend=None, group
                     if status[k] < 0:
                         continue  # decode error: nothing is written for the row (L159-162)
                     o, l = int(out_off[k]), int(usz[k])
-                    os.pwrite(fds[c["paths"][i + k]], out[o:o + l].tobytes(), int(c["fdata_offset"][i + k]))
+                    os.pwrite(out_fd(c["paths"][i + k]), out[o:o + l].tobytes(), int(c["fdata_offset"][i + k]))
             i = j
-    for fd in fds.values():
-        os.close(fd)
+    if cur[1] >= 0:
+        os.close(cur[1])
 
     counters, corrupt_all = reduce_counters(counters, corrupt_all, group)
     corrupt_files = len(set(corrupt_all))

@@ -28,7 +28,7 @@ class _ME(C.Structure):
 
 HOST_EXPORTS = [
     "znippy_host_last_error", "znippy_compress_stream", "znippy_stream_send", "znippy_stream_finish",
-    "znippy_decompress_archive", "znippy_archive_open", "znippy_archive_file_count", "znippy_archive_file_size",
+    "znippy_compress_dir", "znippy_decompress_archive", "znippy_archive_open", "znippy_archive_file_count", "znippy_archive_file_size",
     "znippy_archive_extract_file", "znippy_archive_close", "znippy_index_open", "znippy_index_rows",
     "znippy_index_manifest_len", "znippy_index_manifest_entry", "znippy_index_row", "znippy_index_metadata",
     "znippy_index_close", "znippy_interpret_footer", "znippy_write_manifest_bytes",
@@ -45,6 +45,7 @@ def lib():
         L.znippy_compress_stream.argtypes = [C.c_char_p, C.c_int, C.c_int, C.POINTER(vp)]
         L.znippy_stream_send.argtypes = [vp, C.c_char_p, vp, C.c_size_t, C.c_int, C.c_char_p]
         L.znippy_stream_finish.argtypes = [vp, C.POINTER(_CR)]
+        L.znippy_compress_dir.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.c_char_p, C.c_int, C.POINTER(_CR)]
         L.znippy_decompress_archive.argtypes = [C.c_char_p, C.c_int, C.c_char_p, C.c_int, C.c_uint32, C.c_uint32,
                                                 C.POINTER(_VR), vp, C.c_uint64, C.POINTER(C.c_uint64)]
         L.znippy_archive_open.argtypes = [C.c_char_p, C.c_int, C.POINTER(vp)]
@@ -104,12 +105,26 @@ class StreamCompressor:
         r = _CR()
         h, self.h = self.h, None
         _chk(lib().znippy_stream_finish(h, C.byref(r)), "stream_finish")
-        return ix.CompressionReport(**{n: (float(getattr(r, n)) if n == "compression_ratio" else int(getattr(r, n)))
-                                       for n, _ in _CR._fields_})
+        return _report(r)
+
+
+def _report(r) -> ix.CompressionReport:
+    return ix.CompressionReport(**{n: (float(getattr(r, n)) if n == "compression_ratio" else int(getattr(r, n)))
+                                   for n, _ in _CR._fields_})
 
 
 def compress_stream(output, no_skip=False, device=0):
     return StreamCompressor(output, no_skip, device)
+
+
+def compress_dir(input_dir, output, no_skip=False, plugin=None, repo=None, device=0) -> ix.CompressionReport:
+    """compress_dir(&input_dir, &output, no_skip, plugin, repo) on the compiled host layer."""
+    if plugin is not None:
+        raise NotImplementedError("metadata plugins are outside the hot path (SURVEY §2 #12)")
+    r = _CR()
+    _chk(lib().znippy_compress_dir(str(input_dir).encode(), str(output).encode(), int(no_skip),
+                                   None if repo is None else repo.encode(), device, C.byref(r)), "compress_dir")
+    return _report(r)
 
 
 def decompress_archive(index_path, save_data, out_dir, device=0, rank=0, world=1) -> ix.VerifyReport:
