@@ -55,6 +55,27 @@ def build_workload(name, torch):
         size, sl = 2 << 30, 8 << 20
         return dict(d_src=gen_gpu.text(size), lens=np.full(size // sl, sl, np.uint64), skip=None,
                     name="single 2 GiB text file, 256 x 8 MiB slices (BASELINE configs[2] at the reference's slice size)")
+    if name == "c3slot":
+        size, sl = 2 << 30, 200 << 20
+        lens = np.array([sl] * (size // sl) + ([size % sl] if size % sl else []), dtype=np.uint64)
+        return dict(d_src=gen_gpu.text(size), lens=lens, skip=None,
+                    name="single 2 GiB text file, 11 slices of <= 200 MiB (BASELINE configs[2] as worded there)")
+    if name == "c5":
+        # synthetic stand-in for the 5 GB / 5k-file artifact repo: 3,500 .xml text files of 1-8 KiB,
+        # 1,400 .jar of 100 KiB..2 MiB and 100 .jar of 20..69.5 MiB incompressible bytes (store path), stream
+        # chunking (8 MiB slices).  Jar bytes are consecutive cuts of one LCG stream.
+        sl = 8 << 20
+        xml = [1024 + (i % 8) * 1024 for i in range(3500)]
+        jars = [100 * 1024 + (i % 20) * 100 * 1024 for i in range(1400)] + [(20 << 20) + i * (1 << 19) for i in range(100)]
+        lens, skip = list(xml), [0] * len(xml)
+        for j in jars:
+            for o in range(0, j, sl):
+                lens.append(min(sl, j - o))
+                skip.append(1)
+        d_src = torch.cat([gen_gpu.text(sum(xml)), gen_gpu.incompressible(7, sum(jars))])
+        return dict(d_src=d_src, lens=np.array(lens, np.uint64), skip=np.array(skip, np.uint8),
+                    name="mixed artifact repo stand-in: 3,500 xml (1-8 KiB) + 1,500 jars (100 KiB-69.5 MiB, store path), %.2f GB"
+                         % ((sum(xml) + sum(jars)) / 1e9))
     if name in ("c4store", "c4codec"):
         size, sl = 500 << 20, 8 << 20
         lens = np.array([sl] * (size // sl) + ([size % sl] if size % sl else []), dtype=np.uint64)

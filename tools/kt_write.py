@@ -19,3 +19,10 @@ for i in range(12):
     if i >= 2:
         for k, v in ctx.kernel_times(): acc.setdefault(k, []).append(v)
 print("NOHASH" if os.environ.get("ZNIPPY_NOHASH") else "full", "wall", round(float(np.median(wall[2:])), 3), {k: round(float(np.mean(v)), 4) for k, v in acc.items()}, "blob", r["blob_bytes"])
+# hash alone (no encoder next to it)
+ts = []
+for i in range(12):
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    rounds.hash(d_src)
+    ts.append((time.perf_counter() - t0) * 1e3)
+print("hash_rounds alone wall", round(float(np.median(ts[2:])), 3), dict(ctx.kernel_times()))

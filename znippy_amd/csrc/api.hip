@@ -155,6 +155,7 @@ struct znippy_rounds {
     uint32_t *digests = nullptr;
     std::vector<uint64_t> h_len, h_off;
     std::vector<uint8_t> h_skip;
+    uint64_t in_bytes = 0, enc_bytes = 0;  // all rounds / rounds that go through the encoder
     uint64_t blob_bound = 0;
     DevPlan plan;
     // encoder plan: one item per output piece
@@ -546,7 +547,11 @@ int znippy_rounds_create(znippy_ctx *ctx, const uint64_t *src_offset, const uint
     r->h_off.assign(src_offset, src_offset + n);
     r->h_skip.assign(n, 0);
     if (skip) r->h_skip.assign(skip, skip + n);
-    for (uint64_t i = 0; i < n; i++) r->blob_bound += r->h_skip[i] ? len[i] : znippy_compress_bound(len[i]);
+    for (uint64_t i = 0; i < n; i++) {
+        r->blob_bound += r->h_skip[i] ? len[i] : znippy_compress_bound(len[i]);
+        r->in_bytes += len[i];
+        if (!r->h_skip[i]) r->enc_bytes += len[i];
+    }
     int rc;
     if ((rc = dev_upload(ctx, &r->src_off, src_offset, n)) || (rc = dev_upload(ctx, &r->len, len, n)) ||
         (rc = dev_upload(ctx, &r->skip, r->h_skip.data(), n))) {
@@ -603,7 +608,7 @@ int znippy_rounds_create(znippy_ctx *ctx, const uint64_t *src_offset, const uint
         znippy_rounds_destroy(r);
         return rc;
     }
-    const size_t ni = std::max<size_t>(r->n_items, 1), nsb = (ni + 1023) / 1024;
+    const size_t ni = std::max<size_t>(r->n_items, 1), nsb = (ni + 255) / 256;
     if ((rc = dev_upload(ctx, &r->first_item, first_item.data(), first_item.size())) ||
         hipMalloc(&r->stored, std::max<size_t>(n, 16)) != hipSuccess || hipHostMalloc(&r->h_stored, std::max<size_t>(n, 16)) != hipSuccess) {
         znippy_rounds_destroy(r);
@@ -636,6 +641,8 @@ static int hash_rounds_async(znippy_ctx *ctx, znippy_rounds *r, const void *d_sr
     h.len = r->len;
     h.srcA = (const uint8_t *)d_src; h.offA = r->src_off; h.baseA = 0;
     h.digests = r->digests; h.tile_cv = r->plan.tile_cv;
+    // next to a busy encoder (auxiliary stream) the hash keeps out of LDS: the encoder's residency depends on it
+    if (on && r->enc_bytes * 4 >= r->in_bytes) h.fold_tiles_max = 1;
     ktime_begin(ctx, "blake3_tiles", s);
     launch_hash_tiles(h, s);
     ktime_end(ctx, s);

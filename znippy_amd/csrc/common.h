@@ -49,6 +49,7 @@ struct HashArgs {
     int copy_to_B;
     uint32_t *digests;  // 8 words per unit
     uint32_t *tile_cv;  // 8 words per big-unit tile
+    int fold_tiles_max;  // 0 = pick from the tile count; 1 = no deferred folding (no LDS: the launch shares the CUs with the encoder)
 };
 
 // Row status values on the read side: 0 = done (stored row, or decoded+hashed by the fused

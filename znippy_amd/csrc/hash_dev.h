@@ -95,12 +95,25 @@ struct LdsSrc {
     uint32_t c_sel;
 };
 
-// Hash one tile with the calling wavefront.  Every lane of the wave must call it.
+// What the leaf phase of one tile leaves in the wave: one chaining value per leaf lane plus the shape of
+// the tile's units (segments of consecutive lanes).
+struct LeafOut {
+    uint32_t cv[8];
+    uint32_t seg_start, n;  // this lane's segment: first lane, node count (0 on inactive lanes)
+    uint32_t unit;
+    bool active;
+    uint32_t u_cnt, u_head;  // tile-local unit i sits on lane i: its leaf count and first lane (big tile: lane 0)
+};
+
+// Leaf phase of one tile: every active lane compresses its 1 KiB leaf (16 blocks).  Every lane of the wave
+// must call it.
 template <bool COPY, bool LDSRC = false>
-__device__ __forceinline__ void hash_tile(const HashArgs &a, const Tile &t, const LdsSrc *ls = nullptr) {
+__device__ __forceinline__ void hash_tile_leaves(const HashArgs &a, const Tile &t, const LdsSrc *ls, LeafOut &out) {
     const uint32_t lane = threadIdx.x & 63;
     uint32_t unit, k, unit_leaves, seg_start, local = 0xFFFFFFFFu;
     bool active = lane < t.n_leaves;
+    out.u_cnt = lane == 0 ? t.n_leaves : 0;
+    out.u_head = 0;
     if (t.n_units) {
         uint32_t cnt = 0;
         if (lane < t.n_units) {
@@ -124,6 +137,8 @@ __device__ __forceinline__ void hash_tile(const HashArgs &a, const Tile &t, cons
             }
         }
         uint32_t i = lo;
+        out.u_cnt = cnt;
+        out.u_head = inc - cnt;
         unit_leaves = __shfl(cnt, i);
         seg_start = __shfl(inc, i) - unit_leaves;
         unit = t.first_unit + i;
@@ -246,13 +261,135 @@ __device__ __forceinline__ void hash_tile(const HashArgs &a, const Tile &t, cons
         }
     }
 
-    fold_segments(cv, seg_start, active ? unit_leaves : 0, t.n_units != 0);
-
-    if (active && lane == seg_start) {
-        uint32_t *o = t.n_units ? a.digests + (size_t)unit * 8 : a.tile_cv + (size_t)t.cv_index * 8;
 #pragma unroll
-        for (int i = 0; i < 8; i++) o[i] = cv[i];
+    for (int i = 0; i < 8; i++) out.cv[i] = cv[i];
+    out.seg_start = seg_start;
+    out.n = active ? unit_leaves : 0;
+    out.unit = unit;
+    out.active = active;
+}
+
+// Parent tree of one tile, folded on the spot (4-6 compress passes with few lanes busy).
+__device__ __forceinline__ void fold_tile_now(const HashArgs &a, const Tile &t, LeafOut &lo) {
+    const uint32_t lane = threadIdx.x & 63;
+    fold_segments(lo.cv, lo.seg_start, lo.n, t.n_units != 0);
+    if (lo.active && lane == lo.seg_start) {
+        uint32_t *o = t.n_units ? a.digests + (size_t)lo.unit * 8 : a.tile_cv + (size_t)t.cv_index * 8;
+#pragma unroll
+        for (int i = 0; i < 8; i++) o[i] = lo.cv[i];
     }
 }
+
+// Hash one tile with the calling wavefront.  Every lane of the wave must call it.
+template <bool COPY, bool LDSRC = false>
+__device__ __forceinline__ void hash_tile(const HashArgs &a, const Tile &t, const LdsSrc *ls = nullptr) {
+    LeafOut lo;
+    hash_tile_leaves<COPY, LDSRC>(a, t, ls, lo);
+    fold_tile_now(a, t, lo);
+}
+
+// Deferred parent folding.  A parent level costs one full compress pass of the wave however few lanes take
+// part (a 10-leaf unit folds in 4 passes with 5, 3, 2, 1 lanes busy; a 64-leaf slice in 6).  The queue keeps
+// the leaf CVs of up to G tiles in a wave-private LDS array and folds all of their units together, level by
+// level, with the nodes of a level packed over the 64 lanes: 6 rows x 10 leaves x 4 tiles fold in 6 passes
+// instead of 16, four 64-leaf slices in 7 instead of 24.
+//   nodes : wave-private LDS, G*64 chaining values; tile g's leaf CVs start at node g*64
+//   table : one queued unit per lane (registers): node count, first node, where the result goes
+template <int G>
+struct FoldQueue {
+    static constexpr uint32_t MAX_UNITS_PER_TILE = 64 / G;  // tiles with more units fold on the spot
+    uint32_t n_tab = 0;
+    uint32_t tb_n = 0, tb_off = 0, tb_out = 0, tb_root = 0;
+
+    static __device__ __forceinline__ bool fits(const Tile &t) { return (t.n_units ? t.n_units : 1u) <= MAX_UNITS_PER_TILE; }
+
+    __device__ __forceinline__ void add(uint32_t *nodes, uint32_t g, const Tile &t, const LeafOut &lo) {
+        const uint32_t lane = threadIdx.x & 63;
+        if (lo.active) {
+            uint4 *d = reinterpret_cast<uint4 *>(nodes + (size_t)(g * 64 + lane) * 8);
+            d[0] = make_uint4(lo.cv[0], lo.cv[1], lo.cv[2], lo.cv[3]);
+            d[1] = make_uint4(lo.cv[4], lo.cv[5], lo.cv[6], lo.cv[7]);
+        }
+        const uint32_t units = t.n_units ? t.n_units : 1u;
+        // descriptor of tile-local unit i on lane i, then moved to table lanes [n_tab, n_tab + units)
+        const uint32_t act = __shfl(lo.active ? 1u : 0u, lo.u_head & 63);
+        const uint32_t d_n = (lane < units && act) ? lo.u_cnt : 0u;
+        const uint32_t d_off = g * 64 + lo.u_head;
+        const uint32_t d_out = t.n_units ? t.first_unit + lane : t.cv_index;
+        const uint32_t src = (lane - n_tab) & 63;
+        const uint32_t v_n = __shfl(d_n, src), v_off = __shfl(d_off, src), v_out = __shfl(d_out, src);
+        if (lane >= n_tab && lane < n_tab + units) {
+            tb_n = v_n; tb_off = v_off; tb_out = v_out; tb_root = t.n_units ? 1u : 0u;
+        }
+        n_tab += units;
+    }
+
+    __device__ __forceinline__ void fold_and_write(uint32_t *nodes, const HashArgs &a) {
+        const uint32_t lane = threadIdx.x & 63;
+        if (n_tab == 0) return;
+        uint32_t n = lane < n_tab ? tb_n : 0u, off = tb_off;
+        const bool valid = n > 0;
+        while (__ballot(n > 1) != 0ull) {
+            const uint32_t out_cnt = n > 1 ? (n + 1) >> 1 : n;
+            uint32_t inc = out_cnt;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                uint32_t y = __shfl_up(inc, d);
+                if (lane >= (uint32_t)d) inc += y;
+            }
+            const uint32_t total = __shfl(inc, 63);
+            const uint32_t my_oo = inc - out_cnt;
+            for (uint32_t p = 0; p * 64 < total; p++) {
+                const uint32_t q = p * 64 + lane;
+                const bool on = q < total;
+                uint32_t lo = 0, hi = 63;  // smallest u with inc[u] > q
+#pragma unroll
+                for (int it = 0; it < 6; it++) {
+                    const uint32_t mid = (lo + hi) >> 1;
+                    const uint32_t v = __shfl(inc, mid);
+                    if (lo < hi) {
+                        if (v > q) hi = mid; else lo = mid + 1;
+                    }
+                }
+                const uint32_t u = lo;
+                const uint32_t cu = __shfl(n, u), io = __shfl(off, u), oo = __shfl(my_oo, u), rt = __shfl(tb_root, u);
+                const uint32_t j = q - oo;
+                uint32_t cv[8];
+                if (on) {
+                    const uint4 *s = reinterpret_cast<const uint4 *>(nodes + (size_t)(io + 2 * j) * 8);
+                    const uint4 l0 = s[0], l1 = s[1];
+                    uint32_t L[8] = {l0.x, l0.y, l0.z, l0.w, l1.x, l1.y, l1.z, l1.w};
+                    if (cu > 1 && 2 * j + 1 < cu) {
+                        const uint4 r0 = s[2], r1 = s[3];
+                        uint32_t R[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
+                        b3::parent(cv, L, R, rt && cu == 2);
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < 8; i++) cv[i] = L[i];
+                    }
+                }
+                // every lane has read its children before any lane overwrites a node (one wave: LDS operations
+                // execute in program order); node q only ever replaces a node at or before its own children
+                __builtin_amdgcn_wave_barrier();
+                if (on) {
+                    uint4 *d = reinterpret_cast<uint4 *>(nodes + (size_t)q * 8);
+                    d[0] = make_uint4(cv[0], cv[1], cv[2], cv[3]);
+                    d[1] = make_uint4(cv[4], cv[5], cv[6], cv[7]);
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+            n = out_cnt;
+            off = my_oo;
+        }
+        if (valid) {
+            const uint4 *s = reinterpret_cast<const uint4 *>(nodes + (size_t)off * 8);
+            const uint4 c0 = s[0], c1 = s[1];
+            uint4 *o = reinterpret_cast<uint4 *>((tb_root ? a.digests : a.tile_cv) + (size_t)tb_out * 8);
+            o[0] = c0;
+            o[1] = c1;
+        }
+        n_tab = 0;
+    }
+};
 
 }  // namespace zn

@@ -8,26 +8,61 @@
 
 namespace zn {
 
-template <bool COPY>
+// FOLD_G = tiles per wave whose parent levels are folded together (hash_dev.h, FoldQueue).  More tiles per wave
+// means fewer fold passes but coarser work items; the launcher picks it from the tile count so that a
+// small batch still spreads over every SIMD a few times.
+template <bool COPY, int FOLD_G>
 __global__ __launch_bounds__(256) void k_hash_tiles(HashArgs a) {
-    const uint32_t wave = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (wave >= a.n_tiles) return;
-    const Tile t = a.tiles[wave];
-    if (a.pass == PASS_SECOND && t.n_units) {
-        // second pass: a small tile matters only if the general decoder finished one of its rows
-        if (*a.pending_count == 0) return;
-        const uint32_t lane = threadIdx.x & 63;
-        const bool mine = lane < t.n_units && a.status[t.first_unit + lane] == 2;
-        if (__ballot(mine) == 0ull) return;
+    __shared__ __attribute__((aligned(16))) uint32_t s_nodes[FOLD_G > 1 ? 4 : 1][FOLD_G > 1 ? FOLD_G * 64 * 8 : 4];
+    const uint32_t w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint32_t first = (blockIdx.x * 4 + w) * FOLD_G;
+    if (first >= a.n_tiles) return;
+    if (a.pass == PASS_SECOND && *a.pending_count == 0) {
+        // second pass with nothing handed to the general decoder: only big-unit slices matter; skip the wave
+        // outright when its tiles are all small ones (the common C2 case: one load per tile, no hashing)
+        bool any_big = false;
+        for (uint32_t g = 0; g < FOLD_G && first + g < a.n_tiles; g++) any_big |= a.tiles[first + g].n_units == 0;
+        if (!any_big) return;
     }
-    hash_tile<COPY>(a, t);
+    FoldQueue<FOLD_G> fq;
+    uint32_t *nodes = s_nodes[FOLD_G > 1 ? w : 0];
+    for (uint32_t g = 0; g < FOLD_G && first + g < a.n_tiles; g++) {
+        const Tile t = a.tiles[first + g];
+        if (a.pass == PASS_SECOND && t.n_units) {
+            // second pass: a small tile matters only if the general decoder finished one of its rows
+            if (*a.pending_count == 0) continue;
+            const bool mine = lane < t.n_units && a.status[t.first_unit + lane] == 2;
+            if (__ballot(mine) == 0ull) continue;
+        }
+        LeafOut lo;
+        hash_tile_leaves<COPY, false>(a, t, nullptr, lo);
+        if (FOLD_G > 1 && FoldQueue<FOLD_G>::fits(t)) fq.add(nodes, g, t, lo);
+        else fold_tile_now(a, t, lo);
+    }
+    if (FOLD_G > 1) fq.fold_and_write(nodes, a);
+}
+
+template <int G>
+static void launch_hash_tiles_g(const HashArgs &a, hipStream_t s) {
+    const uint32_t waves = (a.n_tiles + G - 1) / G;
+    dim3 grid((waves + 3) / 4), block(256);
+    if (a.copy_to_B) hipLaunchKernelGGL((k_hash_tiles<true, G>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((k_hash_tiles<false, G>), grid, block, 0, s, a);
 }
 
 void launch_hash_tiles(const HashArgs &a, hipStream_t s) {
     if (!a.n_tiles) return;
-    dim3 grid((a.n_tiles + 3) / 4), block(256);
-    if (a.copy_to_B) hipLaunchKernelGGL(k_hash_tiles<true>, grid, block, 0, s, a);
-    else hipLaunchKernelGGL(k_hash_tiles<false>, grid, block, 0, s, a);
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+    }
+    const uint64_t resident = (uint64_t)cus * 20;  // 5 waves per SIMD at this kernel's register count
+    const int cap = a.fold_tiles_max > 0 ? a.fold_tiles_max : 4;
+    if (cap >= 4 && a.n_tiles >= 6 * resident) launch_hash_tiles_g<4>(a, s);
+    else if (cap >= 2 && a.n_tiles >= 3 * resident) launch_hash_tiles_g<2>(a, s);
+    else launch_hash_tiles_g<1>(a, s);
 }
 
 // Finish units with more than 64 leaves: one wave folds the unit's tile CVs (each the root of

@@ -363,11 +363,13 @@ __global__ __launch_bounds__(64) void k_zstd_encode(EncodeArgs a) {
 }
 
 // ---- piece scan + gather ---------------------------------------------------------------------
-// local exclusive scan of piece lengths inside blocks of 1024 pieces + block totals
-__global__ __launch_bounds__(1024) void k_piece_scan(const uint32_t *piece_len, uint32_t n, uint64_t *local_excl,
-                                                     uint64_t *block_tot) {
-    __shared__ uint64_t wsum[16];
-    const uint32_t i = blockIdx.x * 1024 + threadIdx.x, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+// local exclusive scan of piece lengths inside blocks of 256 pieces + block totals (small workgroups: the
+// scan and the gather run next to the hash kernel of the auxiliary stream and must fit into the wave slots
+// it frees one workgroup at a time)
+__global__ __launch_bounds__(256) void k_piece_scan(const uint32_t *piece_len, uint32_t n, uint64_t *local_excl,
+                                                    uint64_t *block_tot) {
+    __shared__ uint64_t wsum[4];
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     uint64_t v = i < n ? piece_len[i] : 0, inc = v;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
@@ -379,7 +381,7 @@ __global__ __launch_bounds__(1024) void k_piece_scan(const uint32_t *piece_len, 
     uint64_t wbase = 0;
     for (uint32_t k = 0; k < w; k++) wbase += wsum[k];
     if (i < n) local_excl[i] = wbase + inc - v;
-    if (threadIdx.x == 1023) block_tot[blockIdx.x] = wbase + inc;
+    if (threadIdx.x == 255) block_tot[blockIdx.x] = wbase + inc;
 }
 
 // one wave per piece: copy it to its packed position; fill the per-round outputs
@@ -388,7 +390,7 @@ __global__ __launch_bounds__(256) void k_gather(GatherArgs g) {
     const uint32_t piece = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (piece >= g.n_pieces) return;
     // base of my scan block = sum of the totals of the blocks before it
-    const uint32_t sb = piece >> 10;
+    const uint32_t sb = piece >> 8;
     uint64_t part = 0;
     for (uint32_t k = lane; k < sb; k += 64) part += g.block_tot[k];
 #pragma unroll
@@ -416,7 +418,7 @@ void launch_encode(const EncodeArgs &a, int grid, bool small_blocks, hipStream_t
 
 void launch_piece_scan(const uint32_t *piece_len, uint32_t n, uint64_t *local_excl, uint64_t *block_tot, hipStream_t s) {
     if (!n) return;
-    hipLaunchKernelGGL(k_piece_scan, dim3((n + 1023) / 1024), dim3(1024), 0, s, piece_len, n, local_excl, block_tot);
+    hipLaunchKernelGGL(k_piece_scan, dim3((n + 255) / 256), dim3(256), 0, s, piece_len, n, local_excl, block_tot);
 }
 
 // Opt-in store-if-incompressible (reference wish list, TODO_NOW.md:L37-38): a round whose frame is not

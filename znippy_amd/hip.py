@@ -26,6 +26,12 @@ def _dptr(t):
     if isinstance(t, int):
         return vp(t)
     assert t.is_cuda and t.is_contiguous(), "device buffers must be contiguous CUDA tensors"
+    # The context runs on its own non-blocking stream: whatever torch still has queued on ITS stream for this
+    # buffer (a torch.zeros fill, a copy) must have landed before our kernels touch it.
+    import torch
+    ts = torch.cuda.current_stream(t.device)
+    if not ts.query():
+        ts.synchronize()
     return vp(t.data_ptr())
 
 
