@@ -89,6 +89,9 @@ struct Shared {
 };
 
 __device__ __forceinline__ int hibit(uint32_t v) { return 31 - __clz(v); }
+// wave-uniform value -> SGPR: arithmetic on it runs on the scalar unit, branches on it are scalar branches
+__device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+__device__ __forceinline__ uint64_t uni64(uint64_t v) { return ((uint64_t)uni((uint32_t)(v >> 32)) << 32) | uni((uint32_t)v); }
 
 __device__ __forceinline__ uint64_t load8_guard(const uint8_t *p, const uint8_t *end) {
     if (p + 8 <= end) {
@@ -797,28 +800,60 @@ __global__ __launch_bounds__(NWAVES * 64) void k_zstd_decode(DecodeArgs a) {
             while (seq_done < nseq) {
                 const uint32_t bn = nseq - seq_done < SEQ_BATCH ? nseq - seq_done : SEQ_BATCH;
                 __syncthreads();
-                if (tid == 0) {
-                    const FseEntry *tl = S.sel[0] == 0 ? S.dll : (S.sel[0] == 1 ? &S.rle[0] : S.ll);
-                    const FseEntry *to = S.sel[1] == 0 ? S.dof : (S.sel[1] == 1 ? &S.rle[1] : S.of);
-                    const FseEntry *tm = S.sel[2] == 0 ? S.dml : (S.sel[2] == 1 ? &S.rle[2] : S.ml);
-                    BitR b;
-                    b.base = src + S.bs_off; b.end = blob_end; b.pos = S.bs_pos; b.refill();
-                    uint32_t sl = S.st_ll, so = S.st_of, sm = S.st_ml;
-                    uint32_t r0 = S.rep[0], r1 = S.rep[1], r2 = S.rep[2];
+                // Sequence decoding is one serial bitstream: wave 0 runs it as SCALAR code — every value is wave-uniform
+                // (readfirstlane), so the state machine, the bit arithmetic and the branches execute on the scalar unit
+                // and only the table lookups / result stores touch the vector side.
+                if (wave0) {
+                    const uint32_t sel0 = uni(S.sel[0]), sel1 = uni(S.sel[1]), sel2 = uni(S.sel[2]);
+                    const FseEntry *tl = sel0 == 0 ? S.dll : (sel0 == 1 ? &S.rle[0] : S.ll);
+                    const FseEntry *to = sel1 == 0 ? S.dof : (sel1 == 1 ? &S.rle[1] : S.of);
+                    const FseEntry *tm = sel2 == 0 ? S.dml : (sel2 == 1 ? &S.rle[2] : S.ml);
+                    // backward bit reader: `left` unread bits, a 64-bit container covering stream bits [cb, cb + 64);
+                    // bits below bit 0 read as zero and drive `left` negative, which is the corruption test
+                    const uint8_t *const bbase = src + uni(S.bs_off);
+                    int64_t left = (int64_t)uni64((uint64_t)S.bs_pos), cb = 0;
+                    uint64_t c = 0;
+                    auto reload = [&]() {
+                        int64_t b0 = ((left + 7) >> 3) - 8;
+                        if (b0 < 0) b0 = 0;
+                        c = uni64(load8_guard(bbase + b0, blob_end));
+                        cb = b0 * 8;
+                    };
+                    auto rd = [&](uint32_t nb) -> uint32_t {
+                        const int32_t sh = (int32_t)(left - cb) - (int32_t)nb;
+                        const uint64_t v = sh >= 0 ? (c >> sh) : (c << (sh < -63 ? 63 : -sh));
+                        left -= nb;
+                        return (uint32_t)v & ((1u << nb) - 1u);  // nb <= 31
+                    };
+                    reload();
+                    uint32_t sl = uni(S.st_ll), so = uni(S.st_of), sm = uni(S.st_ml);
+                    uint32_t r0 = uni(S.rep[0]), r1 = uni(S.rep[1]), r2 = uni(S.rep[2]);
                     int err = 0;
                     uint64_t produced = 0;
                     uint32_t lits = 0;
+                    const uint32_t lit_room = uni(S.lit_len) - uni(S.lit_pos);
+                    const uint64_t abs0 = uni64(S.out_pos);
+                    const uint64_t out_end = uni64(S.out_end);
+                    const uint2 *const tl2 = reinterpret_cast<const uint2 *>(tl), *const to2 = reinterpret_cast<const uint2 *>(to),
+                                *const tm2 = reinterpret_cast<const uint2 *>(tm);
+                    const bool lane0 = (tid & 63) == 0;
                     for (uint32_t i = 0; i < bn; i++) {
-                        const FseEntry eo = to[so], em = tm[sm], el = tl[sl];
-                        uint32_t ov = eo.base + b.read(eo.addbits);
-                        uint32_t ml = em.base + b.read(em.addbits);
-                        uint32_t ll = el.base + b.read(el.addbits);
+                        // entry = {next:16 | nbits:8 | addbits:8, base}
+                        const uint2 veo = to2[so], vem = tm2[sm], vel = tl2[sl];
+                        const uint32_t eox = uni(veo.x), eoy = uni(veo.y), emx = uni(vem.x), emy = uni(vem.y), elx = uni(vel.x), ely = uni(vel.y);
+                        const uint32_t ofb = eox >> 24, mlb = emx >> 24, llb = elx >> 24;
+                        if (left - cb < 32) reload();
+                        const uint32_t ov = eoy + rd(ofb > 31 ? 31 : ofb);
+                        if (left - cb < 32) reload();
+                        const uint32_t ml = emy + rd(mlb);
+                        const uint32_t ll = ely + rd(llb);
                         if (seq_done + i + 1 < nseq) {
-                            sl = el.next + b.read(el.nbits);
-                            sm = em.next + b.read(em.nbits);
-                            so = eo.next + b.read(eo.nbits);
+                            if (left - cb < 32) reload();
+                            sl = (elx & 0xFFFF) + rd((elx >> 16) & 0xFF);
+                            sm = (emx & 0xFFFF) + rd((emx >> 16) & 0xFF);
+                            so = (eox & 0xFFFF) + rd((eox >> 16) & 0xFF);
                         }
-                        if (b.pos < 0) { err = E_CORRUPT; break; }
+                        if (left < 0) { err = E_CORRUPT; break; }
                         uint32_t offset;
                         if (ov > 3) { offset = ov - 3; r2 = r1; r1 = r0; r0 = offset; }
                         else {
@@ -831,20 +866,22 @@ __global__ __launch_bounds__(NWAVES * 64) void k_zstd_decode(DecodeArgs a) {
                                 r1 = r0; r0 = offset;
                             }
                         }
-                        S.seq_ll[i] = ll; S.seq_ml[i] = ml; S.seq_off[i] = offset;
+                        if (lane0) { S.seq_ll[i] = ll; S.seq_ml[i] = ml; S.seq_off[i] = offset; }
                         lits += ll;
                         produced += (uint64_t)ll + ml;
                         // validate against what exists at that point
-                        if (S.lit_pos + lits > S.lit_len) { err = E_CORRUPT; break; }
-                        if ((uint64_t)offset > S.out_pos + produced - ml) { err = E_CORRUPT; break; }
+                        if (lits > lit_room) { err = E_CORRUPT; break; }
+                        if ((uint64_t)offset > abs0 + produced - ml) { err = E_CORRUPT; break; }
                     }
-                    if (!err && S.out_pos + produced > S.out_end) err = E_CORRUPT;
-                    if (!err && seq_done + bn == nseq && b.pos != 0) err = E_CORRUPT;
-                    S.st_ll = sl; S.st_of = so; S.st_ml = sm;
-                    S.rep[0] = r0; S.rep[1] = r1; S.rep[2] = r2;
-                    S.bs_pos = b.pos;
-                    S.err = err;
-                    S.batch_n = bn;
+                    if (!err && abs0 + produced > out_end) err = E_CORRUPT;
+                    if (!err && seq_done + bn == nseq && left != 0) err = E_CORRUPT;
+                    if (lane0) {
+                        S.bs_pos = left;
+                        S.st_ll = sl; S.st_of = so; S.st_ml = sm;
+                        S.rep[0] = r0; S.rep[1] = r1; S.rep[2] = r2;
+                        S.err = err;
+                        S.batch_n = bn;
+                    }
                 }
                 __syncthreads();
                 if (S.err) break;
