@@ -52,7 +52,9 @@ __constant__ int8_t c_of_default[29] = {1, 1, 1, 1, 1, 1, 2, 2, 2, 1, 1, 1, 1, 1
 
 enum { K_LL = 0, K_OF = 1, K_ML = 2 };
 
-struct Shared {
+// NW = waves of the workgroup: sizes the pattern buffer (16 bytes per thread per trip)
+template <int NW>
+struct SharedT {
     FseEntry ll[512], ml[512], of[256];  // tables described in the current/previous block
     FseEntry dll[64], dml[64], dof[32];  // predefined tables (built once per workgroup)
     FseEntry rle[3];
@@ -65,7 +67,7 @@ struct Shared {
     uint8_t fse_sym[512];
     uint32_t seq_ll[SEQ_BATCH], seq_ml[SEQ_BATCH], seq_off[SEQ_BATCH];
     // pattern buffer for long overlapping matches: E[i] = period[i % off], i < off + 16 * threads
-    __attribute__((aligned(16))) uint8_t ebuf[EXP_OFF_MAX + 16 * 1024 + 64];
+    __attribute__((aligned(16))) uint8_t ebuf[EXP_OFF_MAX + 16 * 64 * NW + 64];
     // per-row / per-block state broadcast from lane 0
     int32_t err;
     uint32_t row;
@@ -300,6 +302,7 @@ __device__ __forceinline__ void coop_match(uint8_t *dst, uint32_t off, uint64_t 
 // ---------------------------------------------------------------------------------------------
 // lane-0 serial helpers
 // ---------------------------------------------------------------------------------------------
+template <class Shared>
 __device__ int fse_read_ncount(Shared &S, const uint8_t *src, uint32_t n, int max_log, int max_sym, int *nsym,
                                int *log, uint32_t *consumed) {
     FwdR b{src, n, 0};
@@ -340,6 +343,7 @@ __device__ int fse_read_ncount(Shared &S, const uint8_t *src, uint32_t n, int ma
 // Build a decoding table from S.norm[0..nsym).  kind selects how (symbol -> base, addbits) maps:
 // LL / ML use the RFC's code tables, OF codes carry `code` extra bits on base 1<<code,
 // kind < 0 = plain symbols (Huffman weights).
+template <class Shared>
 __device__ int fse_build(Shared &S, FseEntry *t, int nsym, int log, int kind) {
     const int size = 1 << log;
     int high = size;
@@ -382,6 +386,7 @@ __device__ int fse_set_rle(FseEntry *e, uint32_t sym, int kind) {
 }
 
 // Huffman tree description -> S.weights / S.sym_start / S.sym_len / S.huf_log (lane 0).
+template <class Shared>
 __device__ int huf_read_tree(Shared &S, const uint8_t *src, uint32_t n, const uint8_t *blob_end, uint32_t *consumed) {
     if (n < 1) return E_TRUNC;
     uint32_t hb = src[0];
@@ -469,6 +474,7 @@ __device__ int huf_read_tree(Shared &S, const uint8_t *src, uint32_t n, const ui
 }
 
 // One lane decodes one Huffman stream (n_out symbols) from [p, p+n) into dst.
+template <class Shared>
 __device__ int huf_decode_stream(const Shared &S, const uint8_t *p, uint32_t n, const uint8_t *blob_end,
                                  uint8_t *dst, uint32_t n_out) {
     BitR b;
@@ -520,7 +526,8 @@ __device__ uint64_t wave_xxh64(const uint8_t *p, uint64_t len, uint32_t lane) {
 // the kernel
 // ---------------------------------------------------------------------------------------------
 template <int NWAVES>
-__global__ __launch_bounds__(NWAVES * 64) void k_zstd_decode(DecodeArgs a) {
+__global__ __launch_bounds__(NWAVES * 64, NWAVES == 4 ? 4 : 1) void k_zstd_decode(DecodeArgs a) {
+    using Shared = SharedT<NWAVES>;
     __shared__ Shared S;
     const uint32_t tid = threadIdx.x, NT = NWAVES * 64;
     const bool wave0 = tid < 64;
