@@ -130,6 +130,124 @@ __device__ __forceinline__ void wave_copy(uint8_t *dst, const uint8_t *src, uint
     if (done + lane < n) dst[done + lane] = src[done + lane];
 }
 
+__device__ __forceinline__ uint32_t suni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+__device__ __forceinline__ uint32_t rdlane(uint32_t v, uint32_t l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)l); }
+
+// Sequences section bitstream (predefined FSE tables), built by the whole wave.
+//   * everything that does not depend on the FSE state is per-lane work (lane j = the j-th sequence in
+//     encoding order of a batch of 64: codes, extra bits, table rows);
+//   * the three state chains (the only serial dependency) run on the scalar unit: the state tables live in
+//     VGPRs (lane k = entry k) and are indexed with v_readlane, the per-step outputs go back to lane j with
+//     a compare+select — no memory access inside the chain;
+//   * each lane then assembles its sequence's <= 75 bits, an exclusive scan places them, and the lanes OR
+//     them into a small LDS window that is streamed out one dword per lane.
+// seqs[3*i..] = {ll, ml-3, offset}; returns the end of the bitstream (after the closing 1 bit).
+template <class SH>
+__device__ __noinline__ uint8_t *encode_sequences(SH &S, const uint32_t *seqs, uint32_t nseq, uint8_t *p, uint32_t lane) {
+    // bit window: 64 sequences x <= 75 bits + carry; lives in the hash table, which is dead once the block's matches are found
+    uint32_t *const ebits = reinterpret_cast<uint32_t *>(S.table);
+    const uint32_t st_ll = S.tabs.ll_state[lane & 63], st_ml = S.tabs.ml_state[lane & 63], st_of = S.tabs.of_state[lane & 31];
+    for (uint32_t i = lane; i < 200; i += 64) ebits[i] = 0;
+    uint32_t vl = 0, vm = 0, vo = 0;  // FSE states (scalar)
+    uint32_t bitpos = 0;              // bits pending in the LDS window (scalar)
+    for (uint32_t e0 = 0; e0 < nseq; e0 += 64) {
+        const uint32_t cnt = nseq - e0 < 64 ? nseq - e0 : 64;
+        const bool on = lane < cnt;
+        const uint32_t i = nseq - 1 - (e0 + (on ? lane : 0));  // encoding order: last sequence first
+        const uint32_t ll = seqs[3 * i], mlb = seqs[3 * i + 1], ov = seqs[3 * i + 2] + 3;
+        const uint32_t lc = ll < 64 ? c_ll_code[ll] : (uint32_t)hib(ll) + 19;
+        const uint32_t mc = mlb < 128 ? c_ml_code[mlb] : (uint32_t)hib(mlb) + 36;
+        const uint32_t oc = (uint32_t)hib(ov);
+        const FseSymTT tl = S.tabs.ll_tt[lc], tm = S.tabs.ml_tt[mc], to = S.tabs.of_tt[oc];
+        uint32_t f_l = 0, f_m = 0, f_o = 0;  // state bits of my sequence: value | nbits << 16 (written by the chain)
+        for (uint32_t j = 0; j < cnt; j++) {
+            const uint32_t dl = rdlane(tl.delta_nb_bits, j), fl = rdlane((uint32_t)tl.delta_find_state, j);
+            const uint32_t dm = rdlane(tm.delta_nb_bits, j), fm = rdlane((uint32_t)tm.delta_find_state, j);
+            const uint32_t d_o = rdlane(to.delta_nb_bits, j), fo = rdlane((uint32_t)to.delta_find_state, j);
+            if (e0 + j == 0) {  // first symbol: initial states, no bits
+                uint32_t nb = (dm + (1u << 15)) >> 16;
+                vm = rdlane(st_ml, (uint32_t)((int32_t)(((nb << 16) - dm) >> nb) + (int32_t)fm));
+                nb = (d_o + (1u << 15)) >> 16;
+                vo = rdlane(st_of, (uint32_t)((int32_t)(((nb << 16) - d_o) >> nb) + (int32_t)fo));
+                nb = (dl + (1u << 15)) >> 16;
+                vl = rdlane(st_ll, (uint32_t)((int32_t)(((nb << 16) - dl) >> nb) + (int32_t)fl));
+            } else {
+                uint32_t nb = (vo + d_o) >> 16;
+                if (lane == j) f_o = (vo & ((1u << nb) - 1)) | (nb << 16);
+                vo = rdlane(st_of, (uint32_t)((int32_t)(vo >> nb) + (int32_t)fo));
+                nb = (vm + dm) >> 16;
+                if (lane == j) f_m = (vm & ((1u << nb) - 1)) | (nb << 16);
+                vm = rdlane(st_ml, (uint32_t)((int32_t)(vm >> nb) + (int32_t)fm));
+                nb = (vl + dl) >> 16;
+                if (lane == j) f_l = (vl & ((1u << nb) - 1)) | (nb << 16);
+                vl = rdlane(st_ll, (uint32_t)((int32_t)(vl >> nb) + (int32_t)fl));
+            }
+        }
+        // my sequence's bits in stream order: OF, ML, LL state bits, then LL, ML, OF extra bits
+        uint64_t lo = 0, hi = 0;
+        uint32_t T = 0;
+        auto put = [&](uint32_t v, uint32_t nb) {  // nb <= 17, v < 2^nb
+            if (T < 64) {
+                lo |= (uint64_t)v << T;
+                if (T + nb > 64) hi |= (uint64_t)v >> (64 - T);
+            } else hi |= (uint64_t)v << (T - 64);
+            T += nb;
+        };
+        if (on) {
+            put(f_o & 0xFFFF, f_o >> 16);
+            put(f_m & 0xFFFF, f_m >> 16);
+            put(f_l & 0xFFFF, f_l >> 16);
+            put(ll - c_ll_base_e[lc], c_ll_bits_e[lc]);
+            put(mlb + 3 - c_ml_base_e[mc], c_ml_bits_e[mc]);
+            put(ov - (1u << oc), oc);
+        }
+        uint32_t inc = T;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t y = __shfl_up(inc, d);
+            if (lane >= (uint32_t)d) inc += y;
+        }
+        const uint32_t pos = bitpos + inc - T;
+        if (T) {
+            const uint32_t sft = pos & 31, w = pos >> 5;  // <= 75 + 31 bits after the shift
+            const uint64_t x0 = lo << sft, x1 = (hi << sft) | (sft ? lo >> (64 - sft) : 0ull);
+            const uint32_t w0 = (uint32_t)x0, w1 = (uint32_t)(x0 >> 32), w2 = (uint32_t)x1, w3 = (uint32_t)(x1 >> 32);
+            if (w0) atomicOr(&ebits[w], w0);
+            if (w1) atomicOr(&ebits[w + 1], w1);
+            if (w2) atomicOr(&ebits[w + 2], w2);
+            if (w3) atomicOr(&ebits[w + 3], w3);
+        }
+        bitpos = suni(bitpos + __shfl(inc, 63));
+        __builtin_amdgcn_wave_barrier();
+        // stream out the complete dwords, keep the partial one in front
+        const uint32_t ndw = bitpos >> 5;
+        uint32_t keep = 0;
+        for (uint32_t k = lane; k < ndw; k += 64) {
+            const uint32_t w = ebits[k];
+            __builtin_memcpy(p + 4 * k, &w, 4);
+        }
+        keep = ebits[ndw];
+        __builtin_amdgcn_wave_barrier();
+        for (uint32_t k = lane; k <= ndw; k += 64) ebits[k] = 0;
+        __builtin_amdgcn_wave_barrier();
+        if (lane == 0) ebits[0] = keep;
+        __builtin_amdgcn_wave_barrier();
+        p += 4 * ndw;
+        bitpos &= 31;
+    }
+    // final states (ML, OF, LL), closing bit
+    if (lane == 0) {
+        uint64_t acc = ebits[0];
+        uint32_t nb = bitpos;
+        acc |= (uint64_t)(vm & 63) << nb; nb += 6;
+        acc |= (uint64_t)(vo & 31) << nb; nb += 5;
+        acc |= (uint64_t)(vl & 63) << nb; nb += 6;
+        acc |= 1ull << nb; nb += 1;
+        for (uint32_t k = 0; k * 8 < nb; k++) p[k] = (uint8_t)(acc >> (8 * k));
+    }
+    return p + ((bitpos + 18 + 7) >> 3);
+}
+
 // One wave encodes one block item pulled from the atomic cursor.  HASH_LOG 11 (4 KiB table, more
 // resident waves) serves batches of small rounds, 13 serves 128 KiB blocks.
 template <uint32_t HASH_LOG>
@@ -291,51 +409,65 @@ __global__ __launch_bounds__(64) void k_zstd_encode(EncodeArgs a) {
         lit_total += nq - anchor;
         __syncthreads();  // sequences + literal bytes of all lanes are visible to lane 0
 
-        // ---- entropy stage (lane 0) ----
-        if (lane == 0) {
-            uint32_t piece_len = 0, hdr_len = 0;
+        // ---- entropy stage: headers by lane 0, the sequences bitstream by the whole wave ----
+        bool raw = nseq == 0;
+        uint32_t csize = 0;
+        if (!raw) {
             uint8_t *p = lits + lit_total;
-            bool raw = nseq == 0;
-            if (!raw) {
+            const uint32_t hl = nseq < 128 ? 1u : (nseq < 0x7F00 ? 2u : 3u);
+            if (lane == 0) {
                 // literals header: Raw_Literals_Block, size_format 3 (20-bit size, 3 bytes)
                 blk[3] = (uint8_t)(0 | (3 << 2) | ((lit_total & 15) << 4));
                 blk[4] = (uint8_t)(lit_total >> 4);
                 blk[5] = (uint8_t)(lit_total >> 12);
-                if (nseq < 128) *p++ = (uint8_t)nseq;
-                else if (nseq < 0x7F00) { *p++ = (uint8_t)((nseq >> 8) + 128); *p++ = (uint8_t)nseq; }
-                else { *p++ = 255; *p++ = (uint8_t)(nseq - 0x7F00); *p++ = (uint8_t)((nseq - 0x7F00) >> 8); }
-                *p++ = 0;  // LL, OF, ML all Predefined_Mode
-                BitW b{p, 0, 0};
-                CState sl, so, sm;
-                for (int32_t i = (int32_t)nseq - 1; i >= 0; i--) {
-                    const uint32_t ll = seqs[3 * i], mlb = seqs[3 * i + 1], ov = seqs[3 * i + 2] + 3;
-                    const uint32_t lc = ll < 64 ? c_ll_code[ll] : (uint32_t)hib(ll) + 19;
-                    const uint32_t mc = mlb < 128 ? c_ml_code[mlb] : (uint32_t)hib(mlb) + 36;
-                    const uint32_t oc = (uint32_t)hib(ov);
-                    if (i == (int32_t)nseq - 1) {
-                        sm.init(S.tabs.ml_state, S.tabs.ml_tt, 6, mc);
-                        so.init(S.tabs.of_state, S.tabs.of_tt, 5, oc);
-                        sl.init(S.tabs.ll_state, S.tabs.ll_tt, 6, lc);
-                    } else {
-                        so.encode(b, oc);
-                        sm.encode(b, mc);
-                        sl.encode(b, lc);
+                if (nseq < 128) p[0] = (uint8_t)nseq;
+                else if (nseq < 0x7F00) { p[0] = (uint8_t)((nseq >> 8) + 128); p[1] = (uint8_t)nseq; }
+                else { p[0] = 255; p[1] = (uint8_t)(nseq - 0x7F00); p[2] = (uint8_t)((nseq - 0x7F00) >> 8); }
+                p[hl] = 0;  // LL, OF, ML all Predefined_Mode
+            }
+            // wide variant (128 KiB blocks, thousands of sequences): wave-parallel bitstream; small variant: serial writer
+            if (HASH_LOG == 13 && nseq > 8) p = encode_sequences(S, seqs, nseq, p + hl + 1, lane);
+            else {
+                // a handful of sequences (periodic data: one or two per block): the serial writer costs fewer
+                // issue slots than a wave-wide pass, and those slots belong to the hash kernel running alongside
+                uint32_t plen = 0;
+                if (lane == 0) {
+                    BitW b{p + hl + 1, 0, 0};
+                    CState sl, so, sm;
+                    for (int32_t i = (int32_t)nseq - 1; i >= 0; i--) {
+                        const uint32_t ll = seqs[3 * i], mlb = seqs[3 * i + 1], ov = seqs[3 * i + 2] + 3;
+                        const uint32_t lc = ll < 64 ? c_ll_code[ll] : (uint32_t)hib(ll) + 19;
+                        const uint32_t mc = mlb < 128 ? c_ml_code[mlb] : (uint32_t)hib(mlb) + 36;
+                        const uint32_t oc = (uint32_t)hib(ov);
+                        if (i == (int32_t)nseq - 1) {
+                            sm.init(S.tabs.ml_state, S.tabs.ml_tt, 6, mc);
+                            so.init(S.tabs.of_state, S.tabs.of_tt, 5, oc);
+                            sl.init(S.tabs.ll_state, S.tabs.ll_tt, 6, lc);
+                        } else {
+                            so.encode(b, oc);
+                            sm.encode(b, mc);
+                            sl.encode(b, lc);
+                        }
+                        b.add(ll - c_ll_base_e[lc], c_ll_bits_e[lc]);
+                        b.add(mlb + 3 - c_ml_base_e[mc], c_ml_bits_e[mc]);
+                        b.add(ov - (1u << oc), oc);
                     }
-                    b.add(ll - c_ll_base_e[lc], c_ll_bits_e[lc]);
-                    b.add(mlb + 3 - c_ml_base_e[mc], c_ml_bits_e[mc]);
-                    b.add(ov - (1u << oc), oc);
+                    sm.flush(b);
+                    so.flush(b);
+                    sl.flush(b);
+                    plen = (uint32_t)(b.close() - p);
                 }
-                sm.flush(b);
-                so.flush(b);
-                sl.flush(b);
-                p = b.close();
-                const uint32_t csize = (uint32_t)(p - (blk + 3));
-                if (csize >= n) raw = true;
-                else {
-                    const uint32_t bh = (last ? 1u : 0u) | (2u << 1) | (csize << 3);
-                    blk[0] = (uint8_t)bh; blk[1] = (uint8_t)(bh >> 8); blk[2] = (uint8_t)(bh >> 16);
-                    piece_len = 3 + csize;
-                }
+                p += suni(plen);
+            }
+            csize = (uint32_t)(p - (blk + 3));
+            if (csize >= n) raw = true;
+        }
+        if (lane == 0) {
+            uint32_t piece_len = 0, hdr_len = 0;
+            if (!raw) {
+                const uint32_t bh = (last ? 1u : 0u) | (2u << 1) | (csize << 3);
+                blk[0] = (uint8_t)bh; blk[1] = (uint8_t)(bh >> 8); blk[2] = (uint8_t)(bh >> 16);
+                piece_len = 3 + csize;
             }
             if (raw) {
                 const uint32_t bh = (last ? 1u : 0u) | (0u << 1) | (n << 3);
