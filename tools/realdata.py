@@ -87,5 +87,6 @@ def run(kind, cap):
     print(f"[{kind}] CPU oracle read loop on libzstd-19 frames: {total/2**20/dt:.0f} MB/s")
 
 cap = int(sys.argv[1]) << 20 if len(sys.argv) > 1 else 128 << 20
+bcap = int(sys.argv[2]) << 20 if len(sys.argv) > 2 else cap
 for kind in ("text", "binary"):
-    run(kind, cap)
+    run(kind, cap if kind == "text" else bcap)

@@ -235,7 +235,7 @@ int znippy_ctx_create(int device, void *hip_stream, znippy_ctx **out) {
         ctx->encode_grid_small = cus * 16;  // 4 KiB hash table per wave
         EncTables t;
         build_encode_tables(&t);
-        if (hipMalloc(&ctx->enc_seq, (size_t)ctx->encode_grid_small * MAX_SEQ * 3 * 4) != hipSuccess ||
+        if (hipMalloc(&ctx->enc_seq, (size_t)ctx->encode_grid * MAX_SEQ * 3 * 4) != hipSuccess ||
             hipMalloc(&ctx->enc_tabs, sizeof(EncTables)) != hipSuccess ||
             hipMemcpy(ctx->enc_tabs, &t, sizeof t, hipMemcpyHostToDevice) != hipSuccess) {
             delete ctx;

@@ -8,7 +8,7 @@ namespace zn {
 
 constexpr uint32_t BLOCK_BYTES = 128 * 1024;  // zstd Block_Maximum_Size
 constexpr uint32_t HDR_ROOM = 16;             // space in front of block 0 for the frame header
-constexpr uint32_t MAX_SEQ = 4096;            // sequences per block (block_len/40 at most)
+constexpr uint32_t MAX_SEQ = 16384;           // sequences per block (block_len/8 at most, wide variant)
 constexpr uint32_t SKIP_PIECE = 64u << 10;    // store-path rounds are gathered in 64 KiB pieces (one wave each)
 
 struct FseSymTT {

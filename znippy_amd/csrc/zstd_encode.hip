@@ -305,7 +305,9 @@ __global__ __launch_bounds__(64) void k_zstd_encode(EncodeArgs a) {
         const bool last = it.block + 1 == it.n_blocks;
         uint8_t *const blk = a.prov + it.prov + HDR_ROOM;  // block header goes here
         uint8_t *const lits = blk + 3 + 3;                 // literals after a 3-byte literals header
-        const uint32_t max_seq = (n / 40) < MAX_SEQ ? (n / 40) : MAX_SEQ;
+        // sequence budget: bounds the provisional slot (worst case ~5.4 bytes per sequence) and the sequence store
+        const uint32_t seq_div = HASH_LOG == 13 ? 8u : 40u;
+        const uint32_t max_seq = (n / seq_div) < MAX_SEQ ? (n / seq_div) : MAX_SEQ;
         // touch every 128-byte line of the block now: all of its HBM fetches are in flight at once and
         // the match finder's dependent loads below hit in L2/L1.  LDS-DMA loads (no VGPR destination,
         // nothing ever reads the sink) so no register is exposed to a late-arriving result.
@@ -330,79 +332,182 @@ __global__ __launch_bounds__(64) void k_zstd_encode(EncodeArgs a) {
         uint32_t anchor = PRE;  // first byte not yet emitted
         uint32_t base = 0, misses = 0;
         const uint32_t scan_end = nq >= 8 ? nq - 7 : 0;  // positions with >= 8 bytes ahead
-        while (base < scan_end && nseq < max_seq) {
-            const uint32_t pos = base + lane;
-            uint32_t cand = 0, hitf = 0;
-            if (pos < scan_end) {
-                const uint32_t v = ld32(inb + pos);
-                const uint32_t h = hash4<HASH_LOG>(v);
-                const uint32_t e = S.table[h];
-                S.table[h] = (uint16_t)pos;  // low 16 bits; candidates are within 64 KiB
-                if (e != 0xFFFF) {
-                    uint32_t c = (pos & ~0xFFFFu) | e;
-                    if (c >= pos) c -= 0x10000u;  // wraps to a huge value when there is no earlier half
-                    if (c < pos && pos >= PRE && ld32(inb + c) == v) { cand = c; hitf = 1; }
+        if constexpr (HASH_LOG == 13) {
+            // Wide variant: every lane probes its position AND extends its own candidate (up to LMAX bytes), then the
+            // window's matches are picked left to right — several sequences per 64 positions on real data instead
+            // of one.  Only a match that runs past LMAX is extended cooperatively (periodic data: 4 KiB per step).
+            constexpr uint32_t LMAX = 64;
+            while (base < scan_end && nseq < max_seq) {
+                const uint32_t pos = base + lane;
+                uint32_t cand = 0, mlen = 0;
+                if (pos < scan_end) {
+                    const uint32_t v = ld32(inb + pos);
+                    const uint32_t h = hash4<HASH_LOG>(v);
+                    const uint32_t e = S.table[h];
+                    S.table[h] = (uint16_t)pos;  // low 16 bits; candidates are within 64 KiB
+                    if (e != 0xFFFF) {
+                        uint32_t c = (pos & ~0xFFFFu) | e;
+                        if (c >= pos) c -= 0x10000u;  // wraps to a huge value when there is no earlier half
+                        if (c < pos && pos >= PRE && ld32(inb + c) == v) { cand = c; mlen = 4; }
+                    }
                 }
-            }
-            const uint64_t hit = __ballot(hitf != 0);
-            if (!hit) {
-                misses++;
-                base += 64 * (1 + (misses >> 4 > 7 ? 7 : misses >> 4));  // accelerate through incompressible data
-                continue;
-            }
-            misses = 0;
-            const uint32_t win = __ffsll((unsigned long long)hit) - 1;
-            const uint32_t mpos = __shfl(pos, win), mcand = __shfl(cand, win);
-            // cooperative extension: 16 bytes per lane per piece, 4 pieces (4 KiB) in flight per step
-            uint32_t ml = 4;
-            for (;;) {
-                uint32_t good[4];
-#pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    const uint32_t o = ml + q * 1024 + lane * 16;
-                    uint32_t g = 0;  // matching bytes in my 16-byte piece
-                    if (mpos + o + 16 <= nq) {
-                        uint4 x = ld128(inb + mpos + o), y = ld128(inb + mcand + o);
-                        const uint32_t d0 = x.x ^ y.x, d1 = x.y ^ y.y, d2 = x.z ^ y.z, d3 = x.w ^ y.w;
-                        g = 16;
-                        if (d0 | d1 | d2 | d3) {  // rare: only the piece where the match ends
-                            if (d0) g = (__ffs(d0) - 1) >> 3;
-                            else if (d1) g = 4 + ((__ffs(d1) - 1) >> 3);
-                            else if (d2) g = 8 + ((__ffs(d2) - 1) >> 3);
-                            else g = 12 + ((__ffs(d3) - 1) >> 3);
+                if (mlen) {
+                    const uint32_t lim = nq - pos < LMAX ? nq - pos : LMAX;
+                    uint32_t k = 4;
+                    bool open = true;
+                    while (open && k + 8 <= lim) {
+                        uint64_t x, y;
+                        __builtin_memcpy(&x, inb + pos + k, 8);
+                        __builtin_memcpy(&y, inb + cand + k, 8);
+                        const uint64_t d = x ^ y;
+                        if (d) { k += (uint32_t)(__ffsll((long long)d) - 1) >> 3; open = false; }
+                        else k += 8;
+                    }
+                    while (open && k < lim && inb[pos + k] == inb[cand + k]) k++;
+                    mlen = k;
+                }
+                const uint64_t hitm = __ballot(mlen != 0);
+                if (!hitm) {
+                    misses++;
+                    base += 64 * (1 + (misses >> 4 > 7 ? 7 : misses >> 4));  // accelerate through incompressible data
+                    continue;
+                }
+                misses = 0;
+                while (nseq < max_seq) {
+                    // leftmost candidate at or after the first byte not yet emitted
+                    const uint32_t skip = anchor > base ? anchor - base : 0;
+                    const uint64_t m = skip >= 64 ? 0ull : (hitm >> skip) << skip;
+                    if (!m) break;
+                    const uint32_t win = (uint32_t)__ffsll((long long)m) - 1;
+                    const uint32_t mpos = base + win, mcand = rdlane(cand, win);
+                    uint32_t ml = rdlane(mlen, win);
+                    if (ml >= LMAX) {
+                // cooperative extension: 16 bytes per lane per piece, 4 pieces (4 KiB) in flight per step
+                for (;;) {
+                    uint32_t good[4];
+    #pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        const uint32_t o = ml + q * 1024 + lane * 16;
+                        uint32_t g = 0;  // matching bytes in my 16-byte piece
+                        if (mpos + o + 16 <= nq) {
+                            uint4 x = ld128(inb + mpos + o), y = ld128(inb + mcand + o);
+                            const uint32_t d0 = x.x ^ y.x, d1 = x.y ^ y.y, d2 = x.z ^ y.z, d3 = x.w ^ y.w;
+                            g = 16;
+                            if (d0 | d1 | d2 | d3) {  // rare: only the piece where the match ends
+                                if (d0) g = (__ffs(d0) - 1) >> 3;
+                                else if (d1) g = 4 + ((__ffs(d1) - 1) >> 3);
+                                else if (d2) g = 8 + ((__ffs(d2) - 1) >> 3);
+                                else g = 12 + ((__ffs(d3) - 1) >> 3);
+                            }
+                        } else {
+                            while (g < 16 && mpos + o + g < nq && inb[mpos + o + g] == inb[mcand + o + g]) g++;
                         }
-                    } else {
-                        while (g < 16 && mpos + o + g < nq && inb[mpos + o + g] == inb[mcand + o + g]) g++;
+                        good[q] = g;
                     }
-                    good[q] = g;
-                }
-                bool done = false;
-#pragma unroll
-                for (int q = 0; q < 4; q++) {
+                    bool done = false;
+    #pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        if (done) break;
+                        const uint64_t partial = __ballot(good[q] != 16);
+                        if (partial) {
+                            const uint32_t fl = __ffsll((unsigned long long)partial) - 1;
+                            ml += fl * 16 + __shfl(good[q], fl);
+                            done = true;
+                        } else {
+                            ml += 1024;
+                        }
+                    }
                     if (done) break;
-                    const uint64_t partial = __ballot(good[q] != 16);
-                    if (partial) {
-                        const uint32_t fl = __ffsll((unsigned long long)partial) - 1;
-                        ml += fl * 16 + __shfl(good[q], fl);
-                        done = true;
-                    } else {
-                        ml += 1024;
+                }
+                    }
+                    const uint32_t ll = mpos - anchor;
+                    wave_copy(lits + lit_total, inb + anchor, ll, lane);
+                    if (lane == 0) {
+                        seqs[3 * nseq] = ll;
+                        seqs[3 * nseq + 1] = ml - 3;
+                        seqs[3 * nseq + 2] = mpos - mcand;
+                    }
+                    lit_total += ll;
+                    nseq++;
+                    anchor = mpos + ml;
+                }
+                base = anchor > base + 64 ? anchor : base + 64;
+            }
+        } else {
+            while (base < scan_end && nseq < max_seq) {
+                const uint32_t pos = base + lane;
+                uint32_t cand = 0, hitf = 0;
+                if (pos < scan_end) {
+                    const uint32_t v = ld32(inb + pos);
+                    const uint32_t h = hash4<HASH_LOG>(v);
+                    const uint32_t e = S.table[h];
+                    S.table[h] = (uint16_t)pos;  // low 16 bits; candidates are within 64 KiB
+                    if (e != 0xFFFF) {
+                        uint32_t c = (pos & ~0xFFFFu) | e;
+                        if (c >= pos) c -= 0x10000u;  // wraps to a huge value when there is no earlier half
+                        if (c < pos && pos >= PRE && ld32(inb + c) == v) { cand = c; hitf = 1; }
                     }
                 }
-                if (done) break;
+                const uint64_t hit = __ballot(hitf != 0);
+                if (!hit) {
+                    misses++;
+                    base += 64 * (1 + (misses >> 4 > 7 ? 7 : misses >> 4));  // accelerate through incompressible data
+                    continue;
+                }
+                misses = 0;
+                const uint32_t win = __ffsll((unsigned long long)hit) - 1;
+                const uint32_t mpos = __shfl(pos, win), mcand = __shfl(cand, win);
+                // cooperative extension: 16 bytes per lane per piece, 4 pieces (4 KiB) in flight per step
+                uint32_t ml = 4;
+                for (;;) {
+                    uint32_t good[4];
+    #pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        const uint32_t o = ml + q * 1024 + lane * 16;
+                        uint32_t g = 0;  // matching bytes in my 16-byte piece
+                        if (mpos + o + 16 <= nq) {
+                            uint4 x = ld128(inb + mpos + o), y = ld128(inb + mcand + o);
+                            const uint32_t d0 = x.x ^ y.x, d1 = x.y ^ y.y, d2 = x.z ^ y.z, d3 = x.w ^ y.w;
+                            g = 16;
+                            if (d0 | d1 | d2 | d3) {  // rare: only the piece where the match ends
+                                if (d0) g = (__ffs(d0) - 1) >> 3;
+                                else if (d1) g = 4 + ((__ffs(d1) - 1) >> 3);
+                                else if (d2) g = 8 + ((__ffs(d2) - 1) >> 3);
+                                else g = 12 + ((__ffs(d3) - 1) >> 3);
+                            }
+                        } else {
+                            while (g < 16 && mpos + o + g < nq && inb[mpos + o + g] == inb[mcand + o + g]) g++;
+                        }
+                        good[q] = g;
+                    }
+                    bool done = false;
+    #pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        if (done) break;
+                        const uint64_t partial = __ballot(good[q] != 16);
+                        if (partial) {
+                            const uint32_t fl = __ffsll((unsigned long long)partial) - 1;
+                            ml += fl * 16 + __shfl(good[q], fl);
+                            done = true;
+                        } else {
+                            ml += 1024;
+                        }
+                    }
+                    if (done) break;
+                }
+                // emit: literals [anchor, mpos) then the match
+                const uint32_t ll = mpos - anchor;
+                wave_copy(lits + lit_total, inb + anchor, ll, lane);
+                if (lane == 0) {
+                    seqs[3 * nseq] = ll;
+                    seqs[3 * nseq + 1] = ml - 3;
+                    seqs[3 * nseq + 2] = mpos - mcand;
+                }
+                lit_total += ll;
+                nseq++;
+                anchor = mpos + ml;
+                base = anchor;
             }
-            // emit: literals [anchor, mpos) then the match
-            const uint32_t ll = mpos - anchor;
-            wave_copy(lits + lit_total, inb + anchor, ll, lane);
-            if (lane == 0) {
-                seqs[3 * nseq] = ll;
-                seqs[3 * nseq + 1] = ml - 3;
-                seqs[3 * nseq + 2] = mpos - mcand;
-            }
-            lit_total += ll;
-            nseq++;
-            anchor = mpos + ml;
-            base = anchor;
         }
         // trailing literals
         wave_copy(lits + lit_total, inb + anchor, nq - anchor, lane);
