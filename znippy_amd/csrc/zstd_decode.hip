@@ -21,6 +21,11 @@ constexpr int LIT_SCRATCH_BYTES = 128 * 1024 + 64;
 constexpr int SEQ_BATCH = 256;
 constexpr uint32_t BIG_COPY = 8192;  // copies at least this long are shared by all waves of the workgroup
 constexpr uint32_t EXP_OFF_MAX = 4096;  // longest period expanded through LDS
+// Narrow variant (4 waves per frame: many small/medium frames): output window in LDS (aliases the pattern
+// buffer): [history | chunk].  Short sequences are executed inside it — literals and matches of up to 64
+// sequences at a time, one per lane — and the chunk is streamed to HBM when full, so a match never waits for
+// the store queue.  Sequences longer than WIN_SEQ_MAX go straight to HBM, as everything does in the wide variant.
+constexpr uint32_t WIN_HIST = 4096, WIN_CAP = 8192, WIN_SEQ_MAX = 2048;
 
 struct FseEntry {
     uint16_t next;    // new-state base
@@ -67,7 +72,7 @@ struct SharedT {
     uint8_t fse_sym[512];
     uint32_t seq_ll[SEQ_BATCH], seq_ml[SEQ_BATCH], seq_off[SEQ_BATCH];
     // pattern buffer for long overlapping matches: E[i] = period[i % off], i < off + 16 * threads
-    __attribute__((aligned(16))) uint8_t ebuf[EXP_OFF_MAX + 16 * 64 * NW + 64];
+    __attribute__((aligned(16))) uint8_t ebuf[(NW == 4 ? WIN_HIST + WIN_CAP : EXP_OFF_MAX + 16 * 64 * NW) + 64];
     // per-row / per-block state broadcast from lane 0
     int32_t err;
     uint32_t row;
@@ -80,7 +85,8 @@ struct SharedT {
     uint32_t sel[3], log_[3], valid[3];
     uint32_t nseq, batch_n;
     uint64_t src_pos, src_end;  // byte offsets inside the frame's blob
-    uint64_t out_pos, out_end;  // byte offsets inside the row's output
+    uint64_t out_pos, out_end;  // byte offsets inside the row's output (out_pos: flushed to HBM)
+    uint32_t win_n, hist_n;     // narrow variant: bytes waiting in the window's chunk part / valid history bytes in front of it
     uint32_t lit_pos;
     uint32_t rep[3];
     uint32_t has_cksum;
@@ -297,6 +303,96 @@ __device__ __forceinline__ void coop_match(uint8_t *dst, uint32_t off, uint64_t 
             if (all_waves && NWAVES > 1) __syncthreads(); else wave_mem_sync();
         }
     }
+}
+
+// ---------------------------------------------------------------------------------------------
+// LDS output window (wave 0).  W = S.ebuf; the chunk starts at W + WIN_HIST and stands for output
+// bytes [chunk_abs, chunk_abs + win_n); `hist_n` bytes in front of it are the output just before.
+// ---------------------------------------------------------------------------------------------
+// per-lane copy, 16 bytes at a time while they fit (never writes past n)
+__device__ __forceinline__ void lane_copy_g2l(uint8_t *d, const uint8_t *g, uint32_t n) {
+    uint32_t k = 0;
+    for (; k + 16 <= n; k += 16) {
+        uint4 v;
+        __builtin_memcpy(&v, g + k, 16);
+        __builtin_memcpy(d + k, &v, 16);
+    }
+    for (; k < n; k++) d[k] = g[k];
+}
+// forward copy inside LDS; valid for overlapping ranges when the distance is >= 16
+__device__ __forceinline__ void lane_copy_l2l(uint8_t *d, const uint8_t *s, uint32_t n) {
+    uint32_t k = 0;
+    for (; k + 16 <= n; k += 16) {
+        uint4 v;
+        __builtin_memcpy(&v, s + k, 16);
+        __builtin_memcpy(d + k, &v, 16);
+    }
+    for (; k < n; k++) d[k] = s[k];
+}
+
+// One sequence per lane (lanes with on == false idle): literals, then matches in dependency rounds — a
+// match is copied once every byte of its source is final, i.e. lies before the destination of the first
+// match still pending (the high-water mark); the first pending match is always ready (its own overlap is
+// a forward copy).  Text needs 1-3 rounds per 64 sequences.
+__device__ __forceinline__ void win_exec_group(uint8_t *W, const uint8_t *out, uint64_t chunk_abs, uint32_t hist_n, uint32_t lane,
+                                               bool on, uint32_t dpos, uint32_t ll, uint32_t ml, uint32_t off, const uint8_t *lit,
+                                               bool rle, uint8_t rle_byte) {
+    if (on && ll) {
+        uint8_t *d = W + dpos;
+        if (rle) for (uint32_t k = 0; k < ll; k++) d[k] = rle_byte;
+        else lane_copy_g2l(d, lit, ll);
+    }
+    const uint32_t mdst = dpos + ll;
+    const int32_t msrc = (int32_t)mdst - (int32_t)off;  // window coordinate of the match source (may lie before the history)
+    const int32_t lds_lo = (int32_t)WIN_HIST - (int32_t)hist_n;
+    bool pend = on && ml != 0;
+    for (;;) {
+        __builtin_amdgcn_wave_barrier();
+        const uint64_t pm = __ballot(pend);
+        if (!pm) break;
+        const uint32_t first = (uint32_t)__ffsll((long long)pm) - 1;
+        const uint32_t hwm = __shfl(mdst, first);
+        if (pend && (lane == first || msrc + (int32_t)ml <= (int32_t)hwm)) {
+            uint32_t k = 0;
+            if (msrc < lds_lo) {  // (part of) the source was flushed long ago: read it back from HBM
+                const uint32_t nf = (uint32_t)(lds_lo - msrc) < ml ? (uint32_t)(lds_lo - msrc) : ml;
+                const uint8_t *g = out + (chunk_abs - WIN_HIST) + (int64_t)msrc;
+                lane_copy_g2l(W + mdst, g, nf);
+                k = nf;
+            }
+            if (k < ml) {
+                uint8_t *d = W + mdst + k;
+                const uint8_t *sp = W + (msrc + (int32_t)k);
+                const uint32_t n = ml - k;
+                if (off >= 16 || off >= ml) lane_copy_l2l(d, sp, n);
+                else for (uint32_t i = 0; i < n; i++) d[i] = sp[i];  // short period: byte-serial extension
+            }
+            pend = false;
+        }
+    }
+}
+
+// chunk -> HBM, then keep the newest bytes as history.  Returns the new history length.
+__device__ __forceinline__ uint32_t win_flush(uint8_t *W, uint8_t *out, uint64_t chunk_abs, uint32_t win_n, uint32_t hist_n, uint32_t lane,
+                                             bool keep_history) {
+    if (win_n) coop_copy(out + chunk_abs, W + WIN_HIST, win_n, lane, 64);
+    uint32_t h = 0;
+    if (keep_history) {
+        h = hist_n + win_n < WIN_HIST ? hist_n + win_n : WIN_HIST;
+        const uint8_t *sp = W + WIN_HIST + win_n - h;
+        uint8_t *dp = W + WIN_HIST - h;
+        if (win_n)
+            for (uint32_t base = 0; base < h; base += 1024) {  // moves down by win_n: ascending 1 KiB steps, read then write
+                const uint32_t i = base + lane * 16;
+                uint4 v = make_uint4(0, 0, 0, 0);
+                if (i < h) __builtin_memcpy(&v, sp + i, 16);
+                __builtin_amdgcn_wave_barrier();
+                if (i < h) __builtin_memcpy(dp + i, &v, 16);
+                __builtin_amdgcn_wave_barrier();
+            }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the chunk has landed: later far matches of this wave may read it back
+    return h;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -564,7 +660,7 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES == 4 ? 4 : 1) void k_zstd_decod
         if (tid == 0) {
             int err = 0;
             uint64_t pos = 0;
-            S.out_pos = 0;
+            S.out_pos = 0; S.win_n = 0; S.hist_n = 0;
             S.huf_valid = 0; S.valid[0] = S.valid[1] = S.valid[2] = 0;
             S.rep[0] = 1; S.rep[1] = 4; S.rep[2] = 8;
             if (src_n < 5) err = E_TRUNC;
@@ -632,14 +728,14 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES == 4 ? 4 : 1) void k_zstd_decod
             if (btype == 0) {
                 coop_copy(out + S.out_pos, src + bpos, bsize, tid, NT);
                 __syncthreads();
-                if (tid == 0) { S.out_pos += bsize; S.src_pos += bsize; }
+                if (tid == 0) { S.out_pos += bsize; S.src_pos += bsize; S.hist_n = 0; }
                 __syncthreads();
                 continue;
             }
             if (btype == 1) {
                 coop_fill(out + S.out_pos, src[bpos], bsize, tid, NT);
                 __syncthreads();
-                if (tid == 0) { S.out_pos += bsize; S.src_pos += 1; }
+                if (tid == 0) { S.out_pos += bsize; S.src_pos += 1; S.hist_n = 0; }
                 __syncthreads();
                 continue;
             }
@@ -839,7 +935,7 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES == 4 ? 4 : 1) void k_zstd_decod
                     uint64_t produced = 0;
                     uint32_t lits = 0;
                     const uint32_t lit_room = uni(S.lit_len) - uni(S.lit_pos);
-                    const uint64_t abs0 = uni64(S.out_pos);
+                    const uint64_t abs0 = uni64(S.out_pos) + uni(S.win_n);
                     const uint64_t out_end = uni64(S.out_end);
                     const uint2 *const tl2 = reinterpret_cast<const uint2 *>(tl), *const to2 = reinterpret_cast<const uint2 *>(to),
                                 *const tm2 = reinterpret_cast<const uint2 *>(tm);
@@ -892,52 +988,189 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES == 4 ? 4 : 1) void k_zstd_decod
                 }
                 __syncthreads();
                 if (S.err) break;
-                // execute: wave 0 walks the batch in order; long copies are shared by all waves
-                {
-                    uint64_t opos = S.out_pos;
-                    uint32_t lpos = S.lit_pos;
-                    const bool rle_lits = S.lit_kind == 1;
-                    const uint8_t rle_byte = (uint8_t)S.lit_rle;
-                    for (uint32_t i = 0; i < bn; i++) {
-                        const uint32_t ll = S.seq_ll[i], ml = S.seq_ml[i], off = S.seq_off[i];
-                        if (ll) {
-                            const bool big = NWAVES > 1 && ll >= BIG_COPY;
-                            if (big) __syncthreads();
-                            if (big || wave0) {
-                                const uint32_t nt = big ? NT : 64;
-                                if (rle_lits) coop_fill(out + opos, rle_byte, ll, tid, nt);
-                                else coop_copy(out + opos, lit_ptr + lpos, ll, tid, nt);
+                if constexpr (NWAVES == 4) {
+                    // execute.  Every wave follows the same control flow (the decisions depend only on the batch in LDS
+                    // and on counters each wave mirrors in registers); wave 0 does the window work, all waves share the
+                    // long direct copies.
+                    {
+                        uint64_t opos = S.out_pos;
+                        uint32_t win_n = S.win_n, hist_n = S.hist_n, lpos = S.lit_pos;
+                        const bool rle_lits = S.lit_kind == 1;
+                        const uint8_t rle_byte = (uint8_t)S.lit_rle;
+                        const uint32_t lane = tid & 63;
+                        uint8_t *const W = S.ebuf;
+                        bool dirty = false;
+                        uint32_t si = 0;
+                        while (si < bn) {
+                            const uint32_t idx = si + lane;
+                            const bool v = idx < bn;
+                            const uint32_t ll = v ? S.seq_ll[idx] : 0, ml = v ? S.seq_ml[idx] : 0, off = v ? S.seq_off[idx] : 1;
+                            const uint32_t tot = ll + ml;
+                            const uint64_t bigm = __ballot(v && (tot > WIN_SEQ_MAX || ll > WIN_SEQ_MAX));
+                            const uint32_t nv = bn - si < 64 ? bn - si : 64;
+                            const uint32_t ncand = bigm ? (uint32_t)__ffsll((long long)bigm) - 1 : nv;
+                            if (ncand == 0) {
+                                // ---- one long sequence, straight to HBM (the window is emptied first) ----
+                                if (win_n) {
+                                    if (wave0) (void)win_flush(W, out, opos, win_n, hist_n, lane, false);
+                                    opos += win_n;
+                                    win_n = 0;
+                                    __syncthreads();
+                                }
+                                hist_n = 0;
+                                const uint32_t ll0 = S.seq_ll[si], ml0 = S.seq_ml[si], off0 = S.seq_off[si];
+                                if (ll0) {
+                                    const bool big = NWAVES > 1 && ll0 >= BIG_COPY;
+                                    if (big) __syncthreads();
+                                    if (big || wave0) {
+                                        const uint32_t nt = big ? NT : 64;
+                                        if (rle_lits) coop_fill(out + opos, rle_byte, ll0, tid, nt);
+                                        else coop_copy(out + opos, lit_ptr + lpos, ll0, tid, nt);
+                                    }
+                                    if (big) __syncthreads();
+                                    opos += ll0; lpos += ll0;
+                                }
+                                {
+                                    const bool big = NWAVES > 1 && ml0 >= BIG_COPY;
+                                    if (big) __syncthreads();
+                                    else if (wave0) wave_mem_sync();
+                                    if (big || wave0) coop_match<NWAVES>(out + opos, off0, ml0, tid, big, S.ebuf);
+                                    if (big) __syncthreads();
+                                    opos += ml0;
+                                }
+                                dirty = true;  // direct stores may still be in flight: whoever reads HBM back drains first
+                                si++;
+                                continue;
                             }
-                            if (big) __syncthreads();
-                            opos += ll; lpos += ll;
+                            // ---- up to 64 short sequences inside the window ----
+                            uint32_t end = lane < ncand ? tot : 0, lend = lane < ncand ? ll : 0;
+    #pragma unroll
+                            for (int d = 1; d < 64; d <<= 1) {
+                                const uint32_t y = __shfl_up(end, d), z = __shfl_up(lend, d);
+                                if (lane >= (uint32_t)d) { end += y; lend += z; }
+                            }
+                            uint32_t fit = (uint32_t)__popcll(__ballot(lane < ncand && end <= WIN_CAP - win_n));
+                            if (fit == 0) {  // chunk full: stream it out, keep the newest bytes as history
+                                uint32_t h = 0;
+                                if (wave0) h = win_flush(W, out, opos, win_n, hist_n, lane, true);
+                                (void)h;
+                                hist_n = hist_n + win_n < WIN_HIST ? hist_n + win_n : WIN_HIST;
+                                opos += win_n;
+                                win_n = 0;
+                                fit = (uint32_t)__popcll(__ballot(lane < ncand && end <= WIN_CAP));
+                            }
+                            if (dirty) {  // far matches / the history read-back below must see every direct store
+                                wave_mem_sync();
+                                __syncthreads();
+                                dirty = false;
+                            }
+                            const uint32_t want_h = opos < WIN_HIST ? (uint32_t)opos : WIN_HIST;
+                            if (win_n == 0 && hist_n < want_h) {
+                                // history lost to a direct copy / raw block: read the newest output back (it has landed:
+                                // every direct write above ends with a drain + barrier)
+                                if (wave0) {
+                                    coop_copy(W + WIN_HIST - want_h, out + opos - want_h, want_h, lane, 64);
+                                }
+                                hist_n = want_h;
+                            }
+                            if (wave0) {
+                                const bool on = lane < fit;
+                                win_exec_group(W, out, opos, hist_n, lane, on, WIN_HIST + win_n + (end - tot), ll, ml, off,
+                                               lit_ptr + lpos + (lend - ll), rle_lits, rle_byte);
+                            }
+                            win_n += __shfl(end, fit - 1);
+                            lpos += __shfl(lend, fit - 1);
+                            si += fit;
                         }
-                        {
-                            const bool big = NWAVES > 1 && ml >= BIG_COPY;
-                            if (big) __syncthreads();
-                            else if (wave0) wave_mem_sync();
-                            if (big || wave0) coop_match<NWAVES>(out + opos, off, ml, tid, big, S.ebuf);
-                            if (big) __syncthreads();
-                            opos += ml;
-                        }
+                        if (dirty) wave_mem_sync();  // with the barrier below: direct stores of this batch have landed
+                        __syncthreads();
+                        if (tid == 0) { S.out_pos = opos; S.win_n = win_n; S.hist_n = hist_n; S.lit_pos = lpos; }
                     }
-                    __syncthreads();
-                    if (tid == 0) { S.out_pos = opos; S.lit_pos = lpos; }
+                } else {
+                    // execute: wave 0 walks the batch in order; long copies are shared by all waves
+                    {
+                        uint64_t opos = S.out_pos;
+                        uint32_t lpos = S.lit_pos;
+                        const bool rle_lits = S.lit_kind == 1;
+                        const uint8_t rle_byte = (uint8_t)S.lit_rle;
+                        for (uint32_t i = 0; i < bn; i++) {
+                            const uint32_t ll = S.seq_ll[i], ml = S.seq_ml[i], off = S.seq_off[i];
+                            if (ll) {
+                                const bool big = NWAVES > 1 && ll >= BIG_COPY;
+                                if (big) __syncthreads();
+                                if (big || wave0) {
+                                    const uint32_t nt = big ? NT : 64;
+                                    if (rle_lits) coop_fill(out + opos, rle_byte, ll, tid, nt);
+                                    else coop_copy(out + opos, lit_ptr + lpos, ll, tid, nt);
+                                }
+                                if (big) __syncthreads();
+                                opos += ll; lpos += ll;
+                            }
+                            {
+                                const bool big = NWAVES > 1 && ml >= BIG_COPY;
+                                if (big) __syncthreads();
+                                else if (wave0) wave_mem_sync();
+                                if (big || wave0) coop_match<NWAVES>(out + opos, off, ml, tid, big, S.ebuf);
+                                if (big) __syncthreads();
+                                opos += ml;
+                            }
+                        }
+                        __syncthreads();
+                        if (tid == 0) { S.out_pos = opos; S.lit_pos = lpos; }
+                    }
                 }
                 seq_done += bn;
                 __syncthreads();
             }
             if (S.err) break;
-            // -- literals left after the last sequence --
-            {
-                const uint32_t rest = S.lit_len - S.lit_pos;
-                if (S.out_pos + rest > S.out_end) { if (tid == 0) S.err = E_CORRUPT; }
-                else if (rest) {
-                    if (S.lit_kind == 1) coop_fill(out + S.out_pos, (uint8_t)S.lit_rle, rest, tid, NT);
-                    else coop_copy(out + S.out_pos, lit_ptr + S.lit_pos, rest, tid, NT);
+            if constexpr (NWAVES == 4) {
+                // -- literals left after the last sequence, then the window goes out (history stays for the next block) --
+                if (S.lit_len != S.lit_pos || S.win_n != 0) {
+                    __syncthreads();
+                    const uint32_t rest = S.lit_len - S.lit_pos;
+                    const uint32_t win_n = S.win_n, hist_n = S.hist_n;
+                    const uint64_t opos = S.out_pos;
+                    const uint8_t *lit_ptr2 = S.lit_kind == 0 ? src + S.lit_src : lit_buf;
+                    if (opos + win_n + rest > S.out_end) { __syncthreads(); if (tid == 0) S.err = E_CORRUPT; }
+                    else {
+                        const bool in_win = rest <= WIN_CAP - win_n;
+                        uint32_t h = hist_n;
+                        if (wave0) {
+                            const uint32_t lane = tid & 63;
+                            if (in_win && rest) {
+                                uint8_t *d = S.ebuf + WIN_HIST + win_n;
+                                if (S.lit_kind == 1) for (uint32_t i = lane; i < rest; i += 64) d[i] = (uint8_t)S.lit_rle;
+                                else coop_copy(d, lit_ptr2 + S.lit_pos, rest, lane, 64);
+                            }
+                            h = win_flush(S.ebuf, out, opos, in_win ? win_n + rest : win_n, hist_n, lane, in_win);
+                        }
+                        __syncthreads();
+                        if (!in_win) {  // long tail: straight to HBM by everyone, history is read back on demand
+                            if (S.lit_kind == 1) coop_fill(out + opos + win_n, (uint8_t)S.lit_rle, rest, tid, NT);
+                            else coop_copy(out + opos + win_n, lit_ptr2 + S.lit_pos, rest, tid, NT);
+                            wave_mem_sync();
+                            h = 0;
+                        }
+                        __syncthreads();
+                        if (tid == 0) { S.out_pos = opos + win_n + rest; S.win_n = 0; S.hist_n = in_win ? h : 0; S.lit_pos += rest; }
+                    }
+                    __syncthreads();
                 }
-                __syncthreads();
-                if (tid == 0) S.out_pos += rest;
-                __syncthreads();
+        
+            } else {
+                // -- literals left after the last sequence --
+                {
+                    const uint32_t rest = S.lit_len - S.lit_pos;
+                    if (S.out_pos + rest > S.out_end) { if (tid == 0) S.err = E_CORRUPT; }
+                    else if (rest) {
+                        if (S.lit_kind == 1) coop_fill(out + S.out_pos, (uint8_t)S.lit_rle, rest, tid, NT);
+                        else coop_copy(out + S.out_pos, lit_ptr + S.lit_pos, rest, tid, NT);
+                    }
+                    __syncthreads();
+                    if (tid == 0) S.out_pos += rest;
+                    __syncthreads();
+                }
+        
             }
         }
         __syncthreads();  // every wave's output stores have landed (same CU)
