@@ -194,3 +194,51 @@ def test_frame_content_checksum_is_verified(gpu_ctx, oracle, gname, n):
     with pytest.raises(ZnippyError) as ei:
         gpu_ctx.decompress(bytes(bad))
     assert ei.value.code == E_CHECKSUM
+
+
+def test_block_items_and_their_fallbacks(gpu_ctx, oracle):
+    """Frames of >= 2 blocks are tried block by block (every 128 KiB block a work item) and fall back to the serial
+    decoder per frame.  One table holds: multi-block frames written by this library (independent blocks: the
+    fast path), libzstd frames (repeat offsets / Huffman: fallback), a library frame with a damaged block (error
+    surfaces through the fallback) — outputs and statuses must equal the oracle's."""
+    import torch
+    from znippy_amd import hip
+    rng = np.random.default_rng(3)
+    srcs = [gen.pseudo_text(700_000, seed=1), gen.binary(300_000), gen.text(1 << 20), gen.pseudo_text(400_000, seed=2),
+            gen.incompressible(4, 300_000), gen.pseudo_text(262_145, seed=5)]
+    own = [gpu_ctx.compress(x) for x in srcs]
+    for f, x in zip(own, srcs):
+        assert oracle.zstd_decompress(f) == x
+    frames = list(own) + [oracle.libzstd_compress(srcs[0], 19), oracle.libzstd_compress(srcs[2], 3)]
+    want = list(srcs) + [srcs[0], srcs[2]]
+    bad = bytearray(own[3])
+    bad[len(bad) // 2] ^= 0x5A                      # somewhere inside a middle block
+    frames.append(bytes(bad)); want.append(srcs[3])
+    lens = np.array([len(x) for x in want], np.uint64)
+    offs = np.concatenate([[0], np.cumsum(lens)[:-1]]).astype(np.uint64)
+    bo = np.concatenate([[0], np.cumsum([len(f) for f in frames])[:-1]]).astype(np.uint64)
+    bs = np.array([len(f) for f in frames], np.uint64)
+    blobs = torch.from_numpy(np.frombuffer(b"".join(frames) + bytes(64), np.uint8).copy()).cuda()
+    d_out = torch.zeros(int(lens.sum()) + 64, dtype=torch.uint8, device="cuda")
+    ck = np.stack([np.frombuffer(oracle.blake3(x), np.uint8) for x in want])
+    rt = hip.RowTable(gpu_ctx, bo, bs, lens, offs, None, ck)
+    counters, corrupt, status = rt.decode_verify(blobs, d_out)
+    out = d_out.cpu().numpy()
+    for i in range(len(frames) - 1):
+        assert status[i] == 0, i
+        assert out[int(offs[i]):int(offs[i] + lens[i])].tobytes() == want[i], i
+    # the damaged frame: the oracle either rejects it or decodes different bytes; the GPU must agree
+    try:
+        ob = oracle.zstd_decompress(bytes(bad))
+    except ValueError:
+        ob = None
+    i = len(frames) - 1
+    if ob is None or len(ob) != len(want[i]):
+        assert status[i] < 0
+        assert counters["decode_errors"] == 1
+    else:
+        assert status[i] == 0 and out[int(offs[i]):int(offs[i] + lens[i])].tobytes() == ob
+        assert list(corrupt) == ([i] if ob != want[i] else [])
+    # timing names tell which path ran
+    names = dict(gpu_ctx.kernel_times())
+    assert "zstd_decode_blocks" in names and "zstd_block_scan" in names

@@ -144,6 +144,10 @@ struct znippy_rows {
     bool wide_rows = false;       // big rows average >= 1 MiB: 1024-thread workgroups
     uint32_t *pending = nullptr;  // rows the fused kernel hands over (+ its counter)
     uint32_t *pending_count = nullptr;
+    // block items: compressed rows of >= 2 blocks are tried block by block first
+    uint32_t n_cand = 0, n_items = 0;
+    uint32_t *cand_row = nullptr, *cand_base = nullptr, *cand_nblocks = nullptr;
+    uint32_t *item_row = nullptr, *item_k = nullptr, *item_src = nullptr, *row_flag = nullptr;
     DevPlan plan;
 };
 
@@ -323,7 +327,8 @@ void znippy_rows_destroy(znippy_rows *r) {
     if (!r) return;
     (void)hipSetDevice(r->ctx->device);
     void *ptrs[] = {r->blob_off, r->blob_size, r->usize, r->out_off, r->compressed, r->checksum,
-                    r->status, r->digests, r->counters, r->corrupt, r->list_a, r->pending, r->pending_count};
+                    r->status, r->digests, r->counters, r->corrupt, r->list_a, r->pending, r->pending_count,
+                    r->cand_row, r->cand_base, r->cand_nblocks, r->item_row, r->item_k, r->item_src, r->row_flag};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     free_plan(r->plan);
@@ -376,14 +381,41 @@ int znippy_rows_create(znippy_ctx *ctx, const uint64_t *blob_offset, const uint6
         znippy_rows_destroy(r);
         return rc;
     }
-    std::vector<uint32_t> la;
-    for (uint32_t i = 0; i < n; i++)
-        if (comp[i] && uncompressed_size[row_begin + i] > 64 * 1024) la.push_back(i);
+    // compressed rows above 64 KiB: frames of >= 2 blocks (and < 4 GiB) are tried block by block (each block a work
+    // item), the others go straight to the general decoder
+    constexpr uint64_t BLK = 128 * 1024;
+    std::vector<uint32_t> la, cand_row, cand_base, cand_nb, item_row, item_k;
+    uint64_t big_bytes = 0, n_big = 0;
+    for (uint32_t i = 0; i < n; i++) {
+        const uint64_t us = uncompressed_size[row_begin + i];
+        if (!comp[i] || us <= 64 * 1024) continue;
+        big_bytes += us;
+        n_big++;
+        const uint64_t nb = (us + BLK - 1) / BLK;
+        if (nb >= 2 && us < 0xFFFFFFFFull && item_row.size() + nb < 0x7FFFFFFFull && !getenv("ZNIPPY_NO_BLOCK_ITEMS")) {
+            cand_row.push_back(i);
+            cand_base.push_back((uint32_t)item_row.size());
+            cand_nb.push_back((uint32_t)nb);
+            for (uint32_t k = 0; k < nb; k++) { item_row.push_back(i); item_k.push_back(k); }
+        } else la.push_back(i);
+    }
     r->n_list_a = (uint32_t)la.size();
-    {
-        uint64_t big_bytes = 0;
-        for (uint32_t i : la) big_bytes += uncompressed_size[row_begin + i];
-        r->wide_rows = !la.empty() && big_bytes / la.size() >= (1u << 20);
+    r->wide_rows = n_big && big_bytes / n_big >= (1u << 20);
+    r->n_cand = (uint32_t)cand_row.size();
+    r->n_items = (uint32_t)item_row.size();
+    if (r->n_cand) {
+        if ((rc = dev_upload(ctx, &r->cand_row, cand_row.data(), cand_row.size())) ||
+            (rc = dev_upload(ctx, &r->cand_base, cand_base.data(), cand_base.size())) ||
+            (rc = dev_upload(ctx, &r->cand_nblocks, cand_nb.data(), cand_nb.size())) ||
+            (rc = dev_upload(ctx, &r->item_row, item_row.data(), item_row.size())) ||
+            (rc = dev_upload(ctx, &r->item_k, item_k.data(), item_k.size()))) {
+            znippy_rows_destroy(r);
+            return rc;
+        }
+        if (hipMalloc(&r->item_src, 4 * (size_t)r->n_items) != hipSuccess || hipMalloc(&r->row_flag, std::max<size_t>(4 * (size_t)n, 16)) != hipSuccess) {
+            znippy_rows_destroy(r);
+            return ZNIPPY_E_NOMEM;
+        }
     }
     if ((rc = dev_upload(ctx, &r->list_a, la.data(), la.size()))) {
         znippy_rows_destroy(r);
@@ -445,7 +477,34 @@ int znippy_decode_verify_rows_async(znippy_ctx *ctx, znippy_rows *r, const void 
         launch_fused_small(f, s);
         ktime_end(ctx);
     }
-    // 2) general decoder: big compressed rows + whatever the fused kernel handed over
+    // 2a) block items: frames of >= 2 blocks, every block a work item (falls back to 2b per frame)
+    if (r->n_cand) {
+        BlockScanArgs b{};
+        b.cand_row = r->cand_row; b.cand_base = r->cand_base; b.cand_nblocks = r->cand_nblocks; b.n_cand = r->n_cand;
+        b.blobs = (const uint8_t *)d_blobs; b.blob_base = blob_base;
+        b.blob_off = r->blob_off; b.blob_size = r->blob_size; b.usize = r->usize; b.out_off = r->out_off; b.out_cap = out_cap;
+        b.item_src = r->item_src; b.row_flag = r->row_flag; b.status = r->status;
+        b.pending = r->pending; b.pending_count = r->pending_count;
+        ktime_begin(ctx, "zstd_block_scan");
+        launch_scan_blocks(b, s);
+        ktime_end(ctx);
+        DecodeArgs a{};
+        a.block_mode = 1;
+        a.item_row = r->item_row; a.item_k = r->item_k; a.item_src = r->item_src; a.n_items = r->n_items; a.row_flag = r->row_flag;
+        a.pending_count = r->pending_count;
+        a.blobs = (const uint8_t *)d_blobs;
+        a.blob_base = blob_base;
+        a.blob_off = r->blob_off; a.blob_size = r->blob_size; a.usize = r->usize; a.out_off = r->out_off;
+        a.compressed = r->compressed;
+        a.out = (uint8_t *)d_out; a.out_cap = out_cap;
+        a.status = r->status; a.n_rows = r->n; a.cursor = ctx->cursor + 4;
+        a.lit_scratch = ctx->lit_scratch;
+        ktime_begin(ctx, "zstd_decode_blocks");
+        launch_decode(a, std::min<int>(ctx->decode_grid, (int)r->n_items), false, s);
+        ktime_end(ctx);
+        launch_finish_blocks(b, s);
+    }
+    // 2b) general decoder: big compressed rows + whatever the fused kernel / the block path handed over
     if (r->n_compressed) {
         DecodeArgs a{};
         a.list_a = r->list_a; a.n_list_a = r->n_list_a;

@@ -70,6 +70,15 @@ struct DecodeArgs {
     uint32_t n_rows;
     uint32_t *cursor;    // atomic row cursor (the reference's AtomicUsize, decompress.rs:L104)
     uint8_t *lit_scratch;  // per resident workgroup: LIT_SCRATCH bytes
+    // Block items: frames of >= 2 blocks are first tried block by block, every block a work item of its own (a
+    // frame written by this library has self-contained 128 KiB blocks; any frame that turns out not to — repeat
+    // offsets, reused tables, a match reaching into an earlier block, another block size — is flagged and decoded
+    // serially afterwards).  block_mode != 0: the work list is the item table instead of rows.
+    int block_mode;
+    const uint32_t *item_row, *item_k;  // item -> row, block index inside the row's frame
+    const uint32_t *item_src;           // item -> offset of the block header inside the frame (0xFFFFFFFF: skip)
+    uint32_t n_items;
+    uint32_t *row_flag;                 // per row, != 0: decode this frame serially
     uint32_t *seq_scratch;
 };
 
@@ -95,5 +104,20 @@ void launch_verify(const uint32_t *digests, const uint8_t *checksum, const uint6
                    uint64_t *corrupt_rows, uint32_t corrupt_cap, hipStream_t s);
 int decode_grid_size(int device);
 void launch_decode(const DecodeArgs &a, int grid, bool wide, hipStream_t s);
+// block-item path: header scan of the candidate frames, then (after the block-mode decode) the per-row verdict
+struct BlockScanArgs {
+    const uint32_t *cand_row, *cand_base, *cand_nblocks;  // candidate -> row, first item, number of items
+    uint32_t n_cand;
+    const uint8_t *blobs;
+    uint64_t blob_base;
+    const uint64_t *blob_off, *blob_size, *usize, *out_off;
+    uint64_t out_cap;
+    uint32_t *item_src;
+    uint32_t *row_flag;
+    int32_t *status;
+    uint32_t *pending, *pending_count;
+};
+void launch_scan_blocks(const BlockScanArgs &a, hipStream_t s);
+void launch_finish_blocks(const BlockScanArgs &a, hipStream_t s);
 
 }  // namespace zn

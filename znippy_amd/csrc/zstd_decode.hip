@@ -75,7 +75,7 @@ struct SharedT {
     __attribute__((aligned(16))) uint8_t ebuf[(NW == 4 ? WIN_HIST + WIN_CAP : EXP_OFF_MAX + 16 * 64 * NW) + 64];
     // per-row / per-block state broadcast from lane 0
     int32_t err;
-    uint32_t row;
+    uint32_t row, skip;
     uint32_t blk_type, blk_size, blk_last;
     uint32_t lit_kind;  // 0 raw (pointer into src), 1 rle, 2 scratch
     uint32_t lit_len, lit_rle;
@@ -86,6 +86,7 @@ struct SharedT {
     uint32_t nseq, batch_n;
     uint64_t src_pos, src_end;  // byte offsets inside the frame's blob
     uint64_t out_pos, out_end;  // byte offsets inside the row's output (out_pos: flushed to HBM)
+    uint64_t blk_base;          // block items: first output byte of the item (matches may not reach in front of it)
     uint32_t win_n, hist_n;     // narrow variant: bytes waiting in the window's chunk part / valid history bytes in front of it
     uint32_t lit_pos;
     uint32_t rep[3];
@@ -630,8 +631,8 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES == 4 ? 4 : 1) void k_zstd_decod
     uint8_t *const lit_buf = a.lit_scratch + (size_t)blockIdx.x * LIT_SCRATCH_BYTES;
 
     // nothing routed here (every row was handled by the fused small-row kernel): leave at once
-    if (a.n_list_a == 0 && *a.pending_count == 0) return;
-    const uint32_t n_work = a.n_list_a + *a.pending_count;
+    if (!a.block_mode && a.n_list_a == 0 && *a.pending_count == 0) return;
+    const uint32_t n_work = a.block_mode ? a.n_items : a.n_list_a + *a.pending_count;
 
     // predefined tables, once per workgroup (lane 0; tiny)
     if (tid == 0) {
@@ -645,22 +646,47 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES == 4 ? 4 : 1) void k_zstd_decod
     __syncthreads();
 
     for (;;) {
-        if (tid == 0) S.row = atomicAdd(a.cursor, 1u);
+        if (tid == 0) {
+            const uint32_t w = atomicAdd(a.cursor, 1u);
+            S.row = w;
+            // block items: one thread decides for the workgroup whether the item is still worth decoding (the flag is
+            // raised concurrently by other workgroups, so it must be sampled once)
+            S.skip = a.block_mode && w < n_work && (a.item_src[w] == 0xFFFFFFFFu || a.row_flag[a.item_row[w]] != 0);
+        }
         __syncthreads();
         const uint32_t widx = S.row;
         if (widx >= n_work) break;
-        const uint32_t row = widx < a.n_list_a ? a.list_a[widx] : a.pending[widx - a.n_list_a];
+        uint32_t row, item_k = 0, item_src = 0;
+        if (a.block_mode) {
+            if (S.skip) { __syncthreads(); continue; }  // not eligible / the frame was already given up
+            row = a.item_row[widx]; item_k = a.item_k[widx]; item_src = a.item_src[widx];
+        } else row = widx < a.n_list_a ? a.list_a[widx] : a.pending[widx - a.n_list_a];
 
         const uint8_t *const src = a.blobs + (a.blob_off[row] - a.blob_base);
         const uint64_t src_n = a.blob_size[row];
         const uint8_t *const blob_end = src + src_n;
         uint8_t *const out = a.out + a.out_off[row];
 
-        // ---- frame header (lane 0) ----
-        if (tid == 0) {
+        // ---- frame header (lane 0); a block item starts at its block header with a clean entropy state ----
+        if (tid == 0 && a.block_mode) {
+            const uint64_t fcs = a.usize[row], o0 = (uint64_t)item_k * BLOCK_MAX;
+            S.out_pos = o0; S.win_n = 0; S.hist_n = 0;
+            S.blk_base = o0;
+            S.huf_valid = 0; S.valid[0] = S.valid[1] = S.valid[2] = 0;
+            S.rep[0] = 1; S.rep[1] = 4; S.rep[2] = 8;
+            S.has_cksum = 0;
+            S.content_size = fcs;
+            S.src_pos = item_src;
+            S.src_end = src_n;
+            S.out_end = o0 + BLOCK_MAX < fcs ? o0 + BLOCK_MAX : fcs;  // this block's share of the output, exactly
+            S.err = 0;
+            S.blk_last = 0;
+        }
+        if (tid == 0 && !a.block_mode) {
             int err = 0;
             uint64_t pos = 0;
             S.out_pos = 0; S.win_n = 0; S.hist_n = 0;
+            S.blk_base = 0;
             S.huf_valid = 0; S.valid[0] = S.valid[1] = S.valid[2] = 0;
             S.rep[0] = 1; S.rep[1] = 4; S.rep[2] = 8;
             if (src_n < 5) err = E_TRUNC;
@@ -712,7 +738,7 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES == 4 ? 4 : 1) void k_zstd_decod
                 if (p + 3 > S.src_end) S.err = E_TRUNC;
                 else {
                     uint32_t bh = src[p] | (src[p + 1] << 8) | (src[p + 2] << 16);
-                    S.blk_last = bh & 1; S.blk_type = (bh >> 1) & 3; S.blk_size = bh >> 3;
+                    S.blk_last = a.block_mode ? 1u : (bh & 1); S.blk_type = (bh >> 1) & 3; S.blk_size = bh >> 3;  // a block item ends after its block
                     S.src_pos = p + 3;
                     uint32_t need = S.blk_type == 1 ? 1 : S.blk_size;
                     if (S.blk_type == 3) S.err = E_CORRUPT;
@@ -935,7 +961,8 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES == 4 ? 4 : 1) void k_zstd_decod
                     uint64_t produced = 0;
                     uint32_t lits = 0;
                     const uint32_t lit_room = uni(S.lit_len) - uni(S.lit_pos);
-                    const uint64_t abs0 = uni64(S.out_pos) + uni(S.win_n);
+                    const uint64_t abs0 = uni64(S.out_pos) + uni(S.win_n) - uni64(S.blk_base);  // bytes a match may reach back over
+                    const bool no_rep = a.block_mode != 0;  // a repeat offset would depend on the block before
                     const uint64_t out_end = uni64(S.out_end);
                     const uint2 *const tl2 = reinterpret_cast<const uint2 *>(tl), *const to2 = reinterpret_cast<const uint2 *>(to),
                                 *const tm2 = reinterpret_cast<const uint2 *>(tm);
@@ -959,6 +986,7 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES == 4 ? 4 : 1) void k_zstd_decod
                         if (left < 0) { err = E_CORRUPT; break; }
                         uint32_t offset;
                         if (ov > 3) { offset = ov - 3; r2 = r1; r1 = r0; r0 = offset; }
+                        else if (no_rep) { err = E_CORRUPT; break; }
                         else {
                             uint32_t idx = ov - 1 + (ll == 0 ? 1 : 0);
                             if (idx == 0) offset = r0;
@@ -976,7 +1004,7 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES == 4 ? 4 : 1) void k_zstd_decod
                         if (lits > lit_room) { err = E_CORRUPT; break; }
                         if ((uint64_t)offset > abs0 + produced - ml) { err = E_CORRUPT; break; }
                     }
-                    if (!err && abs0 + produced > out_end) err = E_CORRUPT;
+                    if (!err && abs0 + uni64(S.blk_base) + produced > out_end) err = E_CORRUPT;
                     if (!err && seq_done + bn == nseq && left != 0) err = E_CORRUPT;
                     if (lane0) {
                         S.bs_pos = left;
@@ -1176,7 +1204,7 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES == 4 ? 4 : 1) void k_zstd_decod
         __syncthreads();  // every wave's output stores have landed (same CU)
         {
             int err = S.err;
-            if (!err && S.out_pos != S.content_size) err = E_CORRUPT;
+            if (!err && S.out_pos != (a.block_mode ? S.out_end : S.content_size)) err = E_CORRUPT;
             if (!err && S.has_cksum) {
                 if (S.src_pos + 4 > S.src_end) err = E_TRUNC;
                 else if (wave0) {  // frame content checksum: low 32 bits of XXH64(content)
@@ -1186,10 +1214,79 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES == 4 ? 4 : 1) void k_zstd_decod
                     if ((uint32_t)h != want) err = -7;  // ZNIPPY_E_CHECKSUM
                 }
             }
-            if (tid == 0) a.status[row] = err ? err : 2;  // 2 = decoded here, to be hashed by the second pass
+            if (tid == 0) {
+                if (a.block_mode) { if (err) atomicOr(&a.row_flag[row], 1u); }  // any trouble: the serial pass decides
+                else a.status[row] = err ? err : 2;  // 2 = decoded here, to be hashed by the second pass
+            }
         }
         __syncthreads();
     }
+}
+
+// ---------------------------------------------------------------------------------------------
+// block items: header scan (one thread per candidate frame) and the per-row verdict afterwards
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_scan_blocks(BlockScanArgs a) {
+    const uint32_t c = blockIdx.x * 64 + threadIdx.x;
+    if (c >= a.n_cand) return;
+    const uint32_t row = a.cand_row[c], base = a.cand_base[c], nb = a.cand_nblocks[c];
+    const uint8_t *src = a.blobs + (a.blob_off[row] - a.blob_base);
+    const uint64_t n = a.blob_size[row], fcs_want = a.usize[row];
+    bool ok = n >= 6 && (src[0] | (src[1] << 8) | (src[2] << 16) | ((uint32_t)src[3] << 24)) == 0xFD2FB528u;
+    uint64_t pos = 5;
+    if (ok) {
+        const uint32_t fhd = src[4];
+        const uint32_t fcs_flag = fhd >> 6, single = (fhd >> 5) & 1, did_flag = fhd & 3;
+        const uint32_t fcs_bytes = fcs_flag == 0 ? single : (1u << fcs_flag);
+        ok = !(fhd & 8) && !((fhd >> 2) & 1) && did_flag == 0 && fcs_bytes != 0;  // no checksum trailer, no dictionary
+        if (ok) {
+            if (!single) pos++;
+            ok = pos + fcs_bytes <= n;
+            uint64_t fcs = 0;
+            for (uint32_t i = 0; ok && i < fcs_bytes; i++) fcs |= (uint64_t)src[pos + i] << (8 * i);
+            if (fcs_bytes == 2) fcs += 256;
+            pos += fcs_bytes;
+            ok = ok && fcs == fcs_want && a.out_off[row] + fcs <= a.out_cap;  // anything odd: the serial pass reports it
+        }
+    }
+    uint32_t k = 0;
+    bool last = false;
+    while (ok && !last) {
+        if (k >= nb || pos + 3 > n) { ok = false; break; }
+        const uint32_t bh = src[pos] | (src[pos + 1] << 8) | (src[pos + 2] << 16);
+        const uint32_t type = (bh >> 1) & 3, size = bh >> 3;
+        const uint64_t o0 = (uint64_t)k * BLOCK_MAX;
+        const uint64_t want = o0 + BLOCK_MAX < fcs_want ? BLOCK_MAX : fcs_want - o0;
+        last = bh & 1;
+        if (type == 3 || (type != 2 && size != want)) { ok = false; break; }  // raw / RLE blocks carry their size
+        // the first block gives the frame's style away: Huffman-coded literals mean an encoder that also leans on
+        // repeat offsets and reused tables (libzstd) — such a frame would only waste the speculative pass
+        if (k == 0 && type == 2 && (pos + 3 >= n || (src[pos + 3] & 3) >= 2)) { ok = false; break; }
+        a.item_src[base + k] = (uint32_t)pos;
+        pos += 3 + (type == 1 ? 1 : size);
+        k++;
+    }
+    ok = ok && k == nb && pos == n;  // the expected number of blocks, nothing behind the last one
+    if (!ok)
+        for (uint32_t i = 0; i < nb; i++) a.item_src[base + i] = 0xFFFFFFFFu;
+    a.row_flag[row] = ok ? 0u : 1u;
+}
+
+__global__ __launch_bounds__(64) void k_finish_blocks(BlockScanArgs a) {
+    const uint32_t c = blockIdx.x * 64 + threadIdx.x;
+    if (c >= a.n_cand) return;
+    const uint32_t row = a.cand_row[c];
+    if (a.row_flag[row]) {
+        a.status[row] = 1;  // handed to the general decoder, like a row the fused kernel gave up on
+        a.pending[atomicAdd(a.pending_count, 1u)] = row;
+    } else a.status[row] = 2;
+}
+
+void launch_scan_blocks(const BlockScanArgs &a, hipStream_t s) {
+    if (a.n_cand) hipLaunchKernelGGL(k_scan_blocks, dim3((a.n_cand + 63) / 64), dim3(64), 0, s, a);
+}
+void launch_finish_blocks(const BlockScanArgs &a, hipStream_t s) {
+    if (a.n_cand) hipLaunchKernelGGL(k_finish_blocks, dim3((a.n_cand + 63) / 64), dim3(64), 0, s, a);
 }
 
 int decode_grid_size(int device) {

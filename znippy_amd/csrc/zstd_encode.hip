@@ -321,11 +321,10 @@ __global__ __launch_bounds__(64) void k_zstd_encode(EncodeArgs a) {
             for (uint32_t i = lane; i < HASH_SIZE / 8; i += 64) t4[i] = ones;
         }
         __syncthreads();
-        // Blocks after the first are seeded with the 64 bytes in front of them (positions 0..PRE-1 of the
-        // shifted coordinate q = pos + PRE are hashed but never emitted), so a match can reach back into
-        // the previous block — legal inside one frame's window — and periodic data costs ~12 bytes per
-        // block instead of a fresh 64-byte literal run.
-        const uint32_t PRE = it.block ? 64u : 0u;
+        // Every block is self-contained: no match reaches in front of the block and no repeat-offset code is
+        // used, so the blocks of a frame can be decoded independently (zstd_decode.hip, block items).  PRE > 0
+        // would seed the block with the bytes in front of it (saves one literal run per block on periodic data).
+        constexpr uint32_t PRE = 0;
         const uint8_t *const inb = in - PRE;
         const uint32_t nq = n + PRE;
         uint32_t nseq = 0, lit_total = 0;
