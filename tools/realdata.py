@@ -45,6 +45,11 @@ def run(kind, cap):
         ts.append(time.perf_counter() - t0)
     enc = {k: (v.copy() if hasattr(v, "copy") else v) for k, v in enc.items()}
     gpu_bytes = int(enc["blob_size"].sum())
+    # independent check: libzstd decodes this encoder's frames (largest rounds + a sample)
+    hb = d_blob.cpu().numpy()
+    for i in sorted(set(np.argsort(lens)[-6:].tolist() + list(range(0, len(ents), max(1, len(ents) // 40))))):
+        f = hb[int(enc["blob_offset"][i]):int(enc["blob_offset"][i] + enc["blob_size"][i])].tobytes()
+        assert O.libzstd_decompress(f, max(int(lens[i]), 1)) == ents[i], f"libzstd disagrees on round {i}"
     print(f"[{kind}] {len(ents)} rounds, {total/1e6:.1f} MB; median round {int(np.median(lens))} B")
     print(f"[{kind}] GPU encode+hash: {min(ts)*1e3:.2f} ms ({total/2**20/min(ts):.0f} MB/s), ratio {gpu_bytes/total:.3f}", dict(ctx.kernel_times()))
     res = {}

@@ -170,6 +170,7 @@ struct znippy_rounds {
     // order_*: item indices of each share; NULL when the whole plan is of one kind.
     uint32_t *order_small = nullptr, *order_wide = nullptr;
     uint32_t n_small = 0, n_wide = 0;
+    uint32_t *retry_list = nullptr, *retry_count = nullptr;  // small blocks the small variant hands to the wide one
     uint64_t prov_bytes = 0;
     uint32_t *piece_len = nullptr, *piece_len_init = nullptr;
     uint64_t *piece_start = nullptr, *local_excl = nullptr, *block_tot = nullptr;
@@ -586,7 +587,7 @@ void znippy_rounds_destroy(znippy_rounds *r) {
     if (!r) return;
     (void)hipSetDevice(r->ctx->device);
     void *ptrs[] = {r->src_off, r->len, r->skip, r->res, r->items, r->piece_len, r->piece_len_init,
-                    r->piece_start, r->local_excl, r->block_tot, r->first_item, r->stored, r->order_small, r->order_wide};
+                    r->piece_start, r->local_excl, r->block_tot, r->first_item, r->stored, r->order_small, r->order_wide, r->retry_list, r->retry_count};
     if (r->h_res) (void)hipHostFree(r->h_res);
     if (r->h_stored) (void)hipHostFree(r->h_stored);
     for (void *p : ptrs)
@@ -666,6 +667,10 @@ int znippy_rounds_create(znippy_ctx *ctx, const uint64_t *src_offset, const uint
         (rc = dev_upload(ctx, &r->order_wide, ord_wide.data(), ord_wide.size()))) {
         znippy_rounds_destroy(r);
         return rc;
+    }
+    if (hipMalloc(&r->retry_list, std::max<size_t>(4 * (size_t)r->n_small, 16)) != hipSuccess || hipMalloc(&r->retry_count, 64) != hipSuccess) {
+        znippy_rounds_destroy(r);
+        return ZNIPPY_E_NOMEM;
     }
     const size_t ni = std::max<size_t>(r->n_items, 1), nsb = (ni + 255) / 256;
     if ((rc = dev_upload(ctx, &r->first_item, first_item.data(), first_item.size())) ||
@@ -805,6 +810,7 @@ extern "C" int znippy_encode_hash_rounds_async(znippy_ctx *ctx, znippy_rounds *r
     HIPCHK(ctx, hipMemsetAsync(r->res, 0, 16 + 16 * (size_t)r->n, s));  // total, overflow, blob_offset, blob_size
     r->h_valid = false;
     HIPCHK(ctx, hipMemsetAsync(ctx->cursor, 0, 64, s));
+    HIPCHK(ctx, hipMemsetAsync(r->retry_count, 0, 4, s));
     EncodeArgs a{};
     a.items = r->items;
     a.src = (const uint8_t *)d_src; a.src_off = r->src_off; a.len = r->len;
@@ -818,7 +824,15 @@ extern "C" int znippy_encode_hash_rounds_async(znippy_ctx *ctx, znippy_rounds *r
         a.cursor = ctx->cursor + (wide ? 8 : 0);
         const int g = wide ? ctx->encode_grid : ctx->encode_grid_small;
         a.batch = std::max<uint32_t>(1, std::min<uint32_t>(16, a.n_items / (uint32_t)(g * 2)));
+        if (!wide) { a.retry_list = r->retry_list; a.retry_count = r->retry_count; }
         launch_encode(a, std::min<int>(g, (int)a.n_items), !wide, s);
+    }
+    if (r->n_small) {  // second wide launch: whatever the small variant handed over (count on the device)
+        a.order = r->retry_list; a.n_items = r->n_small; a.n_items_dev = r->retry_count;
+        a.retry_list = nullptr; a.retry_count = nullptr;
+        a.cursor = ctx->cursor + 12;
+        a.batch = 1;
+        launch_encode(a, std::min<int>(ctx->encode_grid, (int)r->n_small), false, s);
     }
     ktime_end(ctx);
     // checksum over the ORIGINAL bytes (stream_packer.rs:L219): VALU-bound, submitted to the

@@ -34,12 +34,16 @@ struct EncItem {
     uint64_t prov;
 };
 
-inline uint64_t enc_slot_bytes(uint32_t n) { return ((HDR_ROOM + 16 + (uint64_t)n + (n >> 2) + 64) + 15) & ~15ull; }
+// provisional slot of one block: literals + sequences section, plus room behind the raw literals where the wide
+// variant stages its Huffman streams before moving them in front (any block can end up in the wide variant)
+inline uint64_t enc_slot_bytes(uint32_t n) { return ((HDR_ROOM + 16 + 2ull * n + (n >> 2) + 64) + 15) & ~15ull; }
 
 struct EncodeArgs {
     const EncItem *items;
     const uint32_t *order;  // optional: indices into items[] this launch works through (NULL = 0..n_items-1)
     uint32_t n_items;       // entries in order[] (or in items[])
+    const uint32_t *n_items_dev;  // optional: the count is read from the device instead (retry launch)
+    uint32_t *retry_list, *retry_count;  // small variant: blocks that ran out of sequence budget go here, for the wide variant
     uint32_t *cursor;
     uint32_t batch;  // items per cursor dequeue
     const uint8_t *src;

@@ -1259,9 +1259,34 @@ __global__ __launch_bounds__(64) void k_scan_blocks(BlockScanArgs a) {
         const uint64_t want = o0 + BLOCK_MAX < fcs_want ? BLOCK_MAX : fcs_want - o0;
         last = bh & 1;
         if (type == 3 || (type != 2 && size != want)) { ok = false; break; }  // raw / RLE blocks carry their size
-        // the first block gives the frame's style away: Huffman-coded literals mean an encoder that also leans on
-        // repeat offsets and reused tables (libzstd) — such a frame would only waste the speculative pass
-        if (k == 0 && type == 2 && (pos + 3 >= n || (src[pos + 3] & 3) >= 2)) { ok = false; break; }
+        // the first block gives the frame's style away: anything but predefined sequence tables means an encoder
+        // that also leans on repeat offsets and reused tables (libzstd) — such a frame would only waste the
+        // speculative pass
+        if (k == 0 && type == 2) {
+            const uint64_t b = pos + 3, bend = b + size;
+            bool style = bend <= n && size >= 2;
+            uint64_t q = b;
+            if (style) {
+                const uint32_t b0 = src[q], lt = b0 & 3, sf = (b0 >> 2) & 3;
+                uint64_t h = 0;
+                for (uint32_t i = 0; i < 5 && q + i < bend; i++) h |= (uint64_t)src[q + i] << (8 * i);
+                if (lt == 3) style = false;  // treeless: needs the previous block's tree
+                else if (lt <= 1) {
+                    const uint32_t lh = (sf & 1) == 0 ? 1 : (sf == 1 ? 2 : 3);
+                    const uint32_t regen = (uint32_t)((sf & 1) == 0 ? (h & 0xFF) >> 3 : (sf == 1 ? (h & 0xFFFF) >> 4 : (h & 0xFFFFFF) >> 4));
+                    q += lh + (lt == 0 ? regen : 1);
+                } else {
+                    const uint32_t lh = sf <= 1 ? 3 : (sf == 2 ? 4 : 5), nbits = sf <= 1 ? 10 : (sf == 2 ? 14 : 18);
+                    q += lh + (uint32_t)((h >> (4 + nbits)) & ((1u << nbits) - 1));
+                }
+            }
+            if (style && q < bend) {
+                const uint32_t s0 = src[q];
+                const uint32_t hl = s0 == 0 ? 0 : (s0 < 128 ? 1 : (s0 < 255 ? 2 : 3));
+                if (hl && (q + hl >= bend || src[q + hl] != 0)) style = false;  // modes byte: all Predefined
+            } else style = false;
+            if (!style) { ok = false; break; }
+        }
         a.item_src[base + k] = (uint32_t)pos;
         pos += 3 + (type == 1 ? 1 : size);
         k++;

@@ -248,6 +248,206 @@ __device__ __noinline__ uint8_t *encode_sequences(SH &S, const uint32_t *seqs, u
     return p + ((bitpos + 18 + 7) >> 3);
 }
 
+// Huffman-coded literals section (RFC 8878 §4.2.1) for the wide variant, built by the whole wave:
+//   histogram (LDS atomics) -> code lengths <= 11 (Shannon lengths, then greedy repair until the Kraft sum is
+//   exactly 1: lengthen the rarest symbols while over-subscribed, shorten the most frequent ones that fit the gap)
+//   -> canonical codes in the decoder's order (weight ascending, symbol ascending) -> direct 4-bit weight
+//   description -> 1 or 4 backward bitstreams, 64 symbols per step (code lengths scanned into bit positions,
+//   codes OR-ed into an LDS window, full dwords streamed out).
+// The streams are first written to `tmp` (behind the raw literals) and then moved in front of them.  Returns the
+// size of the section written at `dst` (header included), or 0 to keep raw literals: alphabet beyond 128 symbols
+// (would need FSE-compressed weights), a single symbol, or no gain.
+constexpr uint32_t HUF_MIN_LITS = 256, HUF_MAX_BITS = 11;
+template <class SH>
+__device__ __forceinline__ uint32_t huf_literals(SH &S, const uint8_t *lits, uint32_t n, uint8_t *tmp, uint8_t *dst, uint32_t lane) {
+    uint32_t *const T = reinterpret_cast<uint32_t *>(S.table);  // the hash table is dead: hist | codes | bit window
+    uint32_t *const hist = T, *const codes = T + 256, *const win = T + 512;
+    for (uint32_t i = lane; i < 512 + 64; i += 64) T[i] = 0;
+    __builtin_amdgcn_wave_barrier();
+    // histogram in two stages: the first 4 KiB decide whether the alphabet can fit the direct weight form at all
+    // (binary / incompressible literals leave here after 16 steps instead of 512)
+    for (uint32_t stage = 0; stage < 2; stage++) {
+        const uint32_t lo = stage ? 4096u : 0u, hi = stage ? n : (n < 4096u ? n : 4096u);
+        for (uint32_t i = lo + lane * 4; i < hi; i += 256) {
+            if (i + 4 <= hi) {
+                const uint32_t v = ld32(lits + i);
+                atomicAdd(&hist[v & 0xFF], 1u); atomicAdd(&hist[(v >> 8) & 0xFF], 1u);
+                atomicAdd(&hist[(v >> 16) & 0xFF], 1u); atomicAdd(&hist[v >> 24], 1u);
+            } else
+                for (uint32_t k = i; k < hi; k++) atomicAdd(&hist[lits[k]], 1u);
+        }
+        __builtin_amdgcn_wave_barrier();
+        // anything at or above 128 rules the direct weight form out
+        if (__ballot((hist[lane + 128] | hist[lane + 192]) != 0)) return 0;
+    }
+    // lane owns symbols lane and lane + 64
+    const uint32_t c0 = hist[lane], c1 = hist[lane + 64];
+    const uint64_t p0 = __ballot(c0 != 0), p1 = __ballot(c1 != 0);
+    const uint32_t nsym = (uint32_t)(__popcll(p0) + __popcll(p1));
+    if (nsym < 2) return 0;
+    const uint32_t last = p1 ? 64 + (63 - (uint32_t)__clzll(p1)) : 63 - (uint32_t)__clzll(p0);  // highest present symbol
+    auto shannon = [&](uint32_t c) -> uint32_t {
+        if (!c) return 0;
+        uint32_t l = 1;
+        while (l < HUF_MAX_BITS && ((uint64_t)c << l) < n) l++;
+        return l;
+    };
+    uint32_t l0 = shannon(c0), l1 = shannon(c1);
+    auto wsum = [&](uint32_t v) -> uint32_t {
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
+        return v;
+    };
+    auto wmin = [&](uint32_t v) -> uint32_t {
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) { const uint32_t o = __shfl_xor(v, d); v = o < v ? o : v; }
+        return v;
+    };
+    auto wmax = [&](uint32_t v) -> uint32_t {
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) { const uint32_t o = __shfl_xor(v, d); v = o > v ? o : v; }
+        return v;
+    };
+    const uint32_t FULL = 1u << HUF_MAX_BITS;
+    uint32_t K = wsum((l0 ? FULL >> l0 : 0) + (l1 ? FULL >> l1 : 0));
+    // over-subscribed (only through the 11-bit clamp): lengthen the rarest symbol that still can be
+    for (uint32_t guard = 0; K > FULL && guard < 4096; guard++) {
+        const uint32_t k0 = (l0 && l0 < HUF_MAX_BITS) ? (c0 << 8) | lane : 0xFFFFFFFFu;
+        const uint32_t k1 = (l1 && l1 < HUF_MAX_BITS) ? (c1 << 8) | (lane + 64) : 0xFFFFFFFFu;
+        const uint32_t best = wmin(k0 < k1 ? k0 : k1);
+        if (best == 0xFFFFFFFFu) return 0;
+        const uint32_t sym = best & 0xFF;
+        if (sym == lane) { K -= 0; l0++; }
+        if (sym == lane + 64) l1++;
+        K = wsum((l0 ? FULL >> l0 : 0) + (l1 ? FULL >> l1 : 0));
+    }
+    if (K > FULL) return 0;
+    // under-subscribed: shorten the most frequent symbol whose gain still fits the gap
+    for (uint32_t guard = 0; K < FULL && guard < 4096; guard++) {
+        const uint32_t gap = FULL - K;
+        const uint32_t k0 = (l0 > 1 && (FULL >> l0) <= gap) ? (c0 << 8) | lane : 0;
+        const uint32_t k1 = (l1 > 1 && (FULL >> l1) <= gap) ? (c1 << 8) | (lane + 64) : 0;
+        const uint32_t best = wmax(k0 > k1 ? k0 : k1);
+        if (!best) return 0;
+        const uint32_t sym = best & 0xFF;
+        if (sym == lane && k0 == best) l0--;
+        else if (sym == lane + 64 && k1 == best) l1--;
+        K = wsum((l0 ? FULL >> l0 : 0) + (l1 ? FULL >> l1 : 0));
+    }
+    if (K != FULL) return 0;
+    const uint32_t L = wmax(l0 > l1 ? l0 : l1);  // table log; weight = L + 1 - length
+    const uint32_t w0 = l0 ? L + 1 - l0 : 0, w1 = l1 ? L + 1 - l1 : 0;
+    // payload bits, known before a single bit is written
+    const uint32_t pay_bits = wsum(c0 * l0 + c1 * l1);
+    const uint32_t nstreams = n < 1024 ? 1u : 4u;
+    const uint32_t tree_bytes = 1 + (last + 1) / 2;
+    const uint32_t est = tree_bytes + (nstreams == 4 ? 6u : 0u) + (pay_bits + 7) / 8 + nstreams;  // + end marks
+    if (est + 5 + (n >> 6) >= n) return 0;  // not worth a Huffman stage on the decode side
+    // canonical codes: positions in the 2^L table by (weight, symbol) order; code = position >> (weight - 1)
+    uint32_t base = 0, code0 = 0, code1 = 0;
+    const uint64_t below = lane ? (~0ull >> (64 - lane)) : 0ull;
+    for (uint32_t w = 1; w <= L; w++) {
+        const uint64_t m0 = __ballot(w0 == w), m1 = __ballot(w1 == w);
+        const uint32_t n0 = (uint32_t)__popcll(m0), n1 = (uint32_t)__popcll(m1);
+        if (w0 == w) code0 = (base >> (w - 1)) + (uint32_t)__popcll(m0 & below);
+        if (w1 == w) code1 = (base >> (w - 1)) + n0 + (uint32_t)__popcll(m1 & below);
+        base += (n0 + n1) << (w - 1);
+    }
+    codes[lane] = code0 | (l0 << 16);
+    codes[lane + 64] = code1 | (l1 << 16);
+    __builtin_amdgcn_wave_barrier();
+    // streams into tmp
+    const uint32_t seg = (n + 3) / 4;
+    uint32_t ssz[4] = {0, 0, 0, 0};
+    uint8_t *q = tmp;
+    for (uint32_t st = 0; st < nstreams; st++) {
+        const uint32_t a = nstreams == 1 ? 0 : st * seg;
+        const uint32_t b = nstreams == 1 ? n : (st == 3 ? n : a + seg);
+        uint8_t *const q0 = q;
+        uint32_t bitpos = 0;
+        for (uint32_t e0 = 0; e0 < b - a; e0 += 64) {
+            const uint32_t idx = e0 + lane;
+            uint32_t cd = 0, ln = 0;
+            if (idx < b - a) {
+                const uint32_t cw = codes[lits[b - 1 - idx]];  // last symbol first
+                cd = cw & 0xFFFF; ln = cw >> 16;
+            }
+            uint32_t inc = ln;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const uint32_t y = __shfl_up(inc, d);
+                if (lane >= (uint32_t)d) inc += y;
+            }
+            const uint32_t pos = bitpos + inc - ln;
+            if (ln) {
+                const uint64_t x = (uint64_t)cd << (pos & 31);
+                atomicOr(&win[pos >> 5], (uint32_t)x);
+                if (x >> 32) atomicOr(&win[(pos >> 5) + 1], (uint32_t)(x >> 32));
+            }
+            bitpos = suni(bitpos + __shfl(inc, 63));
+            __builtin_amdgcn_wave_barrier();
+            const uint32_t ndw = bitpos >> 5;
+            if (lane < ndw) {
+                const uint32_t w = win[lane];
+                __builtin_memcpy(q + 4 * lane, &w, 4);
+            }
+            const uint32_t keep = win[ndw];
+            __builtin_amdgcn_wave_barrier();
+            if (lane <= ndw) win[lane] = 0;
+            __builtin_amdgcn_wave_barrier();
+            if (lane == 0) win[0] = keep;
+            __builtin_amdgcn_wave_barrier();
+            q += 4 * ndw;
+            bitpos &= 31;
+        }
+        // closing bit, remaining bytes
+        const uint32_t tail_bits = bitpos + 1, tail_bytes = (tail_bits + 7) >> 3;
+        if (lane == 0) {
+            const uint64_t acc = (uint64_t)win[0] | (1ull << bitpos);
+            for (uint32_t k = 0; k < tail_bytes; k++) q[k] = (uint8_t)(acc >> (8 * k));
+            win[0] = 0;
+        }
+        __builtin_amdgcn_wave_barrier();
+        q += tail_bytes;
+        ssz[st] = (uint32_t)(q - q0);
+    }
+    const uint32_t streams_bytes = (uint32_t)(q - tmp);
+    const uint32_t comp = tree_bytes + (nstreams == 4 ? 6u : 0u) + streams_bytes;
+    // size_format: 0 = 1 stream, 10-bit sizes; 2 = 4 streams, 14-bit; 3 = 4 streams, 18-bit
+    uint32_t sf, hdr;
+    if (nstreams == 1) { sf = 0; hdr = 3; if (comp > 1023) return 0; }
+    else if (n <= 16383 && comp <= 16383) { sf = 2; hdr = 4; }
+    else { sf = 3; hdr = 5; }
+    if (hdr + comp + (n >> 6) >= 3 + n || (nstreams == 4 && (ssz[0] > 65535 || ssz[1] > 65535 || ssz[2] > 65535))) return 0;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the streams in tmp have landed before they are moved
+    if (lane == 0) {
+        const uint32_t nb = sf == 0 ? 10u : (sf == 2 ? 14u : 18u);
+        const uint64_t h = 2ull | ((uint64_t)sf << 2) | ((uint64_t)n << 4) | ((uint64_t)comp << (4 + nb));
+        for (uint32_t k = 0; k < hdr; k++) dst[k] = (uint8_t)(h >> (8 * k));
+        dst[hdr] = (uint8_t)(127 + last);  // direct weights for symbols 0 .. last-1, the last one is implied
+    }
+    {
+        // weight nibbles: byte i = weight[2i] << 4 | weight[2i+1]
+        const uint32_t nbytes = (last + 1) / 2;
+        for (uint32_t i = lane; i < nbytes; i += 64) {
+            const uint32_t la = codes[2 * i] >> 16, lb = (2 * i + 1 < last) ? codes[2 * i + 1] >> 16 : 0;
+            const uint32_t wa = la ? L + 1 - la : 0, wb = lb ? L + 1 - lb : 0;
+            dst[hdr + 1 + i] = (uint8_t)((wa << 4) | wb);
+        }
+    }
+    uint8_t *d = dst + hdr + tree_bytes;
+    if (nstreams == 4) {
+        if (lane == 0) {
+            d[0] = (uint8_t)ssz[0]; d[1] = (uint8_t)(ssz[0] >> 8);
+            d[2] = (uint8_t)ssz[1]; d[3] = (uint8_t)(ssz[1] >> 8);
+            d[4] = (uint8_t)ssz[2]; d[5] = (uint8_t)(ssz[2] >> 8);
+        }
+        d += 6;
+    }
+    wave_copy(d, tmp, streams_bytes, lane);  // moves down over the raw literals: ranges do not overlap (comp < n)
+    return hdr + comp;
+}
+
 // One wave encodes one block item pulled from the atomic cursor.  HASH_LOG 11 (4 KiB table, more
 // resident waves) serves batches of small rounds, 13 serves 128 KiB blocks.
 template <uint32_t HASH_LOG>
@@ -256,6 +456,7 @@ __global__ __launch_bounds__(64) void k_zstd_encode(EncodeArgs a) {
     __shared__ __attribute__((aligned(16))) EncShared<HASH_LOG> S;
     __shared__ uint32_t s_item, s_raw;
     const uint32_t lane = threadIdx.x;
+    if (a.n_items_dev && *a.n_items_dev == 0) return;  // retry launch with nothing handed over (periodic data)
     {
         const uint32_t *g = reinterpret_cast<const uint32_t *>(a.tabs);
         uint32_t *l = reinterpret_cast<uint32_t *>(&S.tabs);
@@ -269,6 +470,7 @@ __global__ __launch_bounds__(64) void k_zstd_encode(EncodeArgs a) {
     uint32_t next = 0, lim = 0, first = 0;
     // descriptors of the dequeued batch, one item per lane (loaded together: one memory round trip
     // per batch instead of three dependent ones per item)
+    const uint32_t n_items = a.n_items_dev ? *a.n_items_dev : a.n_items;  // retry launch: the count lives on the device
     uint32_t d_round = 0, d_block = 0, d_nblocks = 0, d_flags = ITEM_SKIP, d_id = 0;
     uint64_t d_prov = 0, d_rlen = 0, d_soff = 0;
     for (;;) {
@@ -280,7 +482,7 @@ __global__ __launch_bounds__(64) void k_zstd_encode(EncodeArgs a) {
             lim = next + a.batch;
             const uint32_t mine = first + lane;
             d_flags = ITEM_SKIP;
-            if (lane < a.batch && mine < a.n_items) {
+            if (lane < a.batch && mine < n_items) {
                 d_id = a.order ? a.order[mine] : mine;  // this variant's share of the plan (or all of it)
                 const EncItem e = a.items[d_id];
                 d_round = e.round; d_block = e.block; d_nblocks = e.n_blocks; d_flags = e.flags; d_prov = e.prov;
@@ -289,7 +491,7 @@ __global__ __launch_bounds__(64) void k_zstd_encode(EncodeArgs a) {
             }
         }
         const uint32_t item = next++;
-        if (item >= a.n_items) break;
+        if (item >= n_items) break;
         __syncthreads();
         const uint32_t bl = item - first;
         EncItem it;
@@ -508,27 +710,43 @@ __global__ __launch_bounds__(64) void k_zstd_encode(EncodeArgs a) {
                 base = anchor;
             }
         }
+        if (HASH_LOG == 11 && a.retry_list && nseq >= max_seq && base < scan_end) {
+            // Sequence budget spent before the end of the block: this is not periodic data.  Hand the block to the
+            // wide variant (denser matcher, Huffman literals, parallel bitstream) instead of emitting the rest raw.
+            if (lane == 0) a.retry_list[atomicAdd(a.retry_count, 1u)] = item_id;
+            continue;
+        }
         // trailing literals
         wave_copy(lits + lit_total, inb + anchor, nq - anchor, lane);
         lit_total += nq - anchor;
         __syncthreads();  // sequences + literal bytes of all lanes are visible to lane 0
 
-        // ---- entropy stage: headers by lane 0, the sequences bitstream by the whole wave ----
-        bool raw = nseq == 0;
+        // ---- entropy stage: literals (Huffman in the wide variant when it pays), headers, sequences bitstream ----
+        uint32_t lit_sec = 0;  // bytes of the literals section at blk + 3
+        if (HASH_LOG == 13 && lit_total >= HUF_MIN_LITS)
+            lit_sec = huf_literals(S, lits, lit_total, lits + ((lit_total + 3) & ~3u), blk + 3, lane);
+        bool raw = nseq == 0 && lit_sec == 0;
         uint32_t csize = 0;
         if (!raw) {
-            uint8_t *p = lits + lit_total;
+            if (!lit_sec) {
+                if (lane == 0) {
+                    // literals header: Raw_Literals_Block, size_format 3 (20-bit size, 3 bytes)
+                    blk[3] = (uint8_t)(0 | (3 << 2) | ((lit_total & 15) << 4));
+                    blk[4] = (uint8_t)(lit_total >> 4);
+                    blk[5] = (uint8_t)(lit_total >> 12);
+                }
+                lit_sec = 3 + lit_total;
+            }
+            uint8_t *p = blk + 3 + lit_sec;
             const uint32_t hl = nseq < 128 ? 1u : (nseq < 0x7F00 ? 2u : 3u);
             if (lane == 0) {
-                // literals header: Raw_Literals_Block, size_format 3 (20-bit size, 3 bytes)
-                blk[3] = (uint8_t)(0 | (3 << 2) | ((lit_total & 15) << 4));
-                blk[4] = (uint8_t)(lit_total >> 4);
-                blk[5] = (uint8_t)(lit_total >> 12);
                 if (nseq < 128) p[0] = (uint8_t)nseq;
                 else if (nseq < 0x7F00) { p[0] = (uint8_t)((nseq >> 8) + 128); p[1] = (uint8_t)nseq; }
                 else { p[0] = 255; p[1] = (uint8_t)(nseq - 0x7F00); p[2] = (uint8_t)((nseq - 0x7F00) >> 8); }
-                p[hl] = 0;  // LL, OF, ML all Predefined_Mode
+                if (nseq) p[hl] = 0;  // LL, OF, ML all Predefined_Mode
             }
+            if (nseq == 0) p += 1;  // a block of literals only: the sequences section is the single count byte
+            else
             // wide variant (128 KiB blocks, thousands of sequences): wave-parallel bitstream; small variant: serial writer
             if (HASH_LOG == 13 && nseq > 8) p = encode_sequences(S, seqs, nseq, p + hl + 1, lane);
             else {
