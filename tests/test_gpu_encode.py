@@ -164,3 +164,59 @@ def test_store_if_incompressible_opt_in(gpu_ctx, oracle):
         counters, corrupt, status = rows.decode_verify(d_blob, d_out)
         assert counters["verified_bytes"] == int(lens.sum()) and len(corrupt) == 0
         assert d_out[:int(lens.sum())].cpu().numpy().tobytes() == b"".join(entries)
+
+
+def _first_block_literals_type(frame):
+    """Literals_Block_Type of the frame's first block (single-segment frame as this encoder writes it)."""
+    fhd = frame[4]
+    fcs = {0: 1, 1: 2, 2: 4, 3: 8}[fhd >> 6] if (fhd >> 5) & 1 else (0 if fhd >> 6 == 0 else 1 << (fhd >> 6))
+    p = 5 + (0 if (fhd >> 5) & 1 else 1) + fcs
+    bh = frame[p] | (frame[p + 1] << 8) | (frame[p + 2] << 16)
+    return (bh >> 1) & 3, frame[p + 3] & 3
+
+
+def _skewed(n, seed, alphabet=b"etaoinshrdlucmfw .,;\n"):
+    """Letters drawn with a skewed distribution: few 4-byte repeats, low entropy per byte."""
+    rng = np.random.default_rng(seed)
+    w = 1.0 / np.arange(1, len(alphabet) + 1)
+    idx = rng.choice(len(alphabet), size=n, p=w / w.sum())
+    return np.frombuffer(alphabet, np.uint8)[idx].tobytes()
+
+
+@pytest.mark.parametrize("n", [40_000, 131_072, 300_001, 900])
+def test_huffman_literals_and_dense_sequences(gpu_ctx, oracle, n):
+    """Wide-variant entropy stages: Huffman-coded literals (direct weights, 1 or 4 streams), the wave-parallel
+    sequences bitstream, a block of literals only — checked by libzstd, the oracle and the GPU decoder."""
+    for data in (gen.pseudo_text(n, seed=n), _skewed(n, n)):
+        frame = gpu_ctx.compress(data)
+        assert oracle.libzstd_decompress(frame, n) == data
+        assert oracle.zstd_decompress(frame) == data
+        assert gpu_ctx.decompress(frame) == data
+        if n >= 40_000:
+            btype, ltype = _first_block_literals_type(frame)
+            assert btype == 2 and ltype == 2, (btype, ltype)   # compressed block with Huffman literals
+            assert len(frame) < 0.75 * n
+
+
+def test_small_real_rounds_are_handed_to_the_wide_variant(gpu_ctx, oracle):
+    """Rounds <= 16 KiB of non-periodic text exhaust the small variant's sequence budget and are re-encoded by the
+    wide variant; periodic rounds of the same size are not.  Either way the frames decode everywhere and the frame
+    of a round does not depend on its neighbours in the batch."""
+    import torch
+    from znippy_amd import hip
+    ents = [gen.pseudo_text(6000 + 37 * i, seed=i) for i in range(40)] + [gen.text(10240)] * 8 + [_skewed(9000, 3)]
+    lens = np.array([len(e) for e in ents], np.uint64)
+    offs = np.concatenate([[0], np.cumsum(lens)[:-1]]).astype(np.uint64)
+    d_src = torch.from_numpy(np.frombuffer(b"".join(ents) + bytes(64), np.uint8).copy()).cuda()
+    rt = hip.RoundTable(gpu_ctx, offs, lens)
+    d_blob = torch.zeros(rt.blob_bound() + 64, dtype=torch.uint8, device="cuda")
+    enc = rt.encode_hash(d_src, d_blob)
+    blob = d_blob.cpu().numpy()
+    for i, e in enumerate(ents):
+        f = blob[int(enc["blob_offset"][i]):int(enc["blob_offset"][i] + enc["blob_size"][i])].tobytes()
+        assert oracle.libzstd_decompress(f, len(e)) == e, i
+        assert f == gpu_ctx.compress(e), i                     # same bytes alone and inside the batch
+        assert enc["checksum"][i].tobytes() == oracle.blake3(e)
+    sizes = enc["blob_size"]
+    assert sizes[:40].sum() < 0.62 * lens[:40].sum()            # the n/40 budget alone leaves ~0.9 here
+    assert (sizes[40:48] < 200).all()
