@@ -199,6 +199,7 @@ def main():
         alg = {
             "decode_verify_fused": path_alg,             # one launch does the whole path for small rows
             "zstd_decode_general": blob_bytes + total_in + 57 * n,
+            "zstd_decode_blocks": blob_bytes + total_in + 57 * n,   # block items: same bytes, one work item per block
             "blake3_second_pass": total_in + 32 * n + (0 if skip is None else total_in),  # read (+ copy on the store path)
         }
         dom = max((k for k in k_read if k in alg), key=lambda k: k_read[k]) if k_read else None
