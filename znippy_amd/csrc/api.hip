@@ -136,7 +136,8 @@ struct znippy_rows {
     uint8_t *compressed = nullptr, *checksum = nullptr;
     int32_t *status = nullptr;
     uint32_t *digests = nullptr;
-    uint64_t *counters = nullptr;  // 8 x u64
+    uint64_t *counters = nullptr;  // 8 x u64 (+ pending_count behind them)
+    uint64_t *h_counters = nullptr;  // pinned mirror, filled by the run's own D2H copy
     uint64_t *corrupt = nullptr;
     uint32_t corrupt_cap = 0;
     uint32_t *list_a = nullptr;   // compressed rows with > 64 leaves: general decoder
@@ -328,10 +329,11 @@ void znippy_rows_destroy(znippy_rows *r) {
     if (!r) return;
     (void)hipSetDevice(r->ctx->device);
     void *ptrs[] = {r->blob_off, r->blob_size, r->usize, r->out_off, r->compressed, r->checksum,
-                    r->status, r->digests, r->counters, r->corrupt, r->list_a, r->pending, r->pending_count,
+                    r->status, r->digests, r->counters, r->corrupt, r->list_a, r->pending,
                     r->cand_row, r->cand_base, r->cand_nblocks, r->item_row, r->item_k, r->item_src, r->row_flag};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
+    if (r->h_counters) (void)hipHostFree(r->h_counters);
     free_plan(r->plan);
     delete r;
 }
@@ -371,7 +373,8 @@ int znippy_rows_create(znippy_ctx *ctx, const uint64_t *blob_offset, const uint6
     r->corrupt_cap = std::max<uint32_t>(n, 1);
     if (hipMalloc(&r->status, std::max<size_t>(4 * (size_t)n, 16)) != hipSuccess ||
         hipMalloc(&r->digests, std::max<size_t>(32 * (size_t)n, 32)) != hipSuccess ||
-        hipMalloc(&r->counters, 64) != hipSuccess ||
+        hipMalloc(&r->counters, 128) != hipSuccess ||  // [counters 8 x u64][pending_count] : one memset per run
+        hipHostMalloc(&r->h_counters, 64) != hipSuccess ||
         hipMalloc(&r->corrupt, 8 * (size_t)r->corrupt_cap) != hipSuccess) {
         znippy_rows_destroy(r);
         return ZNIPPY_E_NOMEM;
@@ -422,8 +425,9 @@ int znippy_rows_create(znippy_ctx *ctx, const uint64_t *blob_offset, const uint6
         znippy_rows_destroy(r);
         return rc;
     }
+    r->pending_count = reinterpret_cast<uint32_t *>(r->counters + 8);
     if (hipMalloc(&r->pending, std::max<size_t>(4 * (size_t)n, 16)) != hipSuccess ||
-        hipMalloc(&r->pending_count, 64) != hipSuccess) {
+        false) {
         znippy_rows_destroy(r);
         return ZNIPPY_E_NOMEM;
     }
@@ -439,10 +443,9 @@ int znippy_decode_verify_rows_async(znippy_ctx *ctx, znippy_rows *r, const void 
     hipStream_t s = ctx->stream;
     ctx->n_ktimes = 0;
     HIPCHK(ctx, hipMemsetAsync(r->status, 0, std::max<size_t>(4 * (size_t)r->n, 16), s));
-    HIPCHK(ctx, hipMemsetAsync(r->counters, 0, 64, s));
+    HIPCHK(ctx, hipMemsetAsync(r->counters, 0, 128, s));  // counters + pending_count
     HIPCHK(ctx, hipMemsetAsync(ctx->cursor, 0, 64, s));
     if (!r->n) return ZNIPPY_OK;
-    HIPCHK(ctx, hipMemsetAsync(r->pending_count, 0, 64, s));
     // 1) fused small-row kernel: decode simple frames + hash (+ copy stored rows), one wave per tile
     HashArgs h{};
     h.tiles = r->plan.tiles; h.n_tiles = r->plan.n_tiles;
@@ -535,6 +538,7 @@ int znippy_decode_verify_rows_async(znippy_ctx *ctx, znippy_rows *r, const void 
     launch_verify(r->digests, r->checksum, r->usize, r->status, r->n, r->row_begin, r->counters, r->corrupt,
                   r->corrupt_cap, s);
     ktime_end(ctx);
+    HIPCHK(ctx, hipMemcpyAsync(r->h_counters, r->counters, 64, hipMemcpyDeviceToHost, s));
     HIPCHK(ctx, hipGetLastError());
     return ZNIPPY_OK;
 }
@@ -545,7 +549,7 @@ int znippy_rows_results(znippy_ctx *ctx, znippy_rows *r, znippy_verify_counters 
     HIPCHK(ctx, hipSetDevice(ctx->device));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     uint64_t c[8] = {0};
-    HIPCHK(ctx, hipMemcpy(c, r->counters, 64, hipMemcpyDeviceToHost));
+    if (r->n) memcpy(c, r->h_counters, 64);  // copied by the run itself (pinned): no extra round trip here
     if (counters) {
         counters->total_chunks = c[0]; counters->total_written_bytes = c[1]; counters->verified_bytes = c[2];
         counters->corrupt_bytes = c[3]; counters->corrupt_rows = c[4]; counters->decode_errors = c[5];
