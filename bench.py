@@ -102,9 +102,15 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
-    torch.cuda.set_device(local_rank)
+    # one process per GPU; ZNIPPY_BENCH_BACKEND=gloo lets several ranks share one card to rehearse the N>1 path
+    backend = os.environ.get("ZNIPPY_BENCH_BACKEND", "nccl")
+    dev = local_rank if backend == "nccl" else local_rank % max(torch.cuda.device_count(), 1)
+    torch.cuda.set_device(dev)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
+        else:
+            dist.init_process_group(backend)
 
     import gen  # noqa: F401
     from oracle import oracle as O  # checker + cpu_baseline leg only
@@ -115,7 +121,7 @@ def main():
     n = len(lens)
     total_in = int(lens.sum())
     src_off = np.concatenate([[0], np.cumsum(lens)[:-1]]).astype(np.uint64)
-    ctx = hip.Context(local_rank)
+    ctx = hip.Context(dev)
 
     # ---- write side: this rank's Rounds over the resident staging buffer ----
     rounds = hip.RoundTable(ctx, src_off, lens, skip)

@@ -78,3 +78,22 @@ def test_world2_gloo_matches_single_process(tmp_path, oracle):
         assert a == b
         if e.relative_path != "stored.jar":
             assert a == e.data
+
+
+@pytest.mark.gpu
+def test_bench_n2_path_rehearsed_on_one_gpu():
+    """bench.py's N>1 code path (rendezvous, per-step counter all-reduce on its own stream, barrier + MAX-over-ranks
+    timing, rank-0 JSON) with two ranks sharing the one card over gloo; the driver runs the real thing over RCCL."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, ZNIPPY_BENCH_BACKEND="gloo")
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29533", os.path.join(root, "bench.py"),
+                        "--gpus", "2", "--steps", "3", "--warmup", "1", "--workload", "c2small"],
+                       capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert p.returncode == 0, p.stderr[-2000:]
+    line = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["value"] > 0
+    assert line["config"]["parallelism"].endswith("x2") and line["cpu_baseline"] is None
