@@ -449,6 +449,10 @@ __device__ int decode_simple(const uint8_t *src, uint32_t n, uint8_t *out, uint6
             else if (b0 < 255) { nseq = ((b0 - 128) << 8) + ((sh >> 8) & 0xFF); pos += 2; }
             else { nseq = ((sh >> 8) & 0xFFFF) + 0x7F00; pos += 3; }
             uint32_t lit_pos = 0;
+            // This path executes sequences one at a time, each match straight into HBM: right for the one or two
+            // long matches of periodic rows, wrong for real text.  Rows with many sequences go to the general
+            // decoder, which executes 64 of them per step inside an LDS window.
+            if (nseq > 16 && opos == 0) return F_NOT_SIMPLE;
             if (nseq) {
                 if (pos >= bend) return F_E_CORRUPT;
                 const uint32_t modes = (uint32_t)W.fwd(pos) & 0xFF;
