@@ -940,21 +940,26 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES == 4 ? 4 : 1) void k_zstd_decod
                     // backward bit reader: `left` unread bits, a 64-bit container covering stream bits [cb, cb + 64);
                     // bits below bit 0 read as zero and drive `left` negative, which is the corruption test
                     const uint8_t *const bbase = src + uni(S.bs_off);
-                    int64_t left = (int64_t)uni64((uint64_t)S.bs_pos), cb = 0;
+                    int32_t left = (int32_t)uni((uint32_t)S.bs_pos), cb = 0;  // a block's bitstream is < 2^20 bits
                     uint64_t c = 0;
-                    auto reload = [&]() {
-                        int64_t b0 = ((left + 7) >> 3) - 8;
+                    // the container always starts 8 bytes below the byte holding bit `left` (or at the stream's first
+                    // byte); past the first load it can only move down inside the stream, so it needs no bounds check
+                    auto refill = [&]() {
+                        int32_t b0 = ((left + 7) >> 3) - 8;
                         if (b0 < 0) b0 = 0;
-                        c = uni64(load8_guard(bbase + b0, blob_end));
+                        uint64_t v;
+                        __builtin_memcpy(&v, bbase + b0, 8);
+                        c = uni64(v);
                         cb = b0 * 8;
                     };
                     auto rd = [&](uint32_t nb) -> uint32_t {
-                        const int32_t sh = (int32_t)(left - cb) - (int32_t)nb;
+                        const int32_t sh = left - cb - (int32_t)nb;
                         const uint64_t v = sh >= 0 ? (c >> sh) : (c << (sh < -63 ? 63 : -sh));
-                        left -= nb;
+                        left -= (int32_t)nb;
                         return (uint32_t)v & ((1u << nb) - 1u);  // nb <= 31
                     };
-                    reload();
+                    if (((left + 7) >> 3) >= 8) refill();
+                    else c = uni64(load8_guard(bbase, blob_end));  // a stream shorter than 8 bytes: everything is in, cb stays 0
                     uint32_t sl = uni(S.st_ll), so = uni(S.st_of), sm = uni(S.st_ml);
                     uint32_t r0 = uni(S.rep[0]), r1 = uni(S.rep[1]), r2 = uni(S.rep[2]);
                     int err = 0;
@@ -972,16 +977,19 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES == 4 ? 4 : 1) void k_zstd_decod
                         const uint2 veo = to2[so], vem = tm2[sm], vel = tl2[sl];
                         const uint32_t eox = uni(veo.x), eoy = uni(veo.y), emx = uni(vem.x), emy = uni(vem.y), elx = uni(vel.x), ely = uni(vel.y);
                         const uint32_t ofb = eox >> 24, mlb = emx >> 24, llb = elx >> 24;
-                        if (left - cb < 32) reload();
+                        const bool more = seq_done + i + 1 < nseq;
+                        const uint32_t nbl = (elx >> 16) & 0xFF, nbm = (emx >> 16) & 0xFF, nbo = (eox >> 16) & 0xFF;
+                        const int32_t need_v = (int32_t)(ofb + mlb + llb), need_s = more ? (int32_t)(nbl + nbm + nbo) : 0;
+                        if (left - cb < need_v + need_s && cb > 0) refill();  // usually the one refill of the sequence
                         const uint32_t ov = eoy + rd(ofb > 31 ? 31 : ofb);
-                        if (left - cb < 32) reload();
+                        if (need_v + need_s > 56 && left - cb < need_v + need_s - (int32_t)ofb && cb > 0) refill();  // long offsets
                         const uint32_t ml = emy + rd(mlb);
                         const uint32_t ll = ely + rd(llb);
-                        if (seq_done + i + 1 < nseq) {
-                            if (left - cb < 32) reload();
-                            sl = (elx & 0xFFFF) + rd((elx >> 16) & 0xFF);
-                            sm = (emx & 0xFFFF) + rd((emx >> 16) & 0xFF);
-                            so = (eox & 0xFFFF) + rd((eox >> 16) & 0xFF);
+                        if (more) {
+                            if (need_v + need_s > 56 && left - cb < need_s && cb > 0) refill();
+                            sl = (elx & 0xFFFF) + rd(nbl);
+                            sm = (emx & 0xFFFF) + rd(nbm);
+                            so = (eox & 0xFFFF) + rd(nbo);
                         }
                         if (left < 0) { err = E_CORRUPT; break; }
                         uint32_t offset;
@@ -1007,7 +1015,7 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES == 4 ? 4 : 1) void k_zstd_decod
                     if (!err && abs0 + uni64(S.blk_base) + produced > out_end) err = E_CORRUPT;
                     if (!err && seq_done + bn == nseq && left != 0) err = E_CORRUPT;
                     if (lane0) {
-                        S.bs_pos = left;
+                        S.bs_pos = (int64_t)left;
                         S.st_ll = sl; S.st_of = so; S.st_ml = sm;
                         S.rep[0] = r0; S.rep[1] = r1; S.rep[2] = r2;
                         S.err = err;
