@@ -653,30 +653,42 @@ namespace {
 
 // WalkDir order (L63-78): a directory's files, then its sub-directories, both in name order; only regular
 // files are ingested, every directory (the root too) is counted.
-void walk_dir(const std::string &dir, std::vector<std::string> *files, std::vector<uint64_t> *sizes, uint64_t *n_dirs) {
+void walk_dir(const std::string &dir, std::vector<std::string> *files, uint64_t *n_dirs) {
     DIR *d = opendir(dir.c_str());
     if (!d) return;
     (*n_dirs)++;
-    std::vector<std::pair<std::string, uint64_t>> fs;
-    std::vector<std::string> ds;
+    std::vector<std::string> fs, ds;
     while (struct dirent *e = readdir(d)) {
         const std::string name = e->d_name;
         if (name == "." || name == "..") continue;
         if (e->d_type == DT_DIR) { ds.push_back(name); continue; }
-        if (e->d_type != DT_REG && e->d_type != DT_UNKNOWN) continue;
-        struct stat st;
+        if (e->d_type == DT_REG) { fs.push_back(name); continue; }
+        if (e->d_type != DT_UNKNOWN) continue;
+        struct stat st;  // a file system that does not report entry types
         if (lstat((dir + "/" + name).c_str(), &st) != 0) continue;
         if (S_ISDIR(st.st_mode)) ds.push_back(name);
-        else if (S_ISREG(st.st_mode)) fs.emplace_back(name, (uint64_t)st.st_size);
+        else if (S_ISREG(st.st_mode)) fs.push_back(name);
     }
     closedir(d);
     std::sort(fs.begin(), fs.end());
     std::sort(ds.begin(), ds.end());
-    for (const auto &f : fs) {
-        files->push_back(dir + "/" + f.first);
-        sizes->push_back(f.second);
-    }
-    for (const auto &sub : ds) walk_dir(dir + "/" + sub, files, sizes, n_dirs);
+    for (const auto &f : fs) files->push_back(dir + "/" + f);
+    for (const auto &sub : ds) walk_dir(dir + "/" + sub, files, n_dirs);
+}
+
+// file sizes, a few threads at a time (100k lstat calls are the larger half of a serial walk)
+void stat_sizes(const std::vector<std::string> &files, std::vector<uint64_t> *sizes) {
+    sizes->assign(files.size(), 0);
+    const unsigned nt = std::max(1u, std::min<unsigned>(io_threads(), (unsigned)(files.size() / 1024 + 1)));
+    std::vector<std::thread> th;
+    for (unsigned t = 0; t < nt; t++)
+        th.emplace_back([&, t] {
+            for (size_t i = t; i < files.size(); i += nt) {
+                struct stat st;
+                if (lstat(files[i].c_str(), &st) == 0) (*sizes)[i] = (uint64_t)st.st_size;
+            }
+        });
+    for (auto &x : th) x.join();
 }
 
 struct ReadTask {
@@ -767,7 +779,8 @@ int znippy_compress_dir(const char *input_dir, const char *output, int no_skip, 
     std::vector<std::string> files;
     std::vector<uint64_t> sizes;
     uint64_t total_dirs = 0;
-    walk_dir(root, &files, &sizes, &total_dirs);
+    walk_dir(root, &files, &total_dirs);
+    stat_sizes(files, &sizes);
     const double t_walk = now_s();
     unsigned cores = std::thread::hardware_concurrency();
     cpu_set_t set;
