@@ -51,14 +51,19 @@ uint64_t env_mb(const char *name, uint64_t dflt_mb) {
 // Bytes per GPU hand-off: one pinned staging slot on the write side, one decoded range on the read side.
 uint64_t stage_bytes() { return env_mb("ZNIPPY_HOST_SLOT_MB", 128); }
 uint64_t range_bytes(bool save) { return env_mb("ZNIPPY_HOST_RANGE_MB", save ? 256 : 1024); }
-unsigned io_threads() {
+// File I/O helper threads.  Readers (compress_dir: open/pread/close, lstat) scale to ~16 threads; writers that
+// CREATE files in one directory contend on its lock and are fastest at ~4 (tmpfs, 100k files: 1 writer 0.50 s,
+// 2: 0.41 s, 4: 0.38 s, 8: 0.52 s, 16: 0.78 s, 32: 1.2 s).  ZNIPPY_HOST_READERS / ZNIPPY_HOST_WRITERS override.
+unsigned env_threads(const char *name, unsigned dflt) {
     unsigned hw = std::thread::hardware_concurrency();
     cpu_set_t set;
     if (sched_getaffinity(0, sizeof set, &set) == 0) hw = (unsigned)CPU_COUNT(&set);
-    const char *v = getenv("ZNIPPY_HOST_IO_THREADS");
-    unsigned want = v && *v ? (unsigned)strtoul(v, nullptr, 10) : 8;
+    const char *v = getenv(name);
+    unsigned want = v && *v ? (unsigned)strtoul(v, nullptr, 10) : dflt;
     return std::max(1u, std::min(want, hw ? hw : 1u));
 }
+unsigned reader_threads() { return env_threads("ZNIPPY_HOST_READERS", 16); }
+unsigned writer_threads() { return env_threads("ZNIPPY_HOST_WRITERS", 4); }
 
 double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 bool trace_on() { const char *v = getenv("ZNIPPY_HOST_TRACE"); return v && *v && *v != '0'; }
@@ -679,7 +684,7 @@ void walk_dir(const std::string &dir, std::vector<std::string> *files, uint64_t 
 // file sizes, a few threads at a time (100k lstat calls are the larger half of a serial walk)
 void stat_sizes(const std::vector<std::string> &files, std::vector<uint64_t> *sizes) {
     sizes->assign(files.size(), 0);
-    const unsigned nt = std::max(1u, std::min<unsigned>(io_threads(), (unsigned)(files.size() / 1024 + 1)));
+    const unsigned nt = std::max(1u, std::min<unsigned>(reader_threads(), (unsigned)(files.size() / 1024 + 1)));
     std::vector<std::thread> th;
     for (unsigned t = 0; t < nt; t++)
         th.emplace_back([&, t] {
@@ -797,7 +802,7 @@ int znippy_compress_dir(const char *input_dir, const char *output, int no_skip, 
         Packer pk(fd, device, std::max<uint64_t>(slice_size, 1));
         int rc = pk.start();
         if (rc) { close(fd); return rc; }
-        ReaderPool readers(&pk, &files, io_threads());
+        ReaderPool readers(&pk, &files, reader_threads());
         bool ok = true;
         for (int pass = 0; pass < 2 && ok; pass++) {  // partition L92-101: pass 0 = big (or empty) files, pass 1 = small
             for (uint32_t i = 0; i < files.size() && ok; i++) {
@@ -1019,7 +1024,7 @@ int znippy_decompress_archive(const char *index_path, int save_data, const char 
     } slabs[2];
     std::atomic<int> werr{0};
     const RowWriter writer{&ix, out_dir, &first_touch, world == 1, &werr};
-    const unsigned n_writers = adjacent ? io_threads() : 1;
+    const unsigned n_writers = adjacent ? writer_threads() : 1;
     const uint64_t batch_bytes = range_bytes(save_data != 0);
     double t_d2h = 0, t_wjoin = 0;
     int which = 0, n_ranges = 0;
