@@ -261,3 +261,31 @@ def test_cpp_compress_dir_matches_python_mirror(tmp_path, monkeypatch):
     r0 = host.compress_dir(tmp_path / "nothing", tmp_path / "n.znippy")
     assert (r0.total_files, r0.chunks, r0.total_dirs) == (0, 0, 1)
     assert host.decompress_archive(tmp_path / "n.znippy", False, "/dev/null").total_files == 0
+
+
+@gpu
+def test_config_c1_plumbing_1000_files(tmp_path):
+    """1,000 files x 10,240 B of generate_text_data named d000/file_000000.txt ... through the
+    directory entry point: compress -> decompress -> byte compare, corrupt_files == 0 (compiled host and Python
+    mirror write interchangeable archives)."""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from znippy_amd import host
+    from znippy_amd.decompress import decompress_archive as py_decompress
+    from znippy_amd.slot_packer import compress_dir as py_compress_dir
+    chunk = gen.text(10 * 1024)
+    root = tmp_path / "in"
+    files = {f"d{i // 100:03}/file_{i:06}.txt": chunk for i in range(1000)}
+    _tree(root, files)
+    rep = host.compress_dir(root, tmp_path / "c1.znippy")
+    assert (rep.total_files, rep.chunks, rep.total_dirs, rep.total_bytes_in) == (1000, 1000, 11, 1000 * 10240)
+    assert rep.total_bytes_out < 400_000                       # ~85 B of frame + ~130 B of index per file
+    v = host.decompress_archive(tmp_path / "c1.znippy", True, tmp_path / "out")
+    assert (v.total_files, v.verified_files, v.corrupt_files, v.total_bytes, v.chunks) == (1000, 1000, 0, 1000 * 10240, 1000)
+    for rel in files:
+        assert (tmp_path / "out" / rel).read_bytes() == chunk, rel
+    # the other implementation of the same interface, both directions
+    py_compress_dir(root, tmp_path / "c1_py.znippy")
+    assert host.decompress_archive(tmp_path / "c1_py.znippy", False, "/dev/null").corrupt_files == 0
+    assert py_decompress(tmp_path / "c1.znippy", False, None).corrupt_files == 0
