@@ -972,10 +972,19 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES == 4 ? 4 : 1) void k_zstd_decod
                     const uint2 *const tl2 = reinterpret_cast<const uint2 *>(tl), *const to2 = reinterpret_cast<const uint2 *>(to),
                                 *const tm2 = reinterpret_cast<const uint2 *>(tm);
                     const bool lane0 = (tid & 63) == 0;
+                    const bool predef = sel0 == 0 && sel1 == 0 && sel2 == 0;
+                    const uint2 rl = tl2[predef ? (tid & 63) : 0], rm = tm2[predef ? (tid & 63) : 0], ro = to2[predef ? (tid & 31) : 0];
+                    auto rdl = [](uint32_t v, uint32_t l) -> uint32_t { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)l); };
                     for (uint32_t i = 0; i < bn; i++) {
                         // entry = {next:16 | nbits:8 | addbits:8, base}
-                        const uint2 veo = to2[so], vem = tm2[sm], vel = tl2[sl];
-                        const uint32_t eox = uni(veo.x), eoy = uni(veo.y), emx = uni(vem.x), emy = uni(vem.y), elx = uni(vel.x), ely = uni(vel.y);
+                        uint32_t eox, eoy, emx, emy, elx, ely;
+                        if (predef) {  // predefined tables sit in registers, one entry per lane: a lookup is a v_readlane
+                            eox = rdl(ro.x, so); eoy = rdl(ro.y, so); emx = rdl(rm.x, sm); emy = rdl(rm.y, sm);
+                            elx = rdl(rl.x, sl); ely = rdl(rl.y, sl);
+                        } else {
+                            const uint2 veo = to2[so], vem = tm2[sm], vel = tl2[sl];
+                            eox = uni(veo.x); eoy = uni(veo.y); emx = uni(vem.x); emy = uni(vem.y); elx = uni(vel.x); ely = uni(vel.y);
+                        }
                         const uint32_t ofb = eox >> 24, mlb = emx >> 24, llb = elx >> 24;
                         const bool more = seq_done + i + 1 < nseq;
                         const uint32_t nbl = (elx >> 16) & 0xFF, nbm = (emx >> 16) & 0xFF, nbo = (eox >> 16) & 0xFF;
@@ -992,25 +1001,51 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES == 4 ? 4 : 1) void k_zstd_decod
                             so = (eox & 0xFFFF) + rd(nbo);
                         }
                         if (left < 0) { err = E_CORRUPT; break; }
-                        uint32_t offset;
-                        if (ov > 3) { offset = ov - 3; r2 = r1; r1 = r0; r0 = offset; }
-                        else if (no_rep) { err = E_CORRUPT; break; }
-                        else {
-                            uint32_t idx = ov - 1 + (ll == 0 ? 1 : 0);
-                            if (idx == 0) offset = r0;
-                            else {
-                                offset = idx == 1 ? r1 : (idx == 2 ? r2 : r0 - 1);
-                                if (offset == 0) { err = E_CORRUPT; break; }
-                                if (idx > 1) r2 = r1;
-                                r1 = r0; r0 = offset;
+                        if (lane0) { S.seq_ll[i] = ll; S.seq_ml[i] = ml; S.seq_off[i] = ov; }  // raw offset value: resolved below
+                    }
+                    // Everything that is not the bitstream's serial dependency happens 64 sequences at a time: repeat
+                    // offsets (only groups that contain one walk their sequences in order), literal / match bounds.
+                    const uint32_t lane = tid & 63;
+                    for (uint32_t g0 = 0; g0 < bn && !err; g0 += 64) {
+                        const uint32_t cnt = bn - g0 < 64 ? bn - g0 : 64;
+                        const bool on = lane < cnt;
+                        const uint32_t ll = on ? S.seq_ll[g0 + lane] : 0, ml = on ? S.seq_ml[g0 + lane] : 0;
+                        const uint32_t ov = on ? S.seq_off[g0 + lane] : 4;
+                        uint32_t offset = ov - 3;
+                        if (__ballot(on && ov <= 3) != 0ull || cnt < 3) {
+                            if (no_rep && __ballot(on && ov <= 3) != 0ull) { err = E_CORRUPT; break; }
+                            for (uint32_t j = 0; j < cnt; j++) {  // in order, on the scalar unit
+                                const uint32_t ovj = uni(__shfl(ov, j)), llj = uni(__shfl(ll, j));
+                                uint32_t o;
+                                if (ovj > 3) { o = ovj - 3; r2 = r1; r1 = r0; r0 = o; }
+                                else {
+                                    const uint32_t idx = ovj - 1 + (llj == 0 ? 1 : 0);
+                                    if (idx == 0) o = r0;
+                                    else {
+                                        o = idx == 1 ? r1 : (idx == 2 ? r2 : r0 - 1);
+                                        if (o == 0) { err = E_CORRUPT; break; }
+                                        if (idx > 1) r2 = r1;
+                                        r1 = r0; r0 = o;
+                                    }
+                                }
+                                if (lane == j) offset = o;
                             }
+                            if (err) break;
+                        } else {  // explicit offsets only: the history is the group's last three
+                            r0 = uni(__shfl(offset, cnt - 1)); r1 = uni(__shfl(offset, cnt - 2)); r2 = uni(__shfl(offset, cnt - 3));
                         }
-                        if (lane0) { S.seq_ll[i] = ll; S.seq_ml[i] = ml; S.seq_off[i] = offset; }
-                        lits += ll;
-                        produced += (uint64_t)ll + ml;
-                        // validate against what exists at that point
-                        if (lits > lit_room) { err = E_CORRUPT; break; }
-                        if ((uint64_t)offset > abs0 + produced - ml) { err = E_CORRUPT; break; }
+                        uint32_t linc = ll, pinc = ll + ml;  // inclusive scans: literals used, bytes produced
+#pragma unroll
+                        for (int d = 1; d < 64; d <<= 1) {
+                            const uint32_t y = __shfl_up(linc, d), z = __shfl_up(pinc, d);
+                            if (lane >= (uint32_t)d) { linc += y; pinc += z; }
+                        }
+                        // a match may reach back over what exists when it starts; literals may not run out
+                        const bool bad = on && ((uint64_t)offset > abs0 + produced + pinc - ml || lits + linc > lit_room);
+                        if (__ballot(bad) != 0ull) { err = E_CORRUPT; break; }
+                        if (on) S.seq_off[g0 + lane] = offset;
+                        lits += uni(__shfl(linc, 63));
+                        produced += uni(__shfl(pinc, 63));
                     }
                     if (!err && abs0 + uni64(S.blk_base) + produced > out_end) err = E_CORRUPT;
                     if (!err && seq_done + bn == nseq && left != 0) err = E_CORRUPT;
