@@ -503,6 +503,17 @@ int znippy_decode_verify_rows_async(znippy_ctx *ctx, znippy_rows *r, const void 
         a.out = (uint8_t *)d_out; a.out_cap = out_cap;
         a.status = r->status; a.n_rows = r->n; a.cursor = ctx->cursor + 4;
         a.lit_scratch = ctx->lit_scratch;
+        if (getenv("ZNIPPY_DDBG")) {  // diagnostic: phase shares of the previous block-item launch
+            static unsigned long long *dbg = nullptr;
+            if (!dbg) { (void)hipMalloc(&dbg, 64); (void)hipMemset(dbg, 0, 64); }
+            unsigned long long h[8];
+            (void)hipStreamSynchronize(s);
+            (void)hipMemcpy(h, dbg, 64, hipMemcpyDeviceToHost);
+            if (h[0]) fprintf(stderr, "[znippy ddbg] block items=%llu  cycles per item: literals=%.0f seq-tables=%.0f seq-decode=%.0f execute=%.0f tail=%.0f\n", h[0],
+                              (double)h[1] / h[0], (double)h[2] / h[0], (double)h[3] / h[0], (double)h[4] / h[0], (double)h[5] / h[0]);
+            (void)hipMemset(dbg, 0, 64);
+            a.dbg = dbg;
+        }
         ktime_begin(ctx, "zstd_decode_blocks");
         launch_decode(a, std::min<int>(ctx->decode_grid, (int)r->n_items), false, s);
         ktime_end(ctx);

@@ -70,6 +70,7 @@ struct DecodeArgs {
     uint32_t n_rows;
     uint32_t *cursor;    // atomic row cursor (the reference's AtomicUsize, decompress.rs:L104)
     uint8_t *lit_scratch;  // per resident workgroup: LIT_SCRATCH bytes
+    unsigned long long *dbg;  // diagnostic only (ZNIPPY_DDBG): phase cycle counters [items, literals, seq tables, seq decode, execute, tail], never an output
     // Block items: frames of >= 2 blocks are first tried block by block, every block a work item of its own (a
     // frame written by this library has self-contained 128 KiB blocks; any frame that turns out not to — repeat
     // offsets, reused tables, a match reaching into an earlier block, another block size — is flagged and decoded

@@ -622,6 +622,9 @@ __device__ uint64_t wave_xxh64(const uint8_t *p, uint64_t len, uint32_t lane) {
 // ---------------------------------------------------------------------------------------------
 // the kernel
 // ---------------------------------------------------------------------------------------------
+// diagnostic phase stamps (ZNIPPY_DDBG): thread 0 adds the cycles since the previous stamp to counter i
+#define DSTAMP(i) do { if (a.dbg && tid == 0) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); atomicAdd(&a.dbg[i], now_ - t_last); t_last = now_; } } while (0)
+
 template <int NWAVES>
 __global__ __launch_bounds__(NWAVES * 64, NWAVES == 4 ? 4 : 1) void k_zstd_decode(DecodeArgs a) {
     using Shared = SharedT<NWAVES>;
@@ -662,6 +665,8 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES == 4 ? 4 : 1) void k_zstd_decod
             row = a.item_row[widx]; item_k = a.item_k[widx]; item_src = a.item_src[widx];
         } else row = widx < a.n_list_a ? a.list_a[widx] : a.pending[widx - a.n_list_a];
 
+        unsigned long long t_last = a.dbg ? __builtin_amdgcn_s_memtime() : 0;
+        if (a.dbg && tid == 0) atomicAdd(&a.dbg[0], 1ull);
         const uint8_t *const src = a.blobs + (a.blob_off[row] - a.blob_base);
         const uint64_t src_n = a.blob_size[row];
         const uint8_t *const blob_end = src + src_n;
@@ -862,6 +867,7 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES == 4 ? 4 : 1) void k_zstd_decod
 
             // -- sequences header + tables (lane 0) --
             __syncthreads();
+            DSTAMP(1);
             if (tid == 0) {
                 int err = 0;
                 const uint64_t end = bpos + bsize;
@@ -922,6 +928,7 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES == 4 ? 4 : 1) void k_zstd_decod
             __syncthreads();
             if (S.err) break;
 
+            DSTAMP(2);
             // -- sequences: lane 0 decodes a batch into LDS, the workgroup executes it --
             uint32_t seq_done = 0;
             const uint32_t nseq = S.nseq;
@@ -1058,6 +1065,7 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES == 4 ? 4 : 1) void k_zstd_decod
                     }
                 }
                 __syncthreads();
+                DSTAMP(3);
                 if (S.err) break;
                 if constexpr (NWAVES == 4) {
                     // execute.  Every wave follows the same control flow (the decisions depend only on the batch in LDS
@@ -1192,6 +1200,7 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES == 4 ? 4 : 1) void k_zstd_decod
                 }
                 seq_done += bn;
                 __syncthreads();
+                DSTAMP(4);
             }
             if (S.err) break;
             if constexpr (NWAVES == 4) {
@@ -1244,6 +1253,7 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES == 4 ? 4 : 1) void k_zstd_decod
         
             }
         }
+        DSTAMP(5);
         __syncthreads();  // every wave's output stores have landed (same CU)
         {
             int err = S.err;
