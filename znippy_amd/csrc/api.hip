@@ -209,6 +209,26 @@ static int dev_upload(znippy_ctx *ctx, T **d, const T *h, size_t n) {
     return ZNIPPY_OK;
 }
 
+// Scratch that only one side of the path needs is allocated on that side's first call (a verify-only context
+// never pays for the encoder's 400 MB of sequence scratch, nor an encode-only one for the literal scratch).
+static int ensure_decoder(znippy_ctx *ctx) {
+    if (ctx->lit_scratch) return ZNIPPY_OK;
+    if (hipMalloc(&ctx->lit_scratch, decode_lit_scratch_bytes(ctx->decode_grid)) != hipSuccess) return ZNIPPY_E_NOMEM;
+    return ZNIPPY_OK;
+}
+static int ensure_encoder(znippy_ctx *ctx) {
+    if (ctx->enc_tabs) return ZNIPPY_OK;
+    EncTables t;
+    build_encode_tables(&t);
+    if (hipMalloc(&ctx->enc_seq, (size_t)ctx->encode_grid * MAX_SEQ * 3 * 4) != hipSuccess ||
+        hipMalloc(&ctx->enc_tabs, sizeof(EncTables)) != hipSuccess ||
+        hipMemcpy(ctx->enc_tabs, &t, sizeof t, hipMemcpyHostToDevice) != hipSuccess) {
+        if (ctx->enc_tabs) { (void)hipFree(ctx->enc_tabs); ctx->enc_tabs = nullptr; }
+        return ZNIPPY_E_NOMEM;
+    }
+    return ZNIPPY_OK;
+}
+
 extern "C" {
 
 int znippy_ctx_create(int device, void *hip_stream, znippy_ctx **out) {
@@ -225,13 +245,12 @@ int znippy_ctx_create(int device, void *hip_stream, znippy_ctx **out) {
     if (hipStreamCreateWithFlags(&ctx->aux, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming) != hipSuccess) {
-        delete ctx;
+        znippy_ctx_destroy(ctx);
         return ZNIPPY_E_HIP;
     }
     ctx->decode_grid = decode_grid_size(device);
-    if (hipMalloc(&ctx->lit_scratch, decode_lit_scratch_bytes(ctx->decode_grid)) != hipSuccess ||
-        hipMalloc(&ctx->cursor, 64) != hipSuccess) {
-        delete ctx;
+    if (hipMalloc(&ctx->cursor, 64) != hipSuccess) {
+        znippy_ctx_destroy(ctx);
         return ZNIPPY_E_NOMEM;
     }
     {
@@ -239,14 +258,6 @@ int znippy_ctx_create(int device, void *hip_stream, znippy_ctx **out) {
         int cus = hipGetDeviceProperties(&p, device) == hipSuccess ? p.multiProcessorCount : 256;
         ctx->encode_grid = cus * 8;         // 16 KiB hash table per wave
         ctx->encode_grid_small = cus * 16;  // 4 KiB hash table per wave
-        EncTables t;
-        build_encode_tables(&t);
-        if (hipMalloc(&ctx->enc_seq, (size_t)ctx->encode_grid * MAX_SEQ * 3 * 4) != hipSuccess ||
-            hipMalloc(&ctx->enc_tabs, sizeof(EncTables)) != hipSuccess ||
-            hipMemcpy(ctx->enc_tabs, &t, sizeof t, hipMemcpyHostToDevice) != hipSuccess) {
-            delete ctx;
-            return ZNIPPY_E_NOMEM;
-        }
     }
     *out = ctx;
     return ZNIPPY_OK;
@@ -442,6 +453,7 @@ int znippy_decode_verify_rows_async(znippy_ctx *ctx, znippy_rows *r, const void 
     HIPCHK(ctx, hipSetDevice(ctx->device));
     hipStream_t s = ctx->stream;
     ctx->n_ktimes = 0;
+    { const int rc0 = ensure_decoder(ctx); if (rc0) return rc0; }
     HIPCHK(ctx, hipMemsetAsync(r->status, 0, std::max<size_t>(4 * (size_t)r->n, 16), s));
     HIPCHK(ctx, hipMemsetAsync(r->counters, 0, 128, s));  // counters + pending_count
     HIPCHK(ctx, hipMemsetAsync(ctx->cursor, 0, 64, s));
@@ -814,6 +826,7 @@ extern "C" int znippy_encode_hash_rounds_async(znippy_ctx *ctx, znippy_rounds *r
     hipStream_t s = ctx->stream;
     ctx->n_ktimes = 0;
     if (!r->n) return ZNIPPY_OK;
+    { const int rc0 = ensure_encoder(ctx); if (rc0) return rc0; }
     if (r->prov_bytes + 64 > ctx->enc_prov_cap) {
         HIPCHK(ctx, hipStreamSynchronize(s));
         if (ctx->enc_prov) (void)hipFree(ctx->enc_prov);
