@@ -70,7 +70,7 @@ struct SharedT {
     int16_t norm[256];
     uint16_t fse_next[256];
     uint8_t fse_sym[512];
-    uint32_t seq_ll[SEQ_BATCH], seq_ml[SEQ_BATCH], seq_off[SEQ_BATCH];
+    uint32_t seq_ll[2][SEQ_BATCH], seq_ml[2][SEQ_BATCH], seq_off[2][SEQ_BATCH];  // two batches: one being decoded, one being executed
     // pattern buffer for long overlapping matches: E[i] = period[i % off], i < off + 16 * threads
     __attribute__((aligned(16))) uint8_t ebuf[(NW == 4 ? WIN_HIST + WIN_CAP : EXP_OFF_MAX + 16 * 64 * NW) + 64];
     // per-row / per-block state broadcast from lane 0
@@ -933,13 +933,10 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES == 4 ? 4 : 1) void k_zstd_decod
             uint32_t seq_done = 0;
             const uint32_t nseq = S.nseq;
             const uint8_t *lit_ptr = S.lit_kind == 0 ? src + S.lit_src : lit_buf;
-            while (seq_done < nseq) {
-                const uint32_t bn = nseq - seq_done < SEQ_BATCH ? nseq - seq_done : SEQ_BATCH;
-                __syncthreads();
-                // Sequence decoding is one serial bitstream: wave 0 runs it as SCALAR code — every value is wave-uniform
-                // (readfirstlane), so the state machine, the bit arithmetic and the branches execute on the scalar unit
-                // and only the table lookups / result stores touch the vector side.
-                if (wave0) {
+            // Decode one batch of sequences [seq_done, seq_done + bn) into buffer `buf` (wave 0).  abs0_in: output bytes in front of
+            // the batch that a match may reach (inside the block for a block item), lit_room_in: literals still unused.
+            auto decode_batch = [&](const uint32_t seq_done, const uint32_t bn, const uint32_t buf, const uint64_t abs0_in, const uint32_t lit_room_in,
+                                    uint64_t &prod_out, uint32_t &lits_out) {
                     const uint32_t sel0 = uni(S.sel[0]), sel1 = uni(S.sel[1]), sel2 = uni(S.sel[2]);
                     const FseEntry *tl = sel0 == 0 ? S.dll : (sel0 == 1 ? &S.rle[0] : S.ll);
                     const FseEntry *to = sel1 == 0 ? S.dof : (sel1 == 1 ? &S.rle[1] : S.of);
@@ -972,8 +969,8 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES == 4 ? 4 : 1) void k_zstd_decod
                     int err = 0;
                     uint64_t produced = 0;
                     uint32_t lits = 0;
-                    const uint32_t lit_room = uni(S.lit_len) - uni(S.lit_pos);
-                    const uint64_t abs0 = uni64(S.out_pos) + uni(S.win_n) - uni64(S.blk_base);  // bytes a match may reach back over
+                    const uint32_t lit_room = lit_room_in;
+                    const uint64_t abs0 = abs0_in;  // bytes a match may reach back over
                     const bool no_rep = a.block_mode != 0;  // a repeat offset would depend on the block before
                     const uint64_t out_end = uni64(S.out_end);
                     const uint2 *const tl2 = reinterpret_cast<const uint2 *>(tl), *const to2 = reinterpret_cast<const uint2 *>(to),
@@ -1008,7 +1005,7 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES == 4 ? 4 : 1) void k_zstd_decod
                             so = (eox & 0xFFFF) + rd(nbo);
                         }
                         if (left < 0) { err = E_CORRUPT; break; }
-                        if (lane0) { S.seq_ll[i] = ll; S.seq_ml[i] = ml; S.seq_off[i] = ov; }  // raw offset value: resolved below
+                        if (lane0) { S.seq_ll[buf][i] = ll; S.seq_ml[buf][i] = ml; S.seq_off[buf][i] = ov; }  // raw offset value: resolved below
                     }
                     // Everything that is not the bitstream's serial dependency happens 64 sequences at a time: repeat
                     // offsets (only groups that contain one walk their sequences in order), literal / match bounds.
@@ -1016,8 +1013,8 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES == 4 ? 4 : 1) void k_zstd_decod
                     for (uint32_t g0 = 0; g0 < bn && !err; g0 += 64) {
                         const uint32_t cnt = bn - g0 < 64 ? bn - g0 : 64;
                         const bool on = lane < cnt;
-                        const uint32_t ll = on ? S.seq_ll[g0 + lane] : 0, ml = on ? S.seq_ml[g0 + lane] : 0;
-                        const uint32_t ov = on ? S.seq_off[g0 + lane] : 4;
+                        const uint32_t ll = on ? S.seq_ll[buf][g0 + lane] : 0, ml = on ? S.seq_ml[buf][g0 + lane] : 0;
+                        const uint32_t ov = on ? S.seq_off[buf][g0 + lane] : 4;
                         uint32_t offset = ov - 3;
                         if (__ballot(on && ov <= 3) != 0ull || cnt < 3) {
                             if (no_rep && __ballot(on && ov <= 3) != 0ull) { err = E_CORRUPT; break; }
@@ -1050,7 +1047,7 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES == 4 ? 4 : 1) void k_zstd_decod
                         // a match may reach back over what exists when it starts; literals may not run out
                         const bool bad = on && ((uint64_t)offset > abs0 + produced + pinc - ml || lits + linc > lit_room);
                         if (__ballot(bad) != 0ull) { err = E_CORRUPT; break; }
-                        if (on) S.seq_off[g0 + lane] = offset;
+                        if (on) S.seq_off[buf][g0 + lane] = offset;
                         lits += uni(__shfl(linc, 63));
                         produced += uni(__shfl(pinc, 63));
                     }
@@ -1063,27 +1060,28 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES == 4 ? 4 : 1) void k_zstd_decod
                         S.err = err;
                         S.batch_n = bn;
                     }
-                }
-                __syncthreads();
-                DSTAMP(3);
-                if (S.err) break;
-                if constexpr (NWAVES == 4) {
-                    // execute.  Every wave follows the same control flow (the decisions depend only on the batch in LDS
-                    // and on counters each wave mirrors in registers); wave 0 does the window work, all waves share the
-                    // long direct copies.
-                    {
+                    prod_out = produced;
+                    lits_out = lits;
+                            };
+            if constexpr (NWAVES == 4) {
+                // Execute one decoded batch.  solo: wave 1 alone, no barrier inside (wave 0 is decoding the next batch meanwhile);
+                // otherwise the whole workgroup follows the same control flow (decisions depend only on the batch in LDS and on
+                // counters every wave mirrors), the worker wave does the window work and all waves share the long direct copies.
+                auto exec_batch = [&](const uint32_t buf, const uint32_t bn, const bool solo) {
                         uint64_t opos = S.out_pos;
                         uint32_t win_n = S.win_n, hist_n = S.hist_n, lpos = S.lit_pos;
                         const bool rle_lits = S.lit_kind == 1;
                         const uint8_t rle_byte = (uint8_t)S.lit_rle;
                         const uint32_t lane = tid & 63;
+                        const bool wk = solo ? (tid >> 6) == 1 : wave0;  // who does the window work
+                        const uint32_t ct = solo ? lane : tid;           // thread index inside cooperative copies
                         uint8_t *const W = S.ebuf;
                         bool dirty = false;
                         uint32_t si = 0;
                         while (si < bn) {
                             const uint32_t idx = si + lane;
                             const bool v = idx < bn;
-                            const uint32_t ll = v ? S.seq_ll[idx] : 0, ml = v ? S.seq_ml[idx] : 0, off = v ? S.seq_off[idx] : 1;
+                            const uint32_t ll = v ? S.seq_ll[buf][idx] : 0, ml = v ? S.seq_ml[buf][idx] : 0, off = v ? S.seq_off[buf][idx] : 1;
                             const uint32_t tot = ll + ml;
                             const uint64_t bigm = __ballot(v && (tot > WIN_SEQ_MAX || ll > WIN_SEQ_MAX));
                             const uint32_t nv = bn - si < 64 ? bn - si : 64;
@@ -1091,30 +1089,30 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES == 4 ? 4 : 1) void k_zstd_decod
                             if (ncand == 0) {
                                 // ---- one long sequence, straight to HBM (the window is emptied first) ----
                                 if (win_n) {
-                                    if (wave0) (void)win_flush(W, out, opos, win_n, hist_n, lane, false);
+                                    if (wk) (void)win_flush(W, out, opos, win_n, hist_n, lane, false);
                                     opos += win_n;
                                     win_n = 0;
-                                    __syncthreads();
+                                    if (!solo) __syncthreads();
                                 }
                                 hist_n = 0;
-                                const uint32_t ll0 = S.seq_ll[si], ml0 = S.seq_ml[si], off0 = S.seq_off[si];
+                                const uint32_t ll0 = S.seq_ll[buf][si], ml0 = S.seq_ml[buf][si], off0 = S.seq_off[buf][si];
                                 if (ll0) {
-                                    const bool big = NWAVES > 1 && ll0 >= BIG_COPY;
-                                    if (big) __syncthreads();
-                                    if (big || wave0) {
+                                    const bool big = !solo && ll0 >= BIG_COPY;
+                                    if (big) __syncthreads();  // big implies !solo
+                                    if (big || wk) {
                                         const uint32_t nt = big ? NT : 64;
-                                        if (rle_lits) coop_fill(out + opos, rle_byte, ll0, tid, nt);
-                                        else coop_copy(out + opos, lit_ptr + lpos, ll0, tid, nt);
+                                        if (rle_lits) coop_fill(out + opos, rle_byte, ll0, ct, nt);
+                                        else coop_copy(out + opos, lit_ptr + lpos, ll0, ct, nt);
                                     }
-                                    if (big) __syncthreads();
+                                    if (big) __syncthreads();  // big implies !solo
                                     opos += ll0; lpos += ll0;
                                 }
                                 {
-                                    const bool big = NWAVES > 1 && ml0 >= BIG_COPY;
-                                    if (big) __syncthreads();
-                                    else if (wave0) wave_mem_sync();
-                                    if (big || wave0) coop_match<NWAVES>(out + opos, off0, ml0, tid, big, S.ebuf);
-                                    if (big) __syncthreads();
+                                    const bool big = !solo && ml0 >= BIG_COPY;
+                                    if (big) __syncthreads();  // big implies !solo
+                                    else if (wk) wave_mem_sync();
+                                    if (big || wk) coop_match<NWAVES>(out + opos, off0, ml0, ct, big, S.ebuf);
+                                    if (big) __syncthreads();  // big implies !solo
                                     opos += ml0;
                                 }
                                 dirty = true;  // direct stores may still be in flight: whoever reads HBM back drains first
@@ -1131,7 +1129,7 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES == 4 ? 4 : 1) void k_zstd_decod
                             uint32_t fit = (uint32_t)__popcll(__ballot(lane < ncand && end <= WIN_CAP - win_n));
                             if (fit == 0) {  // chunk full: stream it out, keep the newest bytes as history
                                 uint32_t h = 0;
-                                if (wave0) h = win_flush(W, out, opos, win_n, hist_n, lane, true);
+                                if (wk) h = win_flush(W, out, opos, win_n, hist_n, lane, true);
                                 (void)h;
                                 hist_n = hist_n + win_n < WIN_HIST ? hist_n + win_n : WIN_HIST;
                                 opos += win_n;
@@ -1140,19 +1138,19 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES == 4 ? 4 : 1) void k_zstd_decod
                             }
                             if (dirty) {  // far matches / the history read-back below must see every direct store
                                 wave_mem_sync();
-                                __syncthreads();
+                                if (!solo) __syncthreads();
                                 dirty = false;
                             }
                             const uint32_t want_h = opos < WIN_HIST ? (uint32_t)opos : WIN_HIST;
                             if (win_n == 0 && hist_n < want_h) {
                                 // history lost to a direct copy / raw block: read the newest output back (it has landed:
                                 // every direct write above ends with a drain + barrier)
-                                if (wave0) {
+                                if (wk) {
                                     coop_copy(W + WIN_HIST - want_h, out + opos - want_h, want_h, lane, 64);
                                 }
                                 hist_n = want_h;
                             }
-                            if (wave0) {
+                            if (wk) {
                                 const bool on = lane < fit;
                                 win_exec_group(W, out, opos, hist_n, lane, on, WIN_HIST + win_n + (end - tot), ll, ml, off,
                                                lit_ptr + lpos + (lend - ll), rle_lits, rle_byte);
@@ -1162,10 +1160,46 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES == 4 ? 4 : 1) void k_zstd_decod
                             si += fit;
                         }
                         if (dirty) wave_mem_sync();  // with the barrier below: direct stores of this batch have landed
-                        __syncthreads();
-                        if (tid == 0) { S.out_pos = opos; S.win_n = win_n; S.hist_n = hist_n; S.lit_pos = lpos; }
+                        if (!solo) __syncthreads();
+                        if (wk && lane == 0) { S.out_pos = opos; S.win_n = win_n; S.hist_n = hist_n; S.lit_pos = lpos; }
+                                    };
+                // wave 0 decodes batch k+1 while wave 1 executes batch k; the last batch of a block is executed by everyone
+                uint64_t d_abs0 = S.out_pos + S.win_n - S.blk_base;  // the decoder's own running totals
+                uint32_t d_room = S.lit_len - S.lit_pos;
+                uint32_t bn = nseq < SEQ_BATCH ? nseq : SEQ_BATCH, buf = 0;
+                __syncthreads();
+                if (wave0 && bn) {
+                    uint64_t p_ = 0; uint32_t l_ = 0;
+                    decode_batch(0, bn, 0, d_abs0, d_room, p_, l_);
+                    d_abs0 += p_; d_room -= l_ <= d_room ? l_ : d_room;
+                }
+                __syncthreads();
+                DSTAMP(3);
+                while (bn && !S.err) {
+                    const uint32_t next0 = seq_done + bn;
+                    const uint32_t nbn = nseq - next0 < SEQ_BATCH ? nseq - next0 : SEQ_BATCH;
+                    if (nbn) {
+                        if (wave0) {
+                            uint64_t p_ = 0; uint32_t l_ = 0;
+                            decode_batch(next0, nbn, buf ^ 1, d_abs0, d_room, p_, l_);
+                            d_abs0 += p_; d_room -= l_ <= d_room ? l_ : d_room;
+                        } else if ((tid >> 6) == 1) exec_batch(buf, bn, true);
+                    } else exec_batch(buf, bn, false);
+                    __syncthreads();
+                    DSTAMP(4);
+                    seq_done = next0; bn = nbn; buf ^= 1;
+                }
+            } else {
+                while (seq_done < nseq) {
+                    const uint32_t bn = nseq - seq_done < SEQ_BATCH ? nseq - seq_done : SEQ_BATCH;
+                    __syncthreads();
+                    if (wave0) {
+                        uint64_t p_ = 0; uint32_t l_ = 0;
+                        decode_batch(seq_done, bn, 0, uni64(S.out_pos) + uni(S.win_n) - uni64(S.blk_base), uni(S.lit_len) - uni(S.lit_pos), p_, l_);
                     }
-                } else {
+                    __syncthreads();
+                    DSTAMP(3);
+                    if (S.err) break;
                     // execute: wave 0 walks the batch in order; long copies are shared by all waves
                     {
                         uint64_t opos = S.out_pos;
@@ -1173,7 +1207,7 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES == 4 ? 4 : 1) void k_zstd_decod
                         const bool rle_lits = S.lit_kind == 1;
                         const uint8_t rle_byte = (uint8_t)S.lit_rle;
                         for (uint32_t i = 0; i < bn; i++) {
-                            const uint32_t ll = S.seq_ll[i], ml = S.seq_ml[i], off = S.seq_off[i];
+                            const uint32_t ll = S.seq_ll[0][i], ml = S.seq_ml[0][i], off = S.seq_off[0][i];
                             if (ll) {
                                 const bool big = NWAVES > 1 && ll >= BIG_COPY;
                                 if (big) __syncthreads();
@@ -1197,10 +1231,10 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES == 4 ? 4 : 1) void k_zstd_decod
                         __syncthreads();
                         if (tid == 0) { S.out_pos = opos; S.lit_pos = lpos; }
                     }
+                                    seq_done += bn;
+                    __syncthreads();
+                    DSTAMP(4);
                 }
-                seq_done += bn;
-                __syncthreads();
-                DSTAMP(4);
             }
             if (S.err) break;
             if constexpr (NWAVES == 4) {
