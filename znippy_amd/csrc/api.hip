@@ -54,6 +54,7 @@ struct znippy_ctx {
     EncTables *enc_tabs = nullptr;
     // auxiliary stream: the write side hashes on it while the main stream encodes
     hipStream_t aux = nullptr;
+    uint8_t *lit_scratch_b = nullptr;  // literal scratch of the block-item launch (runs next to the general decoder)
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     // kernel timing
     std::vector<KTime> ktimes;
@@ -147,7 +148,7 @@ struct znippy_rows {
     uint32_t *pending_count = nullptr;
     // block items: compressed rows of >= 2 blocks are tried block by block first
     uint32_t n_cand = 0, n_items = 0;
-    uint32_t *cand_row = nullptr, *cand_base = nullptr, *cand_nblocks = nullptr;
+    uint32_t *cand_row = nullptr, *cand_base = nullptr, *cand_nblocks = nullptr, *pending2 = nullptr;
     uint32_t *item_row = nullptr, *item_k = nullptr, *item_src = nullptr, *row_flag = nullptr;
     DevPlan plan;
 };
@@ -269,6 +270,7 @@ void znippy_ctx_destroy(znippy_ctx *ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     for (auto &k : ctx->ktimes) { (void)hipEventDestroy(k.t0); (void)hipEventDestroy(k.t1); }
     if (ctx->lit_scratch) (void)hipFree(ctx->lit_scratch);
+    if (ctx->lit_scratch_b) (void)hipFree(ctx->lit_scratch_b);
     if (ctx->cursor) (void)hipFree(ctx->cursor);
     if (ctx->shim_in) (void)hipFree(ctx->shim_in);
     if (ctx->shim_out) (void)hipFree(ctx->shim_out);
@@ -341,7 +343,7 @@ void znippy_rows_destroy(znippy_rows *r) {
     (void)hipSetDevice(r->ctx->device);
     void *ptrs[] = {r->blob_off, r->blob_size, r->usize, r->out_off, r->compressed, r->checksum,
                     r->status, r->digests, r->counters, r->corrupt, r->list_a, r->pending,
-                    r->cand_row, r->cand_base, r->cand_nblocks, r->item_row, r->item_k, r->item_src, r->row_flag};
+                    r->cand_row, r->cand_base, r->cand_nblocks, r->item_row, r->item_k, r->item_src, r->row_flag, r->pending2};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (r->h_counters) (void)hipHostFree(r->h_counters);
@@ -427,7 +429,8 @@ int znippy_rows_create(znippy_ctx *ctx, const uint64_t *blob_offset, const uint6
             znippy_rows_destroy(r);
             return rc;
         }
-        if (hipMalloc(&r->item_src, 4 * (size_t)r->n_items) != hipSuccess || hipMalloc(&r->row_flag, std::max<size_t>(4 * (size_t)n, 16)) != hipSuccess) {
+        if (hipMalloc(&r->item_src, 4 * (size_t)r->n_items) != hipSuccess || hipMalloc(&r->row_flag, std::max<size_t>(4 * (size_t)n, 16)) != hipSuccess ||
+            hipMalloc(&r->pending2, std::max<size_t>(4 * (size_t)r->n_cand, 16)) != hipSuccess) {
             znippy_rows_destroy(r);
             return ZNIPPY_E_NOMEM;
         }
@@ -493,17 +496,23 @@ int znippy_decode_verify_rows_async(znippy_ctx *ctx, znippy_rows *r, const void 
         launch_fused_small(f, s);
         ktime_end(ctx);
     }
-    // 2a) block items: frames of >= 2 blocks, every block a work item (falls back to 2b per frame)
+    // 2) the two decode paths run side by side: block items (frames of >= 2 blocks, every block a work item) on the
+    //    auxiliary stream, the general decoder (single-block big rows + whatever the fused kernel handed over) on the
+    //    main one — each is latency-bound on its own and leaves most of the chip idle.  Frames the block path gives up
+    //    on are decoded by a second general launch afterwards.
+    BlockScanArgs b{};
     if (r->n_cand) {
-        BlockScanArgs b{};
+        if (!ctx->lit_scratch_b && hipMalloc(&ctx->lit_scratch_b, decode_lit_scratch_bytes(ctx->decode_grid)) != hipSuccess) return ZNIPPY_E_NOMEM;
         b.cand_row = r->cand_row; b.cand_base = r->cand_base; b.cand_nblocks = r->cand_nblocks; b.n_cand = r->n_cand;
         b.blobs = (const uint8_t *)d_blobs; b.blob_base = blob_base;
         b.blob_off = r->blob_off; b.blob_size = r->blob_size; b.usize = r->usize; b.out_off = r->out_off; b.out_cap = out_cap;
         b.item_src = r->item_src; b.row_flag = r->row_flag; b.status = r->status;
-        b.pending = r->pending; b.pending_count = r->pending_count;
-        ktime_begin(ctx, "zstd_block_scan");
-        launch_scan_blocks(b, s);
-        ktime_end(ctx);
+        b.pending = r->pending2; b.pending_count = r->pending_count + 1;  // its own hand-over list (count: second word of the control block)
+        HIPCHK(ctx, hipEventRecord(ctx->ev_fork, s));
+        HIPCHK(ctx, hipStreamWaitEvent(ctx->aux, ctx->ev_fork, 0));
+        ktime_begin(ctx, "zstd_block_scan", ctx->aux);
+        launch_scan_blocks(b, ctx->aux);
+        ktime_end(ctx, ctx->aux);
         DecodeArgs a{};
         a.block_mode = 1;
         a.item_row = r->item_row; a.item_k = r->item_k; a.item_src = r->item_src; a.n_items = r->n_items; a.row_flag = r->row_flag;
@@ -514,24 +523,24 @@ int znippy_decode_verify_rows_async(znippy_ctx *ctx, znippy_rows *r, const void 
         a.compressed = r->compressed;
         a.out = (uint8_t *)d_out; a.out_cap = out_cap;
         a.status = r->status; a.n_rows = r->n; a.cursor = ctx->cursor + 4;
-        a.lit_scratch = ctx->lit_scratch;
+        a.lit_scratch = ctx->lit_scratch_b;
         if (getenv("ZNIPPY_DDBG")) {  // diagnostic: phase shares of the previous block-item launch
             static unsigned long long *dbg = nullptr;
             if (!dbg) { (void)hipMalloc(&dbg, 64); (void)hipMemset(dbg, 0, 64); }
             unsigned long long h[8];
             (void)hipStreamSynchronize(s);
+            (void)hipStreamSynchronize(ctx->aux);
             (void)hipMemcpy(h, dbg, 64, hipMemcpyDeviceToHost);
             if (h[0]) fprintf(stderr, "[znippy ddbg] block items=%llu  cycles per item: literals=%.0f seq-tables=%.0f seq-decode=%.0f execute=%.0f tail=%.0f\n", h[0],
                               (double)h[1] / h[0], (double)h[2] / h[0], (double)h[3] / h[0], (double)h[4] / h[0], (double)h[5] / h[0]);
             (void)hipMemset(dbg, 0, 64);
             a.dbg = dbg;
         }
-        ktime_begin(ctx, "zstd_decode_blocks");
-        launch_decode(a, std::min<int>(ctx->decode_grid, (int)r->n_items), false, s);
-        ktime_end(ctx);
-        launch_finish_blocks(b, s);
+        ktime_begin(ctx, "zstd_decode_blocks", ctx->aux);
+        launch_decode(a, std::min<int>(ctx->decode_grid, (int)r->n_items), false, ctx->aux);
+        ktime_end(ctx, ctx->aux);
+        HIPCHK(ctx, hipEventRecord(ctx->ev_join, ctx->aux));
     }
-    // 2b) general decoder: big compressed rows + whatever the fused kernel / the block path handed over
     if (r->n_compressed) {
         DecodeArgs a{};
         a.list_a = r->list_a; a.n_list_a = r->n_list_a;
@@ -546,6 +555,16 @@ int znippy_decode_verify_rows_async(znippy_ctx *ctx, znippy_rows *r, const void 
         ktime_begin(ctx, "zstd_decode_general");
         launch_decode(a, std::min<int>(ctx->decode_grid, (int)r->n_compressed), r->wide_rows, s);
         ktime_end(ctx);
+        if (r->n_cand) {  // join, then the frames the block path gave up on
+            HIPCHK(ctx, hipStreamWaitEvent(s, ctx->ev_join, 0));
+            launch_finish_blocks(b, s);
+            a.list_a = nullptr; a.n_list_a = 0;
+            a.pending = r->pending2; a.pending_count = r->pending_count + 1;
+            a.cursor = ctx->cursor + 8;
+            ktime_begin(ctx, "zstd_decode_fallback");
+            launch_decode(a, std::min<int>(ctx->decode_grid, (int)r->n_cand), r->wide_rows, s);
+            ktime_end(ctx);
+        }
     }
     // 3) second hash pass: slices of big rows + rows the general decoder finished
     h.pass = 2;  // PASS_SECOND
