@@ -863,6 +863,17 @@ extern "C" int znippy_encode_hash_rounds_async(znippy_ctx *ctx, znippy_rounds *r
     a.src = (const uint8_t *)d_src; a.src_off = r->src_off; a.len = r->len;
     a.prov = ctx->enc_prov; a.seq_scratch = ctx->enc_seq;
     a.piece_len = r->piece_len; a.piece_start = r->piece_start; a.tabs = ctx->enc_tabs;
+    if (getenv("ZNIPPY_EDBG")) {  // diagnostic: phase shares of the previous run's wide-variant blocks
+        static unsigned long long *dbg = nullptr;
+        if (!dbg) { (void)hipMalloc(&dbg, 64); (void)hipMemset(dbg, 0, 64); }
+        unsigned long long h[8];
+        (void)hipStreamSynchronize(s);
+        (void)hipMemcpy(h, dbg, 64, hipMemcpyDeviceToHost);
+        if (h[0]) fprintf(stderr, "[znippy edbg] wide blocks=%llu  cycles per block: setup=%.0f matching=%.0f literals=%.0f sequences=%.0f\n", h[0],
+                          (double)h[1] / h[0], (double)h[2] / h[0], (double)h[3] / h[0], (double)h[4] / h[0]);
+        (void)hipMemset(dbg, 0, 64);
+        a.dbg = dbg;
+    }
     ktime_begin(ctx, "zstd_encode");
     for (int wide = 1; wide >= 0; wide--) {  // the wide share first: its blocks are the long ones
         a.n_items = wide ? r->n_wide : r->n_small;

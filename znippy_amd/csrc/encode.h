@@ -43,6 +43,7 @@ struct EncodeArgs {
     const uint32_t *order;  // optional: indices into items[] this launch works through (NULL = 0..n_items-1)
     uint32_t n_items;       // entries in order[] (or in items[])
     const uint32_t *n_items_dev;  // optional: the count is read from the device instead (retry launch)
+    unsigned long long *dbg;  // diagnostic only (ZNIPPY_EDBG): [blocks, setup, matching, literals, sequences] cycle counters of the wide variant
     uint32_t *retry_list, *retry_count;  // small variant: blocks that ran out of sequence budget go here, for the wide variant
     uint32_t *cursor;
     uint32_t batch;  // items per cursor dequeue

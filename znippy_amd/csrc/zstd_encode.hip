@@ -516,6 +516,9 @@ __global__ __launch_bounds__(64) void k_zstd_encode(EncodeArgs a) {
         for (uint32_t o = lane * 128; o + 4 <= n; o += 64 * 128)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(in + o),
                                              (__attribute__((address_space(3))) void *)S.sink, 4, 0, 0);
+        unsigned long long t_last = (HASH_LOG == 13 && a.dbg) ? __builtin_amdgcn_s_memtime() : 0;
+#define ESTAMP(i) do { if (HASH_LOG == 13 && a.dbg && lane == 0) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); atomicAdd(&a.dbg[i], now_ - t_last); t_last = now_; } } while (0)
+        if (HASH_LOG == 13 && a.dbg && lane == 0) atomicAdd(&a.dbg[0], 1ull);
         // ---- match finding ----
         {
             uint4 *t4 = reinterpret_cast<uint4 *>(S.table);
@@ -523,6 +526,7 @@ __global__ __launch_bounds__(64) void k_zstd_encode(EncodeArgs a) {
             for (uint32_t i = lane; i < HASH_SIZE / 8; i += 64) t4[i] = ones;
         }
         __syncthreads();
+        ESTAMP(1);
         // Every block is self-contained: no match reaches in front of the block and no repeat-offset code is
         // used, so the blocks of a frame can be decoded independently (zstd_decode.hip, block items).  PRE > 0
         // would seed the block with the bytes in front of it (saves one literal run per block on periodic data).
@@ -530,7 +534,8 @@ __global__ __launch_bounds__(64) void k_zstd_encode(EncodeArgs a) {
         const uint8_t *const inb = in - PRE;
         const uint32_t nq = n + PRE;
         uint32_t nseq = 0, lit_total = 0;
-        uint32_t anchor = PRE;  // first byte not yet emitted
+        uint32_t anchor = PRE;  // first byte not yet covered by a sequence
+        uint32_t emitted = PRE; // wide variant: literal bytes [anchor, emitted) are already written
         uint32_t base = 0, misses = 0;
         const uint32_t scan_end = nq >= 8 ? nq - 7 : 0;  // positions with >= 8 bytes ahead
         if constexpr (HASH_LOG == 13) {
@@ -538,11 +543,25 @@ __global__ __launch_bounds__(64) void k_zstd_encode(EncodeArgs a) {
             // window's matches are picked left to right — several sequences per 64 positions on real data instead
             // of one.  Only a match that runs past LMAX is extended cooperatively (periodic data: 4 KiB per step).
             constexpr uint32_t LMAX = 64;
+            // Literals are written as the windows go by, straight from the bytes each lane has just loaded: input
+            // bytes [anchor, emitted) already sit behind lits + lit_total.  A sequence then costs stores only — no
+            // load/store round trip per match (that round trip was most of the matcher's time on real data).
             while (base < scan_end && nseq < max_seq) {
                 const uint32_t pos = base + lane;
-                uint32_t cand = 0, mlen = 0;
+                uint32_t cand = 0, mlen = 0, v = 0;
+                auto store_tail = [&]() {  // this window's bytes that no match of the window covers
+                    const uint32_t wend = base + 64 < nq ? base + 64 : nq;
+                    if (emitted < base) {  // a stretch skipped while accelerating through incompressible data
+                        wave_copy(lits + lit_total + (emitted - anchor), inb + emitted, base - emitted, lane);
+                        emitted = base;
+                    }
+                    if (emitted < wend) {
+                        if (pos >= emitted && pos < wend) lits[lit_total + (pos - anchor)] = pos < scan_end ? (uint8_t)v : inb[pos];
+                        emitted = wend;
+                    }
+                };
                 if (pos < scan_end) {
-                    const uint32_t v = ld32(inb + pos);
+                    v = ld32(inb + pos);
                     const uint32_t h = hash4<HASH_LOG>(v);
                     const uint32_t e = S.table[h];
                     S.table[h] = (uint16_t)pos;  // low 16 bits; candidates are within 64 KiB
@@ -569,6 +588,7 @@ __global__ __launch_bounds__(64) void k_zstd_encode(EncodeArgs a) {
                 }
                 const uint64_t hitm = __ballot(mlen != 0);
                 if (!hitm) {
+                    if (misses < 2) store_tail();  // a run of misses is incompressible data: leave it to one bulk copy later
                     misses++;
                     base += 64 * (1 + (misses >> 4 > 7 ? 7 : misses >> 4));  // accelerate through incompressible data
                     continue;
@@ -622,7 +642,13 @@ __global__ __launch_bounds__(64) void k_zstd_encode(EncodeArgs a) {
                 }
                     }
                     const uint32_t ll = mpos - anchor;
-                    wave_copy(lits + lit_total, inb + anchor, ll, lane);
+                    if (emitted < mpos) {  // literals of this sequence not written yet: the part inside the window
+                        if (emitted < base) {
+                            wave_copy(lits + lit_total + (emitted - anchor), inb + emitted, base - emitted, lane);
+                            emitted = base;
+                        }
+                        if (pos >= emitted && pos < mpos) lits[lit_total + (pos - anchor)] = (uint8_t)v;
+                    }
                     if (lane == 0) {
                         seqs[3 * nseq] = ll;
                         seqs[3 * nseq + 1] = ml - 3;
@@ -631,7 +657,9 @@ __global__ __launch_bounds__(64) void k_zstd_encode(EncodeArgs a) {
                     lit_total += ll;
                     nseq++;
                     anchor = mpos + ml;
+                    emitted = anchor;
                 }
+                store_tail();
                 base = anchor > base + 64 ? anchor : base + 64;
             }
         } else {
@@ -716,15 +744,20 @@ __global__ __launch_bounds__(64) void k_zstd_encode(EncodeArgs a) {
             if (lane == 0) a.retry_list[atomicAdd(a.retry_count, 1u)] = item_id;
             continue;
         }
-        // trailing literals
-        wave_copy(lits + lit_total, inb + anchor, nq - anchor, lane);
+        // trailing literals (the wide variant has written most of them already)
+        {
+            const uint32_t e0 = (HASH_LOG == 13 && emitted > anchor) ? emitted : anchor;
+            if (e0 < nq) wave_copy(lits + lit_total + (e0 - anchor), inb + e0, nq - e0, lane);
+        }
         lit_total += nq - anchor;
         __syncthreads();  // sequences + literal bytes of all lanes are visible to lane 0
 
+        ESTAMP(2);
         // ---- entropy stage: literals (Huffman in the wide variant when it pays), headers, sequences bitstream ----
         uint32_t lit_sec = 0;  // bytes of the literals section at blk + 3
         if (HASH_LOG == 13 && lit_total >= HUF_MIN_LITS)
             lit_sec = huf_literals(S, lits, lit_total, lits + ((lit_total + 3) & ~3u), blk + 3, lane);
+        ESTAMP(3);
         bool raw = nseq == 0 && lit_sec == 0;
         uint32_t csize = 0;
         if (!raw) {
@@ -784,6 +817,7 @@ __global__ __launch_bounds__(64) void k_zstd_encode(EncodeArgs a) {
             csize = (uint32_t)(p - (blk + 3));
             if (csize >= n) raw = true;
         }
+        ESTAMP(4);
         if (lane == 0) {
             uint32_t piece_len = 0, hdr_len = 0;
             if (!raw) {
