@@ -80,6 +80,32 @@ def test_world2_gloo_matches_single_process(tmp_path, oracle):
             assert a == e.data
 
 
+def test_world2_gloo_write_side_equals_single_process(tmp_path, oracle):
+    """SURVEY 8e, write side: each rank encodes a contiguous range of the Rounds, rank 0 concatenates the payload
+    regions (blob offsets rebased by a running sum) and writes the archive — byte-identical to the one-process
+    archive, same report on every rank."""
+    import _mr_write_worker as w
+    from oracle_backend import OracleBackend
+    c = compress_stream(tmp_path / "single.znippy", False, backend=OracleBackend())
+    for e in w.entries():
+        c.sender().send(e)
+    single = c.finish()
+    port = _free_port()
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE="2")
+    procs = []
+    for r in range(2):
+        e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "_mr_write_worker.py"), str(tmp_path / "multi.znippy"),
+                                       str(tmp_path / "rep.json")], env=e))
+    for p in procs:
+        assert p.wait(timeout=300) == 0
+    assert (tmp_path / "multi.znippy").read_bytes() == (tmp_path / "single.znippy").read_bytes()
+    for r in range(2):
+        assert json.load(open(f"{tmp_path / 'rep.json'}.{r}")) == single.__dict__
+    v = decompress_archive(tmp_path / "multi.znippy", False, None, backend=OracleBackend())
+    assert (v.corrupt_files, v.total_files) == (0, len(w.entries()))
+
+
 @pytest.mark.gpu
 def test_bench_n2_path_rehearsed_on_one_gpu():
     """bench.py's N>1 code path (rendezvous, per-step counter all-reduce on its own stream, barrier + MAX-over-ranks

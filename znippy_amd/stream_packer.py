@@ -91,45 +91,92 @@ def plan_rounds(entries: List[ArchiveEntry], no_skip: bool):
     return rounds, (uf, ub, cf, cb)
 
 
+def encode_round_range(rounds, entries, backend, lo, hi):
+    """The barrels' work for rounds [lo, hi): staging batches through the backend.  Returns the per-round columns
+    (blob_offset relative to this range's payload region) and the region's bytes."""
+    n = hi - lo
+    cols = dict(blob_offset=np.zeros(n, np.uint64), blob_size=np.zeros(n, np.uint64),
+                checksum=np.zeros((n, 32), np.uint8), compressed=np.zeros(n, np.uint8))
+    parts, cursor, i = [], 0, lo
+    while i < hi:
+        j, nbytes = i, 0
+        while j < hi and (j == i or nbytes + rounds[j][2] <= BATCH_BYTES):
+            nbytes += rounds[j][2]
+            j += 1
+        staging = np.empty(nbytes, dtype=np.uint8)
+        off = np.zeros(j - i, dtype=np.uint64)
+        ln = np.zeros(j - i, dtype=np.uint64)
+        sk = np.zeros(j - i, dtype=np.uint8)
+        pos = 0
+        for k, (fi, start, l, skip, _, _) in enumerate(rounds[i:j]):
+            if l:
+                staging[pos:pos + l] = np.frombuffer(entries[fi].data, dtype=np.uint8, count=l, offset=start)
+            off[k], ln[k], sk[k] = pos, l, 1 if skip else 0
+            pos += l
+        res, blob = backend.encode_hash(staging, off, ln, sk)
+        cols["blob_offset"][i - lo:j - lo] = np.asarray(res["blob_offset"], np.uint64) + np.uint64(cursor)
+        cols["blob_size"][i - lo:j - lo] = res["blob_size"]
+        cols["checksum"][i - lo:j - lo] = res["checksum"]
+        cols["compressed"][i - lo:j - lo] = res["compressed"]
+        parts.append(np.asarray(blob, np.uint8).tobytes())
+        cursor += len(parts[-1])
+        i = j
+    return cols, b"".join(parts)
+
+
 def run_pipeline(entries, output, no_skip, backend=None, config=None) -> ix.CompressionReport:
+    """Single process: all rounds.  Inside an initialised torch.distributed group every rank encodes a contiguous
+    range of the rounds balanced by bytes (its GPU's share), rank 0 concatenates the payload regions in rank order —
+    blob offsets are a running sum, so rebasing a region is one addition — and writes the archive; the
+    report is the same on every rank.  Every rank is handed the same entries."""
     from .backend import default_backend
+    from .sharding import split_rows
     backend = backend or default_backend()
     config = config or ix.CONFIG
     output_path = with_extension(output, "znippy")  # L132
     rounds, (uf, ub, cf, cb) = plan_rounds(entries, no_skip)
+    rank, world = 0, 1
+    try:
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized():
+            rank, world = dist.get_rank(), dist.get_world_size()
+    except ImportError:
+        dist = None
+    if world > 1:
+        lo, hi = split_rows([r[2] for r in rounds], world)[rank]
+        mine = encode_round_range(rounds, entries, backend, lo, hi)
+        gathered = [None] * world
+        dist.all_gather_object(gathered, mine)
+        report = [None]
+        if rank == 0:
+            base, col_parts, regions = 0, [], []
+            for cols, region in gathered:
+                cols = dict(cols)
+                cols["blob_offset"] = cols["blob_offset"] + np.uint64(base)
+                base += len(region)
+                col_parts.append(cols)
+                regions.append(region)
+            cols = {k: np.concatenate([c[k] for c in col_parts]) for k in col_parts[0]}
+            report[0] = _write_archive(output_path, entries, rounds, cols, b"".join(regions), (uf, ub, cf, cb), config)
+        dist.broadcast_object_list(report, src=0)
+        return report[0]
+    cols, region = encode_round_range(rounds, entries, backend, 0, len(rounds))
+    return _write_archive(output_path, entries, rounds, cols, region, (uf, ub, cf, cb), config)
 
+
+def _write_archive(output_path, entries, rounds, cols, region, counts, config) -> ix.CompressionReport:
+    uf, ub, cf, cb = counts
     blobs: List[ix.BlobMeta] = []
-    out_cursor = 0  # blob region starts at 0 (L134)
     with open(output_path, "wb+") as f:
-        # batches of Rounds over one staging buffer
-        i = 0
-        while i < len(rounds):
-            j, nbytes = i, 0
-            while j < len(rounds) and (j == i or nbytes + rounds[j][2] <= BATCH_BYTES):
-                nbytes += rounds[j][2]
-                j += 1
-            staging = np.empty(nbytes, dtype=np.uint8)
-            off = np.zeros(j - i, dtype=np.uint64)
-            ln = np.zeros(j - i, dtype=np.uint64)
-            sk = np.zeros(j - i, dtype=np.uint8)
-            pos = 0
-            for k, (fi, start, l, skip, _, _) in enumerate(rounds[i:j]):
-                if l:
-                    staging[pos:pos + l] = np.frombuffer(entries[fi].data, dtype=np.uint8, count=l, offset=start)
-                off[k], ln[k], sk[k] = pos, l, 1 if skip else 0
-                pos += l
-            res, blob = backend.encode_hash(staging, off, ln, sk)
-            # the writer: payloads appended at the running cursor (L255-284)
-            os.pwrite(f.fileno(), blob.tobytes(), out_cursor)
-            for k, (fi, start, l, skip, fdata_offset, chunk_seq) in enumerate(rounds[i:j]):
-                bsz = int(res["blob_size"][k])
-                blobs.append(ix.BlobMeta(
-                    ix.ChunkMeta(fdata_offset=fdata_offset, file_index=fi, chunk_seq=chunk_seq,
-                                 checksum=res["checksum"][k].tobytes(), compressed=bool(res["compressed"][k]),
-                                 uncompressed_size=l, compressed_size=bsz),
-                    blob_offset=out_cursor + int(res["blob_offset"][k]), blob_size=bsz))
-            out_cursor += len(blob)
-            i = j
+        os.pwrite(f.fileno(), region, 0)  # the writer: payloads from offset 0 in round order (L255-284)
+        out_cursor = len(region)
+        for k, (fi, start, l, skip, fdata_offset, chunk_seq) in enumerate(rounds):
+            bsz = int(cols["blob_size"][k])
+            blobs.append(ix.BlobMeta(
+                ix.ChunkMeta(fdata_offset=fdata_offset, file_index=fi, chunk_seq=chunk_seq,
+                             checksum=cols["checksum"][k].tobytes(), compressed=bool(cols["compressed"][k]),
+                             uncompressed_size=l, compressed_size=bsz),
+                blob_offset=int(cols["blob_offset"][k]), blob_size=bsz))
 
         # finalizer (L293-346)
         blobs.sort(key=lambda b: (b.chunk_meta.file_index, b.chunk_meta.chunk_seq))
