@@ -462,6 +462,7 @@ static int zr_decode_block(zr_frame_t *f, const uint8_t *src, size_t n, uint8_t 
                            size_t dst_pos, size_t dst_cap, size_t *produced) {
     zr_lits_t lits;
     size_t used, lit_at = 0, out = dst_pos;
+    memset(&lits, 0, sizeof lits);
     const uint8_t *p, *end = src + n;
     uint32_t nseq;
     int rc = zr_decode_literals(f, src, n, &lits, &used);
