@@ -402,11 +402,12 @@ int znippy_rows_create(znippy_ctx *ctx, const uint64_t *blob_offset, const uint6
     // item), the others go straight to the general decoder
     constexpr uint64_t BLK = 128 * 1024;
     std::vector<uint32_t> la, cand_row, cand_base, cand_nb, item_row, item_k;
-    uint64_t big_bytes = 0, n_big = 0;
+    uint64_t big_bytes = 0, big_blob = 0, n_big = 0;
     for (uint32_t i = 0; i < n; i++) {
         const uint64_t us = uncompressed_size[row_begin + i];
         if (!comp[i] || us <= 64 * 1024) continue;
         big_bytes += us;
+        big_blob += blob_size[row_begin + i];
         n_big++;
         const uint64_t nb = (us + BLK - 1) / BLK;
         if (nb >= 2 && us < 0xFFFFFFFFull && item_row.size() + nb < 0x7FFFFFFFull && !getenv("ZNIPPY_NO_BLOCK_ITEMS")) {
@@ -417,7 +418,10 @@ int znippy_rows_create(znippy_ctx *ctx, const uint64_t *blob_offset, const uint6
         } else la.push_back(i);
     }
     r->n_list_a = (uint32_t)la.size();
-    r->wide_rows = n_big && big_bytes / n_big >= (1u << 20);
+    // 1024-thread workgroups pay off where a few very long copies dominate (multi-MiB frames of periodic or stored
+    // data: a frame that is < 2 % of its content); entropy-coded frames are a serial bitstream and want the narrow
+    // variant's window execution instead, whatever their size
+    r->wide_rows = n_big && big_bytes / n_big >= (1u << 20) && big_blob * 50 < big_bytes;
     r->n_cand = (uint32_t)cand_row.size();
     r->n_items = (uint32_t)item_row.size();
     if (r->n_cand) {
