@@ -1314,7 +1314,8 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES == 4 ? 4 : 1) void k_zstd_decod
 // block items: header scan (one thread per candidate frame) and the per-row verdict afterwards
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(64) void k_scan_blocks(BlockScanArgs a) {
-    const uint32_t c = blockIdx.x * 64 + threadIdx.x;
+    // one wave per candidate frame; every lane runs the frame-header part on the same addresses (broadcast loads)
+    const uint32_t c = blockIdx.x, lane = threadIdx.x;
     if (c >= a.n_cand) return;
     const uint32_t row = a.cand_row[c], base = a.cand_base[c], nb = a.cand_nblocks[c];
     const uint8_t *src = a.blobs + (a.blob_off[row] - a.blob_base);
@@ -1336,52 +1337,72 @@ __global__ __launch_bounds__(64) void k_scan_blocks(BlockScanArgs a) {
             ok = ok && fcs == fcs_want && a.out_off[row] + fcs <= a.out_cap;  // anything odd: the serial pass reports it
         }
     }
+    // Block headers.  The position of a header is only known once the previous one has been read — a chain of
+    // dependent loads, 1,600 of them in a 200 MiB frame.  Blocks of periodic or stored data all have the same size,
+    // so lane i guesses "header i blocks ahead = pos + i * (size of the previous block)": when the guess holds the
+    // wave walks 64 headers per round trip, when it does not (real data) it advances by one, as before.
     uint32_t k = 0;
     bool last = false;
+    uint64_t stride = 0;  // 3 + payload bytes of the previous block (0: no guess yet)
     while (ok && !last) {
-        if (k >= nb || pos + 3 > n) { ok = false; break; }
-        const uint32_t bh = src[pos] | (src[pos + 1] << 8) | (src[pos + 2] << 16);
+        const uint64_t p_i = pos + (uint64_t)lane * stride;
+        const bool valid = (lane == 0 || stride != 0) && k + lane < nb && p_i + 3 <= n;
+        uint32_t bh = 0;
+        if (valid) bh = src[p_i] | (src[p_i + 1] << 8) | (src[p_i + 2] << 16);
         const uint32_t type = (bh >> 1) & 3, size = bh >> 3;
-        const uint64_t o0 = (uint64_t)k * BLOCK_MAX;
+        const bool lst = bh & 1;
+        const uint64_t step = 3 + (type == 1 ? 1 : size);
+        // lanes 0 .. run sit on real headers: every lane before them continued with exactly the guessed stride
+        const uint64_t contm = __ballot(valid && !lst && type != 3 && step == stride);
+        const uint32_t run = contm == ~0ull ? 63u : (uint32_t)__ffsll((long long)~contm) - 1;
+        const bool mine = lane <= run && valid;
+        if (__ballot(lane <= run && !valid) & 1ull) { ok = false; break; }  // lane 0 itself has no header to read
+        const uint32_t taken = (uint32_t)__popcll(__ballot(mine));
+        const uint64_t o0 = (uint64_t)(k + lane) * BLOCK_MAX;
         const uint64_t want = o0 + BLOCK_MAX < fcs_want ? BLOCK_MAX : fcs_want - o0;
-        last = bh & 1;
-        if (type == 3 || (type != 2 && size != want)) { ok = false; break; }  // raw / RLE blocks carry their size
-        // the first block gives the frame's style away: anything but predefined sequence tables means an encoder
-        // that also leans on repeat offsets and reused tables (libzstd) — such a frame would only waste the
-        // speculative pass
-        if (k == 0 && type == 2) {
-            const uint64_t b = pos + 3, bend = b + size;
-            bool style = bend <= n && size >= 2;
-            uint64_t q = b;
-            if (style) {
-                const uint32_t b0 = src[q], lt = b0 & 3, sf = (b0 >> 2) & 3;
-                uint64_t h = 0;
-                for (uint32_t i = 0; i < 5 && q + i < bend; i++) h |= (uint64_t)src[q + i] << (8 * i);
-                if (lt == 3) style = false;  // treeless: needs the previous block's tree
-                else if (lt <= 1) {
-                    const uint32_t lh = (sf & 1) == 0 ? 1 : (sf == 1 ? 2 : 3);
-                    const uint32_t regen = (uint32_t)((sf & 1) == 0 ? (h & 0xFF) >> 3 : (sf == 1 ? (h & 0xFFFF) >> 4 : (h & 0xFFFFFF) >> 4));
-                    q += lh + (lt == 0 ? regen : 1);
-                } else {
-                    const uint32_t lh = sf <= 1 ? 3 : (sf == 2 ? 4 : 5), nbits = sf <= 1 ? 10 : (sf == 2 ? 14 : 18);
-                    q += lh + (uint32_t)((h >> (4 + nbits)) & ((1u << nbits) - 1));
-                }
+        const bool bad = mine && (type == 3 || (type != 2 && size != want));  // raw / RLE blocks carry their size
+        if (__ballot(bad)) { ok = false; break; }
+        if (k == 0) {  // lane 0 of the first step: the frame's first block (all lanes run it, same addresses)
+            const uint32_t type0 = __shfl(type, 0), size0 = __shfl(size, 0);
+            if (type0 == 2) {
+                const uint32_t type = type0, size = size0;
+                (void)type;
+                    const uint64_t b = pos + 3, bend = b + size;
+                    bool style = bend <= n && size >= 2;
+                    uint64_t q = b;
+                    if (style) {
+                        const uint32_t b0 = src[q], lt = b0 & 3, sf = (b0 >> 2) & 3;
+                        uint64_t h = 0;
+                        for (uint32_t i = 0; i < 5 && q + i < bend; i++) h |= (uint64_t)src[q + i] << (8 * i);
+                        if (lt == 3) style = false;  // treeless: needs the previous block's tree
+                        else if (lt <= 1) {
+                            const uint32_t lh = (sf & 1) == 0 ? 1 : (sf == 1 ? 2 : 3);
+                            const uint32_t regen = (uint32_t)((sf & 1) == 0 ? (h & 0xFF) >> 3 : (sf == 1 ? (h & 0xFFFF) >> 4 : (h & 0xFFFFFF) >> 4));
+                            q += lh + (lt == 0 ? regen : 1);
+                        } else {
+                            const uint32_t lh = sf <= 1 ? 3 : (sf == 2 ? 4 : 5), nbits = sf <= 1 ? 10 : (sf == 2 ? 14 : 18);
+                            q += lh + (uint32_t)((h >> (4 + nbits)) & ((1u << nbits) - 1));
+                        }
+                    }
+                    if (style && q < bend) {
+                        const uint32_t s0 = src[q];
+                        const uint32_t hl = s0 == 0 ? 0 : (s0 < 128 ? 1 : (s0 < 255 ? 2 : 3));
+                        if (hl && (q + hl >= bend || src[q + hl] != 0)) style = false;  // modes byte: all Predefined
+                    } else style = false;
+                    if (!style) { ok = false; break; }
             }
-            if (style && q < bend) {
-                const uint32_t s0 = src[q];
-                const uint32_t hl = s0 == 0 ? 0 : (s0 < 128 ? 1 : (s0 < 255 ? 2 : 3));
-                if (hl && (q + hl >= bend || src[q + hl] != 0)) style = false;  // modes byte: all Predefined
-            } else style = false;
-            if (!style) { ok = false; break; }
         }
-        a.item_src[base + k] = (uint32_t)pos;
-        pos += 3 + (type == 1 ? 1 : size);
-        k++;
+        if (mine) a.item_src[base + k + lane] = (uint32_t)p_i;
+        const uint32_t lastl = taken - 1;  // the last lane taken decides where the walk continues
+        pos = __shfl(p_i, lastl) + __shfl(step, lastl);
+        stride = __shfl(step, lastl);
+        last = __shfl(lst ? 1u : 0u, lastl) != 0;
+        k += taken;
     }
     ok = ok && k == nb && pos == n;  // the expected number of blocks, nothing behind the last one
     if (!ok)
-        for (uint32_t i = 0; i < nb; i++) a.item_src[base + i] = 0xFFFFFFFFu;
-    a.row_flag[row] = ok ? 0u : 1u;
+        for (uint32_t i = lane; i < nb; i += 64) a.item_src[base + i] = 0xFFFFFFFFu;
+    if (lane == 0) a.row_flag[row] = ok ? 0u : 1u;
 }
 
 __global__ __launch_bounds__(64) void k_finish_blocks(BlockScanArgs a) {
@@ -1395,7 +1416,7 @@ __global__ __launch_bounds__(64) void k_finish_blocks(BlockScanArgs a) {
 }
 
 void launch_scan_blocks(const BlockScanArgs &a, hipStream_t s) {
-    if (a.n_cand) hipLaunchKernelGGL(k_scan_blocks, dim3((a.n_cand + 63) / 64), dim3(64), 0, s, a);
+    if (a.n_cand) hipLaunchKernelGGL(k_scan_blocks, dim3(a.n_cand), dim3(64), 0, s, a);
 }
 void launch_finish_blocks(const BlockScanArgs &a, hipStream_t s) {
     if (a.n_cand) hipLaunchKernelGGL(k_finish_blocks, dim3((a.n_cand + 63) / 64), dim3(64), 0, s, a);
