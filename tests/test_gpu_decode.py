@@ -242,3 +242,55 @@ def test_block_items_and_their_fallbacks(gpu_ctx, oracle):
     # timing names tell which path ran
     names = dict(gpu_ctx.kernel_times())
     assert "zstd_decode_blocks" in names and "zstd_block_scan" in names
+
+
+def _periodic(period, n, seed):
+    rng = np.random.default_rng(seed)
+    p = rng.integers(32, 127, size=period, dtype=np.uint8).tobytes()
+    return (p * (n // period + 1))[:n]
+
+
+@pytest.mark.parametrize("level", [1, 19])
+def test_periodic_rows_every_period_and_alignment(gpu_ctx, oracle, level):
+    """The lane-parallel recognised-row path of the fused kernel (literal prefix + one overlapping match):
+    periods 1..600, sizes that are whole leaves (hashed from the staged window) and ragged ones (hashed from the
+    output), output offsets of every alignment because the rows are packed back to back."""
+    rng = np.random.default_rng(5)
+    entries = []
+    for i, period in enumerate(list(range(1, 70)) + [100, 127, 128, 129, 255, 256, 257, 400, 511, 600]):
+        n = int(rng.integers(1, 40)) * 1024 if i % 3 else int(rng.integers(70, 40000))
+        entries.append(_periodic(period, n, i))
+    entries += [gen.text(10240)] * 40 + [gen.text(10239), gen.text(10241), gen.text(65536), gen.text(65), gen.text(64)]
+    arch = _build_archive(oracle, entries, level=level)
+    counters, corrupt, status, out, rt = _run_gpu(gpu_ctx, arch, pad_blobs=3)
+    assert (status == 0).all()
+    assert len(corrupt) == 0 and counters["verified_bytes"] == sum(len(e) for e in entries)
+    assert out.tobytes() == b"".join(entries)
+    assert np.array_equal(rt.digests(), arch["checksum"])
+
+
+def test_periodic_rows_from_this_encoder(gpu_ctx, oracle):
+    """Same shapes, frames written by the HIP encoder (what the fused kernel sees in practice)."""
+    import torch
+    from znippy_amd import hip
+    rng = np.random.default_rng(6)
+    entries = []
+    for i, period in enumerate(list(range(1, 70)) + [100, 128, 257, 600, 1000, 1024, 1025, 2000]):
+        n = int(rng.integers(1, 40)) * 1024 if i % 3 else int(rng.integers(70, 40000))
+        entries.append(_periodic(period, n, 100 + i))
+    entries += [gen.text(10240)] * 30
+    src = np.frombuffer(b"".join(entries), dtype=np.uint8)
+    lens = np.array([len(e) for e in entries], dtype=np.uint64)
+    offs = np.concatenate([[0], np.cumsum(lens)[:-1]]).astype(np.uint64)
+    d_src = torch.from_numpy(src.copy()).cuda()
+    rounds = hip.RoundTable(gpu_ctx, offs, lens)
+    d_blob = torch.zeros(rounds.blob_bound() + 64, dtype=torch.uint8, device="cuda")
+    enc = rounds.encode_hash(d_src, d_blob)
+    rows = hip.RowTable(gpu_ctx, enc["blob_offset"], enc["blob_size"], lens, offs, None, enc["checksum"])
+    d_out = torch.zeros(len(src) + 64, dtype=torch.uint8, device="cuda")
+    counters, corrupt, status = rows.decode_verify(d_blob, d_out)
+    assert (status == 0).all() and len(corrupt) == 0
+    assert counters["verified_bytes"] == len(src)
+    assert np.array_equal(d_out.cpu().numpy()[:len(src)], src)
+    for i in (0, 5, 40, len(entries) - 1):
+        assert bytes(enc["checksum"][i]) == oracle.blake3(entries[i])

@@ -571,6 +571,224 @@ __device__ int decode_simple(const uint8_t *src, uint32_t n, uint8_t *out, uint6
     return 0;
 }
 
+// ---- lane-parallel recognition of the common small-row shape ------------------------------------------
+// Most small rows of compressible data are ONE compressed block = raw literals + ONE sequence whose match
+// repeats a period lying inside those literals (a 10 KiB text chunk: 45 literal bytes + a 10,195-byte
+// match at offset 45).  Parsing such a frame is ~40 dependent steps; done as scalar code row after row
+// it was the longest serial chain of the kernel.  Here lane u parses row u on its own (every staged row
+// of the tile at once, straight-line code, no divergence), and a row that is not of this shape —
+// or is malformed in any way — is left to decode_simple, which reports the precise status.
+struct FastRow {
+    uint32_t ok, lit_at, L0, off;
+};
+struct FastTabs {  // lane i holds entry i: state -> base | addbits << 24 (LL, ML), state -> code (OF), code -> base | addbits << 24
+    uint32_t ll, ml, of, lls, mls;
+};
+__device__ __forceinline__ uint64_t lds8(const uint8_t *p) {
+    uint64_t v;
+    __builtin_memcpy(&v, p, 8);
+    return v;
+}
+__device__ __forceinline__ uint4 lds16(const uint8_t *p) {
+    uint4 v;
+    __builtin_memcpy(&v, p, 16);
+    return v;
+}
+__device__ __forceinline__ FastRow parse_fast(const uint8_t *w, uint32_t n, uint64_t usize, bool want, const FastTabs &T) {
+    bool ok = want && n >= 12 && n <= WIN && usize >= 65 && usize <= 0xFFFFFFull;
+    const uint64_t h0 = lds8(w);
+    ok &= (uint32_t)h0 == 0xFD2FB528u;
+    const uint32_t fhd = (uint32_t)(h0 >> 32) & 0xFF;
+    ok &= (fhd & 0x0F) == 0;  // no reserved bit, no content checksum, no dictionary id
+    const uint32_t single = (fhd >> 5) & 1, fcs_flag = fhd >> 6;
+    const uint32_t fcs_bytes = fcs_flag == 0 ? single : (1u << fcs_flag);
+    ok &= fcs_bytes != 0;
+    uint32_t pos = 6 - single;
+    uint64_t f = lds8(w + pos);
+    if (fcs_bytes < 8) f &= (1ull << (8 * fcs_bytes)) - 1;
+    if (fcs_bytes == 2) f += 256;
+    ok &= f == usize;
+    pos += fcs_bytes;  // <= 14
+    const uint64_t b = lds8(w + pos);  // block header (3 bytes) + literals header (<= 3)
+    const uint32_t bh = (uint32_t)b & 0xFFFFFF;
+    ok &= (bh & 7) == 5;  // last block, compressed
+    pos += 3;
+    ok &= pos + (bh >> 3) == n;
+    const uint32_t lh = (uint32_t)(b >> 24);
+    ok &= (lh & 3) == 0;  // raw literals
+    const uint32_t sf = (lh >> 2) & 3;
+    const uint32_t regen = (sf & 1) == 0 ? (lh & 0xFF) >> 3 : (sf == 1 ? (lh & 0xFFFF) >> 4 : (lh & 0xFFFFFF) >> 4);
+    const uint32_t lit_at = pos + ((sf & 1) == 0 ? 1u : sf);
+    ok &= regen <= WIN;
+    uint32_t sp = lit_at + regen;  // sequences section
+    ok &= sp + 3 <= n;
+    sp = ok ? sp : 0;
+    const uint64_t sh = lds8(w + sp);
+    ok &= (sh & 0xFF) == 1;  // one sequence
+    const uint32_t modes = (uint32_t)(sh >> 8) & 0xFF;
+    const uint32_t m_ll = modes >> 6, m_of = (modes >> 4) & 3, m_ml = (modes >> 2) & 3;
+    ok &= (modes & 3) == 0 && m_ll <= 1 && m_of <= 1 && m_ml <= 1;  // predefined or RLE tables
+    uint32_t q = 2;
+    const uint32_t s_ll = (uint32_t)(sh >> 16) & 0xFF;
+    q += m_ll & 1;
+    const uint32_t s_of = (uint32_t)(sh >> (8 * q)) & 0xFF;
+    q += m_of & 1;
+    const uint32_t s_ml = (uint32_t)(sh >> (8 * q)) & 0xFF;
+    q += m_ml & 1;
+    ok &= (!m_ll || s_ll <= 35) && (!m_of || s_of <= 31) && (!m_ml || s_ml <= 52);
+    const uint32_t bs = sp + q;  // the bitstream: at most 8 bytes, held in one register
+    ok &= bs < n && n - bs <= 8;
+    const uint32_t slen = ok ? n - bs : 1;
+    const uint64_t cw = lds8(w + (ok ? n - 8 : 0));
+    const uint32_t lastb = (uint32_t)(cw >> 56);
+    ok &= lastb != 0;
+    int32_t bp = (int32_t)(slen * 8) - (int32_t)(8 - fhib(lastb | 1));
+    const int32_t base = 64 - 8 * (int32_t)slen;
+    auto rd = [&](uint32_t nb) -> uint32_t {  // nb <= 31; running out of bits leaves bp < 0 (checked once, below)
+        bp -= (int32_t)nb;
+        const int32_t s = bp + base;
+        return (uint32_t)((cw >> (s < 0 ? 0 : s)) & ((1ull << nb) - 1));
+    };
+    const uint32_t st_ll = m_ll ? 0 : rd(6);
+    const uint32_t st_of = m_of ? 0 : rd(5);
+    const uint32_t st_ml = m_ml ? 0 : rd(6);
+    const uint32_t e_ll_s = __shfl(T.ll, st_ll & 63), e_ll_r = __shfl(T.lls, s_ll & 63);
+    const uint32_t e_ml_s = __shfl(T.ml, st_ml & 63), e_ml_r = __shfl(T.mls, s_ml & 63);
+    const uint32_t c_of_s = __shfl(T.of, st_of & 31);
+    const uint32_t e_ll = m_ll ? e_ll_r : e_ll_s, e_ml = m_ml ? e_ml_r : e_ml_s, c_of = (m_of ? s_of : c_of_s) & 31;
+    const uint32_t ov = (1u << c_of) + rd(c_of);
+    const uint32_t ml = (e_ml & 0xFFFFFF) + rd(e_ml >> 24);
+    const uint32_t ll = (e_ll & 0xFFFFFF) + rd(e_ll >> 24);
+    ok &= bp == 0;
+    // first sequence of the frame, ll > 0: repeat codes 1..3 mean the initial offsets 1, 4, 8 (RFC 8878 3.1.1.5)
+    const uint32_t off = ov > 3 ? ov - 3 : (ov == 1 ? 1u : (ov == 2 ? 4u : 8u));
+    ok &= ll == regen && ll >= 1 && (uint64_t)ll + ml == usize && off <= ll && off < ml && off <= EOFF_MAX && ml >= 64 &&
+          lit_at + ll + 64 <= WSTRIDE;
+    FastRow r;
+    r.ok = ok ? 1u : 0u; r.lit_at = lit_at; r.L0 = ll; r.off = off;
+    return r;
+}
+
+// x mod d for per-lane x < 2^22 and wave-uniform d >= 1 (inv = 1/d): float quotient, off by at most one
+__device__ __forceinline__ uint32_t lmod(uint32_t x, uint32_t d, float inv) {
+    const uint32_t q = (uint32_t)((float)x * inv);
+    int32_t r = (int32_t)(x - q * d);
+    if (r < 0) r += (int32_t)d;
+    else if ((uint32_t)r >= d) r -= (int32_t)d;
+    return (uint32_t)r;
+}
+
+// Writing the recognised rows: out[i] = Y[i] for i < L0, Y[B + (i - B) mod off] after that (B = L0 - off), with
+// Y = the row's literals in the staged window, extended by 64 bytes of the period, so that any 16 output
+// bytes are 16 CONTIGUOUS bytes of Y — at i itself (i + 16 <= L0 + 64) or inside the period copy at B + r.
+// The whole row goes out as aligned 16-byte stores read straight from the window, 1 KiB per wave-instruction,
+// with no expansion buffer and no dependence on bytes already written — which is what lets the stores be
+// issued a few at a time BETWEEN the BLAKE3 compressions of the tile (the hash reads the same windows, not
+// the output): the write traffic of a tile is spread over its hash instead of arriving as one burst that
+// every wave of the chip issues at the same moment.
+struct Emitter {
+    uint8_t *WL;       // this wave's staged windows
+    uint8_t *outbase;  // output region
+    uint32_t lane;
+    // lane u = row u of the tile
+    uint32_t f_lit, f_L0, f_off, c_len_lo;
+    uint64_t c_oo;
+    // schedule (wave-uniform)
+    uint32_t todo;   // bit u: recognised row u not opened yet
+    uint32_t total;  // trips of all rows (pacing)
+    uint32_t done;
+    // the open row (wave-uniform) and this lane's position in it
+    uint32_t open_, i0, body16, off, step, B, lim;
+    uint8_t *Y, *out;
+    uint32_t x, r;  // per lane: byte position of piece i0 + lane, (x - B) mod off
+
+    // extend every recognised row's window by 64 period bytes (the hash and the trips both rely on it)
+    __device__ __forceinline__ void prepare(uint32_t mask) {
+        todo = mask; total = 0; done = 0; open_ = 0;
+        for (uint32_t m = mask; m; m &= m - 1) {
+            const uint32_t u = (uint32_t)__builtin_ctz(m);
+            const uint32_t lit_at = __builtin_amdgcn_readlane(f_lit, u), L0 = __builtin_amdgcn_readlane(f_L0, u),
+                           o = __builtin_amdgcn_readlane(f_off, u);
+            uint8_t *y = WL + u * WSTRIDE + lit_at;
+            y[L0 + lane] = y[L0 - o + lmod(lane, o, 1.0f / (float)o)];
+            total += (__builtin_amdgcn_readlane(c_len_lo, u) + 4095) >> 12;
+        }
+    }
+    // one step = (open the next row: head and tail bytes) + one trip of up to four 1 KiB stores
+    __device__ __forceinline__ bool step_one() {
+        if (!open_) {
+            if (!todo) return false;
+            const uint32_t u = (uint32_t)__builtin_ctz(todo);
+            todo &= todo - 1;
+            const uint32_t lit_at = __builtin_amdgcn_readlane(f_lit, u), L0 = __builtin_amdgcn_readlane(f_L0, u);
+            off = __builtin_amdgcn_readlane(f_off, u);
+            const uint32_t osize = __builtin_amdgcn_readlane(c_len_lo, u);
+            const uint64_t oo = ((uint64_t)__builtin_amdgcn_readlane((uint32_t)(c_oo >> 32), u) << 32) |
+                                __builtin_amdgcn_readlane((uint32_t)c_oo, u);
+            out = outbase + oo;
+            Y = WL + u * WSTRIDE + lit_at;
+            B = L0 - off;
+            lim = L0 + 64;
+            const float inv = 1.0f / (float)off;
+            const uint32_t head = (uint32_t)((16 - ((uintptr_t)out & 15)) & 15);
+            body16 = (osize - head) >> 4;  // whole 16-byte pieces (>= 3: a recognised row has >= 65 bytes)
+            step = smod(1024, off);
+            const uint32_t rb = smod(B, off);
+            if (lane < head) out[lane] = Y[lane];
+            const uint32_t tail = (osize - head) & 15, p = head + 16 * body16 + lane;
+            if (lane < tail) {
+                uint32_t rt = lmod(p, off, inv) + off - rb;
+                if (rt >= off) rt -= off;
+                out[p] = p < lim ? Y[p] : Y[B + rt];
+            }
+            x = head + 16 * lane;
+            r = lmod(x, off, inv) + off - rb;  // (x - B) mod off
+            if (r >= off) r -= off;
+            i0 = 0;
+            open_ = 1;
+        }
+        {
+            const uint32_t i = i0 + lane;
+            uint4 v0 = make_uint4(0, 0, 0, 0), v1 = v0, v2 = v0, v3 = v0;
+            const uint32_t r0 = r;
+            uint32_t r1 = r0 + step; if (r1 >= off) r1 -= off;
+            uint32_t r2 = r1 + step; if (r2 >= off) r2 -= off;
+            uint32_t r3 = r2 + step; if (r3 >= off) r3 -= off;
+            r = r3 + step; if (r >= off) r -= off;
+            const bool p0 = i < body16, p1 = i + 64 < body16, p2 = i + 128 < body16, p3 = i + 192 < body16;
+            if (p0) v0 = lds16(x + 16 <= lim ? Y + x : Y + B + r0);
+            if (p1) v1 = lds16(x + 1040 <= lim ? Y + x + 1024 : Y + B + r1);
+            if (p2) v2 = lds16(Y + B + r2);  // x + 2048 is past any window
+            if (p3) v3 = lds16(Y + B + r3);
+            uint8_t *d = out + x;
+            if (p0) *reinterpret_cast<uint4 *>(d) = v0;
+            if (p1) *reinterpret_cast<uint4 *>(d + 1024) = v1;
+            if (p2) *reinterpret_cast<uint4 *>(d + 2048) = v2;
+            if (p3) *reinterpret_cast<uint4 *>(d + 3072) = v3;
+            x += 4096;
+            i0 += 256;
+            if (i0 >= body16) open_ = 0;
+        }
+        return true;
+    }
+    __device__ __forceinline__ void drain() {
+        if (g_abl & 16) return;  // ablation: no stream-out
+        while (step_one()) {}
+    }
+};
+struct EmitHook {
+    static constexpr bool enabled = true;
+    Emitter *e;
+    __device__ __forceinline__ void operator()(uint32_t b) const {
+        if (g_abl & 16) return;
+        const uint32_t target = (e->total * (b + 1) + 15) >> 4;
+        while (e->done < target) {
+            if (!e->step_one()) { e->done = 0xFFFFFFFFu; break; }
+            e->done++;
+        }
+    }
+};
+
 __global__ __launch_bounds__(256, 4) void k_fused_small(FusedArgs a) {
     __shared__ __attribute__((aligned(16))) uint8_t s_E[4][EBUF];
     __shared__ __attribute__((aligned(16))) uint8_t s_W[4][WROWS * WSTRIDE];
@@ -615,6 +833,7 @@ __global__ __launch_bounds__(256, 4) void k_fused_small(FusedArgs a) {
     if (lane < WROWS) d_y[lane] = 0xFFFF;
     l_st[lane] = 0;
     uint32_t need_reread = 0;  // some compressed row of the tile must be hashed from its global output
+
     if (!(a.dbg & 2)) {
         const uint32_t nw = t.n_units < WROWS ? t.n_units : WROWS;
         uint2 wv[WROWS];
@@ -645,6 +864,35 @@ __global__ __launch_bounds__(256, 4) void k_fused_small(FusedArgs a) {
         }
     }
 
+    // every staged compressed row is parsed by its own lane; rows of the common shape never see the scalar parser
+    FastRow fr{0, 0, 0, 0};
+    if (!(a.dbg & (2 | 128))) {
+        FastTabs T;
+        {
+            const DTab eL = c_dll[lane], eM = c_dml[lane], eO = c_dof[lane & 31];
+            T.ll = eL.base | (uint32_t)eL.addbits << 24;
+            T.ml = eM.base | (uint32_t)eM.addbits << 24;
+            T.of = eO.addbits;
+            T.lls = lane < 36 ? c_llb[lane] | (uint32_t)c_lla[lane] << 24 : 0u;
+            T.mls = lane < 53 ? c_mlb[lane] | (uint32_t)c_mla[lane] << 24 : 0u;
+        }
+        const bool want = lane < t.n_units && lane < WROWS && c_sel && c_oo + c_len <= a.out_cap;
+        fr = parse_fast(WL + (lane < WROWS ? lane : 0) * WSTRIDE, c_bs, c_len, want, T);
+    }
+    const uint32_t fmask = (uint32_t)__ballot(fr.ok != 0);
+    Emitter em;
+    em.WL = WL; em.outbase = a.h.srcB; em.lane = lane;
+    em.f_lit = fr.lit_at; em.f_L0 = fr.L0; em.f_off = fr.off; em.c_len_lo = (uint32_t)c_len; em.c_oo = c_oo;
+    em.prepare(fmask);
+    if (fr.ok && !(a.dbg & 4)) {
+        d_y[lane] = (uint16_t)(lane * WSTRIDE + fr.lit_at);
+        d_B[lane] = (uint16_t)(fr.L0 - fr.off);
+        d_off[lane] = (uint16_t)fr.off;
+    }
+    // a tile with any ragged leaf is hashed by the generic leaf path, which reads every row from the output and has
+    // no room for side work: write the recognised rows before the hash
+    const bool early = __ballot(lane < t.n_units && (c_len == 0 || ((uint32_t)c_len & 1023) != 0)) != 0ull || (a.dbg & (1 | 4));
+    if (early && fmask) { em.drain(); need_reread = 1; }
     if (stamp) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); t1 = __builtin_amdgcn_s_memtime(); }
     // decode = short bursts of scalar parsing + store issue: let it issue ahead of SIMD-mates that are in
     // their VALU-bound hash phase, so the stores get out early and drain while this wave hashes
@@ -656,6 +904,7 @@ __global__ __launch_bounds__(256, 4) void k_fused_small(FusedArgs a) {
         const uint64_t ooff = ((uint64_t)uni((uint32_t)(__shfl(c_oo, u) >> 32)) << 32) | uni((uint32_t)__shfl(c_oo, u));
         const uint64_t soff = ((uint64_t)uni((uint32_t)(__shfl(c_src, u) >> 32)) << 32) | uni((uint32_t)__shfl(c_src, u));
         const uint32_t bsz = uni(__shfl(c_bs, u));
+        if (fmask >> u & 1) continue;  // recognised row: written by the emitter
         int rc;
         Periodic per;
         per.ok = 0;
@@ -686,8 +935,9 @@ __global__ __launch_bounds__(256, 4) void k_fused_small(FusedArgs a) {
     if (stamp) t2 = __builtin_amdgcn_s_memtime();
     if (!(a.dbg & 1)) {
         LdsSrc ls{WL, d_y, d_B, d_off, WROWS, l_st, c_len, c_src, c_oo, c_sel};
-        hash_tile<true, true>(a.h, t, &ls);
+        hash_tile<true, true, EmitHook>(a.h, t, &ls, EmitHook{&em});
     }
+    em.drain();
     if (stamp) {
         t3 = __builtin_amdgcn_s_memtime();
         if (lane == 0) {

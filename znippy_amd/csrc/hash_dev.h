@@ -107,8 +107,14 @@ struct LeafOut {
 
 // Leaf phase of one tile: every active lane compresses its 1 KiB leaf (16 blocks).  Every lane of the wave
 // must call it.
-template <bool COPY, bool LDSRC = false>
-__device__ __forceinline__ void hash_tile_leaves(const HashArgs &a, const Tile &t, const LdsSrc *ls, LeafOut &out) {
+// `hook(b)`: optional wave-wide side work between the compressions of the full-leaf path (all 64 lanes call
+// it, after block b's compression was issued); the fused kernel streams its decoded rows out there.
+struct NoHook {
+    static constexpr bool enabled = false;
+    __device__ __forceinline__ void operator()(uint32_t) const {}
+};
+template <bool COPY, bool LDSRC = false, class Hook = NoHook>
+__device__ __forceinline__ void hash_tile_leaves(const HashArgs &a, const Tile &t, const LdsSrc *ls, LeafOut &out, Hook hook = Hook()) {
     const uint32_t lane = threadIdx.x & 63;
     uint32_t unit, k, unit_leaves, seg_start, local = 0xFFFFFFFFu;
     bool active = lane < t.n_leaves;
@@ -201,41 +207,51 @@ __device__ __forceinline__ void hash_tile_leaves(const HashArgs &a, const Tile &
             r = (p1 - yB) % yoff;
             step64 = 64 % yoff;
         }
-        if (active) {
-            uint4 n0, n1, n2, n3;
-            uint32_t p = (uint32_t)leaf_off;  // row position of the next block (LDS path)
-            auto fetch = [&](uint32_t b) {
-                if (LDSRC && Y) {
-                    const uint8_t *q = Y + p;
-                    if (p > yL0) {
-                        q = Y + yB + r;
-                        r += step64;
-                        if (r >= yoff) r -= yoff;
-                    }
-                    __builtin_memcpy(&n0, q, 16); __builtin_memcpy(&n1, q + 16, 16);
-                    __builtin_memcpy(&n2, q + 32, 16); __builtin_memcpy(&n3, q + 48, 16);
-                    p += 64;
-                } else {
-                    const uint8_t *q = src + b * 64;
-                    n0 = ld16(q); n1 = ld16(q + 16); n2 = ld16(q + 32); n3 = ld16(q + 48);
+        uint4 n0, n1, n2, n3;
+        uint32_t p = (uint32_t)leaf_off;  // row position of the next block (LDS path)
+        auto fetch = [&](uint32_t b) {
+            if (LDSRC && Y) {
+                const uint8_t *q = Y + p;
+                if (p > yL0) {
+                    q = Y + yB + r;
+                    r += step64;
+                    if (r >= yoff) r -= yoff;
                 }
-            };
-            fetch(0);
+                __builtin_memcpy(&n0, q, 16); __builtin_memcpy(&n1, q + 16, 16);
+                __builtin_memcpy(&n2, q + 32, 16); __builtin_memcpy(&n3, q + 48, 16);
+                p += 64;
+            } else {
+                const uint8_t *q = src + b * 64;
+                n0 = ld16(q); n1 = ld16(q + 16); n2 = ld16(q + 32); n3 = ld16(q + 48);
+            }
+        };
+        auto block = [&](uint32_t b) {
+            uint32_t m[16] = {n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, n1.z, n1.w,
+                              n2.x, n2.y, n2.z, n2.w, n3.x, n3.y, n3.z, n3.w};
+            if (b < 15) fetch(b + 1);
+            if (COPY && dst) {
+                uint8_t *d = dst + b * 64;
+                st16(d, make_uint4(m[0], m[1], m[2], m[3]));
+                st16(d + 16, make_uint4(m[4], m[5], m[6], m[7]));
+                st16(d + 32, make_uint4(m[8], m[9], m[10], m[11]));
+                st16(d + 48, make_uint4(m[12], m[13], m[14], m[15]));
+            }
+            const uint32_t flags = (b == 0 ? b3::CHUNK_START : 0u) |
+                                   (b == 15 ? (b3::CHUNK_END | (single ? b3::ROOT : 0u)) : 0u);
+            b3::compress(cv, m, k, 0, 64, flags);
+        };
+        if constexpr (Hook::enabled) {
+            if (active) fetch(0);
 #pragma unroll 1
             for (uint32_t b = 0; b < 16; b++) {
-                uint32_t m[16] = {n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, n1.z, n1.w,
-                                  n2.x, n2.y, n2.z, n2.w, n3.x, n3.y, n3.z, n3.w};
-                if (b < 15) fetch(b + 1);
-                if (COPY && dst) {
-                    uint8_t *d = dst + b * 64;
-                    st16(d, make_uint4(m[0], m[1], m[2], m[3]));
-                    st16(d + 16, make_uint4(m[4], m[5], m[6], m[7]));
-                    st16(d + 32, make_uint4(m[8], m[9], m[10], m[11]));
-                    st16(d + 48, make_uint4(m[12], m[13], m[14], m[15]));
-                }
-                const uint32_t flags = (b == 0 ? b3::CHUNK_START : 0u) |
-                                       (b == 15 ? (b3::CHUNK_END | (single ? b3::ROOT : 0u)) : 0u);
-                b3::compress(cv, m, k, 0, 64, flags);
+                if (active) block(b);
+                hook(b);
+            }
+        } else {
+            if (active) {
+                fetch(0);
+#pragma unroll 1
+                for (uint32_t b = 0; b < 16; b++) block(b);
             }
         }
     } else {
@@ -281,10 +297,10 @@ __device__ __forceinline__ void fold_tile_now(const HashArgs &a, const Tile &t, 
 }
 
 // Hash one tile with the calling wavefront.  Every lane of the wave must call it.
-template <bool COPY, bool LDSRC = false>
-__device__ __forceinline__ void hash_tile(const HashArgs &a, const Tile &t, const LdsSrc *ls = nullptr) {
+template <bool COPY, bool LDSRC = false, class Hook = NoHook>
+__device__ __forceinline__ void hash_tile(const HashArgs &a, const Tile &t, const LdsSrc *ls = nullptr, Hook hook = Hook()) {
     LeafOut lo;
-    hash_tile_leaves<COPY, LDSRC>(a, t, ls, lo);
+    hash_tile_leaves<COPY, LDSRC, Hook>(a, t, ls, lo, hook);
     fold_tile_now(a, t, lo);
 }
 
