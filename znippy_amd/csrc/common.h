@@ -94,6 +94,8 @@ struct FusedArgs {
     unsigned long long *dbg_buf;  // diagnostic stamps (ZNIPPY_DBG & 8)
     uint32_t lds_pad;  // extra dynamic LDS per block: caps blocks/CU (in-flight footprint vs Infinity Cache)
     uint32_t stagger;  // start-up skew per hardware wave slot, in units of 127*64 cycles
+    uint32_t *tile_cursor;  // atomic work cursor of the persistent blocks (zeroed before the launch)
+    uint32_t grid;          // resident blocks: 4 per CU
 };
 
 void launch_hash_tiles(const HashArgs &a, hipStream_t s);

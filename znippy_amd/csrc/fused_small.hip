@@ -20,8 +20,8 @@
 
 namespace zn {
 
-constexpr uint32_t EOFF_MAX = 1024;             // longest period expanded in LDS
-constexpr uint32_t EBUF = EOFF_MAX + 1024 + 64; // pattern buffer per wave
+constexpr uint32_t EOFF_MAX = 960;              // longest period expanded in LDS
+constexpr uint32_t EBUF = EOFF_MAX + 1024 + 64; // pattern buffer per wave (= 2 KiB: it shares the wave's slice of the fold nodes)
 constexpr int F_E_CORRUPT = -5, F_E_UNSUP = -6, F_E_DST = -4;
 constexpr int F_NOT_SIMPLE = 1;
 
@@ -776,42 +776,30 @@ struct Emitter {
         while (step_one()) {}
     }
 };
-struct EmitHook {
-    static constexpr bool enabled = true;
-    Emitter *e;
-    __device__ __forceinline__ void operator()(uint32_t b) const {
-        if (g_abl & 16) return;
-        const uint32_t target = (e->total * (b + 1) + 15) >> 4;
-        while (e->done < target) {
-            if (!e->step_one()) { e->done = 0xFFFFFFFFu; break; }
-            e->done++;
-        }
-    }
+// The parent trees of a block's four tiles are folded TOGETHER by one of its waves: a parent level costs a whole
+// compress pass of a wave however few lanes take part (a tile of six 10-leaf rows: 4 passes with 30, 12, 6, 6 busy
+// lanes), so every wave leaves its leaf chaining values and unit shapes in LDS and one wave folds all of them with
+// the nodes of a level packed over its 64 lanes — 6 passes for the block instead of 4 x 4.
+struct BlockFold {
+    uint32_t *nodes;                // 4 x 64 chaining values
+    uint32_t *tab_n, *tab_off, *tab_out;  // 4 x FOLD_UNITS unit descriptors (n = 0: nothing to fold)
 };
+constexpr uint32_t FOLD_UNITS = 16;  // tiles with more units fold on the spot
 
-__global__ __launch_bounds__(256, 4) void k_fused_small(FusedArgs a) {
-    __shared__ __attribute__((aligned(16))) uint8_t s_E[4][EBUF];
+__device__ __forceinline__ void fused_tile(const FusedArgs &a, const uint32_t wave, const BlockFold &bf) {
     __shared__ __attribute__((aligned(16))) uint8_t s_W[4][WROWS * WSTRIDE];
     const uint32_t lane = threadIdx.x & 63;
-    const uint32_t wave = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (wave >= a.h.n_tiles) return;
     const Tile t = a.h.tiles[wave];
     if (t.n_units == 0) return;  // slices of big rows: general decoder + second hash pass
-    uint8_t *const E = s_E[threadIdx.x >> 6];
+    // the pattern buffer of the scalar decoder lives in this wave's slice of the node array it fills at the end
+    static_assert(EBUF <= 64 * 8 * 4, "pattern buffer must fit the wave's node slice");
+    uint8_t *const E = reinterpret_cast<uint8_t *>(bf.nodes + (size_t)(threadIdx.x >> 6) * 64 * 8);
     uint8_t *const WL = s_W[threadIdx.x >> 6];
     const bool stamp = (a.dbg & 8) && a.dbg_buf;  // diagnostic only: phase durations -> a.dbg_buf (never an output)
     __shared__ unsigned long long s_acc[4][8];
     if (lane < 8) s_acc[threadIdx.x >> 6][lane] = 0;
     unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0;
     if (stamp) t0 = __builtin_amdgcn_s_memtime();
-
-    // Stagger: waves sharing a SIMD run the same decode(memory)->hash(VALU) program and fall into
-    // lockstep (all waiting, then all contending for VALU).  Delaying the wave in hardware slot k by
-    // k quanta puts SIMD-mates in different phases so one wave's stores overlap another's hashing.
-    if (a.stagger) {
-        const uint32_t slot = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4) & 15;  // HW_REG_HW_ID.wave_id
-        for (uint32_t i = 0; i < (slot & 3) * a.stagger; i++) __builtin_amdgcn_s_sleep(127);
-    }
 
     // ---- tile prologue: the rows' index columns, one row per lane (coalesced), then the first
     // WIN bytes of up to WROWS frames staged into LDS with all loads in flight at once ----
@@ -893,6 +881,7 @@ __global__ __launch_bounds__(256, 4) void k_fused_small(FusedArgs a) {
     // no room for side work: write the recognised rows before the hash
     const bool early = __ballot(lane < t.n_units && (c_len == 0 || ((uint32_t)c_len & 1023) != 0)) != 0ull || (a.dbg & (1 | 4));
     if (early && fmask) { em.drain(); need_reread = 1; }
+    // otherwise every leaf of the tile is full and the recognised rows are written by the lanes that hash them
     if (stamp) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); t1 = __builtin_amdgcn_s_memtime(); }
     // decode = short bursts of scalar parsing + store issue: let it issue ahead of SIMD-mates that are in
     // their VALU-bound hash phase, so the stores get out early and drain while this wave hashes
@@ -934,10 +923,26 @@ __global__ __launch_bounds__(256, 4) void k_fused_small(FusedArgs a) {
     if (need_reread) fwave_mem_sync();
     if (stamp) t2 = __builtin_amdgcn_s_memtime();
     if (!(a.dbg & 1)) {
-        LdsSrc ls{WL, d_y, d_B, d_off, WROWS, l_st, c_len, c_src, c_oo, c_sel};
-        hash_tile<true, true, EmitHook>(a.h, t, &ls, EmitHook{&em});
+        LdsSrc ls{WL, d_y, d_B, d_off, WROWS, l_st, c_len, c_src, c_oo, c_sel, (early || (g_abl & 16)) ? 0u : fmask};
+        LeafOut lo;
+        hash_tile_leaves<true, true>(a.h, t, &ls, lo);
+        if (t.n_units <= FOLD_UNITS && !(a.dbg & 256)) {
+            const uint32_t w = threadIdx.x >> 6;
+            if (lo.active) {
+                uint4 *d = reinterpret_cast<uint4 *>(bf.nodes + (size_t)(w * 64 + lane) * 8);
+                d[0] = make_uint4(lo.cv[0], lo.cv[1], lo.cv[2], lo.cv[3]);
+                d[1] = make_uint4(lo.cv[4], lo.cv[5], lo.cv[6], lo.cv[7]);
+            }
+            const uint32_t act = __shfl(lo.active ? 1u : 0u, lo.u_head & 63);  // a unit is hashed as a whole or not at all
+            if (lane < t.n_units) {
+                bf.tab_n[w * FOLD_UNITS + lane] = act ? lo.u_cnt : 0u;
+                bf.tab_off[w * FOLD_UNITS + lane] = w * 64 + lo.u_head;
+                bf.tab_out[w * FOLD_UNITS + lane] = t.first_unit + lane;
+            }
+        } else {
+            fold_tile_now(a.h, t, lo);
+        }
     }
-    em.drain();
     if (stamp) {
         t3 = __builtin_amdgcn_s_memtime();
         if (lane == 0) {
@@ -948,6 +953,32 @@ __global__ __launch_bounds__(256, 4) void k_fused_small(FusedArgs a) {
             for (int q = 4; q < 8; q++) atomicAdd(&a.dbg_buf[q], s_acc[threadIdx.x >> 6][q]);
         }
     }
+}
+
+__device__ __forceinline__ void lds_barrier() {  // workgroup barrier that orders LDS only (pending global stores stay in flight)
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+__global__ __launch_bounds__(256, 4) void k_fused_small(FusedArgs a) {
+    __shared__ __attribute__((aligned(16))) uint32_t s_nodes[4 * 64 * 8];
+    __shared__ uint32_t s_tab[3][4 * FOLD_UNITS];
+    const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const BlockFold bf{s_nodes, s_tab[0], s_tab[1], s_tab[2]};
+    if (lane < FOLD_UNITS) bf.tab_n[w * FOLD_UNITS + lane] = 0;
+    const uint32_t wave = blockIdx.x * 4 + w;
+    if (wave < a.h.n_tiles) fused_tile(a, wave, bf);
+    lds_barrier();
+    // the folding wave changes from block to block, so that over the blocks resident on a CU the extra passes
+    // spread over its four SIMDs
+    if (w != (blockIdx.x * 2654435761u) >> 30) return;
+    FoldQueue<4> fq;
+    fq.n_tab = 4 * FOLD_UNITS;
+    fq.tb_n = bf.tab_n[lane];
+    fq.tb_off = bf.tab_off[lane];
+    fq.tb_out = bf.tab_out[lane];
+    fq.tb_root = 1;
+    if (__ballot(fq.tb_n != 0) == 0ull) return;
+    fq.fold_and_write(s_nodes, a.h);
 }
 
 void set_fused_dbg(unsigned long long *) {}

@@ -4,8 +4,14 @@
 #pragma once
 #include "common.h"
 #include "blake3_dev.h"
+#include <type_traits>
 
 namespace zn {
+
+// 16 bytes at any byte address of the LDS (address space 3: a ds_read_b128, whatever the pointer came through)
+typedef uint32_t u4v __attribute__((ext_vector_type(4)));
+typedef u4v __attribute__((aligned(1))) u4v_unaligned;
+typedef __attribute__((address_space(3))) u4v_unaligned lds_u4;
 
 __device__ __forceinline__ uint4 ld16(const uint8_t *p) {
     uint4 v;
@@ -93,6 +99,10 @@ struct LdsSrc {
     // hash issues no global load of its own, so it never queues behind the decode's pending stores
     uint64_t c_len, c_src, c_oo;
     uint32_t c_sel;
+    // bit u: tile-local row u has not been written yet — its lanes store every 64-byte block they hash (the data
+    // is in the message registers anyway), so writing such a row costs four store instructions per compression
+    // and no data movement of its own
+    uint32_t store_mask;
 };
 
 // What the leaf phase of one tile leaves in the wave: one chaining value per leaf lane plus the shape of
@@ -206,54 +216,71 @@ __device__ __forceinline__ void hash_tile_leaves(const HashArgs &a, const Tile &
             const uint32_t p1 = p0 > yL0 ? p0 : ((yL0 >> 6) + 1) << 6;  // first block read through the period
             r = (p1 - yB) % yoff;
             step64 = 64 % yoff;
+            if (COPY && (ls->store_mask >> local & 1)) dst = const_cast<uint8_t *>(src);  // src = the row's place in the output + leaf_off
         }
         uint4 n0, n1, n2, n3;
         uint32_t p = (uint32_t)leaf_off;  // row position of the next block (LDS path)
-        auto fetch = [&](uint32_t b) {
-            if (LDSRC && Y) {
-                const uint8_t *q = Y + p;
-                if (p > yL0) {
-                    q = Y + yB + r;
-                    r += step64;
-                    if (r >= yoff) r -= yoff;
+        // ALL_LDS: every active lane reads its leaf from the staged windows.  The loop is then compiled with LDS
+        // instructions only (ds_read_b128, counted by lgkmcnt): with one loop for both sources the compiler has to
+        // use flat loads, which count on vmcnt as well, complete in order behind every earlier global STORE of the
+        // wave, and make each compression wait for the row bytes written one compression earlier.
+        auto run = [&](auto all_lds) {
+            constexpr bool ALL_LDS = decltype(all_lds)::value;
+            auto fetch = [&](uint32_t b) {
+                if (ALL_LDS || (LDSRC && Y)) {
+                    const uint8_t *q = Y + p;
+                    if (p > yL0) {
+                        q = Y + yB + r;
+                        r += step64;
+                        if (r >= yoff) r -= yoff;
+                    }
+                    if constexpr (ALL_LDS) {
+                        const lds_u4 *q3 = (const lds_u4 *)q;
+                        const u4v a0 = q3[0], a1 = q3[1], a2 = q3[2], a3 = q3[3];
+                        n0 = make_uint4(a0.x, a0.y, a0.z, a0.w); n1 = make_uint4(a1.x, a1.y, a1.z, a1.w);
+                        n2 = make_uint4(a2.x, a2.y, a2.z, a2.w); n3 = make_uint4(a3.x, a3.y, a3.z, a3.w);
+                    } else {
+                        __builtin_memcpy(&n0, q, 16); __builtin_memcpy(&n1, q + 16, 16);
+                        __builtin_memcpy(&n2, q + 32, 16); __builtin_memcpy(&n3, q + 48, 16);
+                    }
+                    p += 64;
+                } else {
+                    const uint8_t *q = src + b * 64;
+                    n0 = ld16(q); n1 = ld16(q + 16); n2 = ld16(q + 32); n3 = ld16(q + 48);
                 }
-                __builtin_memcpy(&n0, q, 16); __builtin_memcpy(&n1, q + 16, 16);
-                __builtin_memcpy(&n2, q + 32, 16); __builtin_memcpy(&n3, q + 48, 16);
-                p += 64;
+            };
+            auto block = [&](uint32_t b) {
+                uint32_t m[16] = {n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, n1.z, n1.w,
+                                  n2.x, n2.y, n2.z, n2.w, n3.x, n3.y, n3.z, n3.w};
+                if (b < 15) fetch(b + 1);
+                if (COPY && dst) {
+                    uint8_t *d = dst + b * 64;
+                    st16(d, make_uint4(m[0], m[1], m[2], m[3]));
+                    st16(d + 16, make_uint4(m[4], m[5], m[6], m[7]));
+                    st16(d + 32, make_uint4(m[8], m[9], m[10], m[11]));
+                    st16(d + 48, make_uint4(m[12], m[13], m[14], m[15]));
+                }
+                const uint32_t flags = (b == 0 ? b3::CHUNK_START : 0u) |
+                                       (b == 15 ? (b3::CHUNK_END | (single ? b3::ROOT : 0u)) : 0u);
+                b3::compress(cv, m, k, 0, 64, flags);
+            };
+            if constexpr (Hook::enabled) {
+                if (active) fetch(0);
+#pragma unroll 1
+                for (uint32_t b = 0; b < 16; b++) {
+                    if (active) block(b);
+                    hook(b);
+                }
             } else {
-                const uint8_t *q = src + b * 64;
-                n0 = ld16(q); n1 = ld16(q + 16); n2 = ld16(q + 32); n3 = ld16(q + 48);
+                if (active) {
+                    fetch(0);
+#pragma unroll 1
+                    for (uint32_t b = 0; b < 16; b++) block(b);
+                }
             }
         };
-        auto block = [&](uint32_t b) {
-            uint32_t m[16] = {n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, n1.z, n1.w,
-                              n2.x, n2.y, n2.z, n2.w, n3.x, n3.y, n3.z, n3.w};
-            if (b < 15) fetch(b + 1);
-            if (COPY && dst) {
-                uint8_t *d = dst + b * 64;
-                st16(d, make_uint4(m[0], m[1], m[2], m[3]));
-                st16(d + 16, make_uint4(m[4], m[5], m[6], m[7]));
-                st16(d + 32, make_uint4(m[8], m[9], m[10], m[11]));
-                st16(d + 48, make_uint4(m[12], m[13], m[14], m[15]));
-            }
-            const uint32_t flags = (b == 0 ? b3::CHUNK_START : 0u) |
-                                   (b == 15 ? (b3::CHUNK_END | (single ? b3::ROOT : 0u)) : 0u);
-            b3::compress(cv, m, k, 0, 64, flags);
-        };
-        if constexpr (Hook::enabled) {
-            if (active) fetch(0);
-#pragma unroll 1
-            for (uint32_t b = 0; b < 16; b++) {
-                if (active) block(b);
-                hook(b);
-            }
-        } else {
-            if (active) {
-                fetch(0);
-#pragma unroll 1
-                for (uint32_t b = 0; b < 16; b++) block(b);
-            }
-        }
+        if (LDSRC && __ballot(active && !Y) == 0ull) run(std::true_type{});
+        else run(std::false_type{});
     } else {
         // generic path: ragged / partial / empty leaves
         uint32_t maxblk = active ? nblk : 0;
