@@ -30,7 +30,7 @@ def build(force=False, verbose=False):
     for src in sources():
         obj = os.path.splitext(src)[0] + ".o"
         cmd = [hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-c", src, "-o", obj,
-               "-Wall", "-Wno-unused-function"]
+               "-Wall", "-Wno-unused-function"] + os.environ.get("ZN_CFLAGS", "").split()
         if verbose:
             print(" ".join(cmd))
         procs.append((subprocess.Popen(cmd), cmd))

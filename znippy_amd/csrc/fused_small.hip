@@ -4,15 +4,20 @@
 // XCD's L2 — the body of the reference's read worker loop (znippy-common/src/decompress.rs:L135-190)
 // for up to 64 KiB of output per wave, with no intermediate pass over HBM.
 //
-// The in-wave decoder handles "simple" zstd frames: raw/RLE blocks and compressed blocks whose
-// literals are raw/RLE and whose sequence tables are predefined/RLE (what this build's encoder
-// emits, and what libzstd emits for short or highly repetitive chunks).  Parsing is SCALAR:
-// the frame lives in one VGPR (lane = dword of a 256-byte window) and every header field /
-// bitstream read is a v_readlane + SALU shift, so no lane idles on a serial byte loop.
-// Overlapping LZ matches (offset < length, e.g. a 45-byte text period) are expanded once into
-// an LDS pattern buffer and streamed out 1 KiB per wave-instruction with aligned 16-byte stores.
-// Anything else (Huffman literals, FSE table descriptions) is handed to the general decoder
-// through the pending list and hashed by the second pass.
+// Rows of the common shape — one compressed block = raw literals + ONE sequence whose match repeats a period
+// lying inside those literals — are recognised lane-parallel (lane u parses row u, parse_fast), never expanded
+// anywhere: the BLAKE3 lanes read their 64-byte blocks straight from the staged frame window in LDS (the
+// literals + 64 bytes of the period) and the same message registers are stored to the output, so such a row
+// costs one read of its frame, one write of its bytes and the hash.
+//
+// Every other "simple" frame (raw/RLE blocks, compressed blocks with raw/RLE literals and predefined/RLE
+// sequence tables, up to 16 sequences) is decoded by the wave row after row with SCALAR parsing
+// (decode_simple: the frame lives in one VGPR, lane = dword of a 256-byte window, every header field /
+// bitstream read is a v_readlane + SALU shift); overlapping matches are expanded once into an LDS pattern
+// buffer and streamed out 1 KiB per wave-instruction.  Anything else (Huffman literals, FSE table
+// descriptions) is handed to the general decoder through the pending list and hashed by the second pass.
+//
+// The parent trees of a workgroup's four tiles are folded together by one of its waves (BlockFold).
 #include "common.h"
 #include "hash_dev.h"
 
@@ -678,14 +683,13 @@ __device__ __forceinline__ uint32_t lmod(uint32_t x, uint32_t d, float inv) {
     return (uint32_t)r;
 }
 
-// Writing the recognised rows: out[i] = Y[i] for i < L0, Y[B + (i - B) mod off] after that (B = L0 - off), with
-// Y = the row's literals in the staged window, extended by 64 bytes of the period, so that any 16 output
-// bytes are 16 CONTIGUOUS bytes of Y — at i itself (i + 16 <= L0 + 64) or inside the period copy at B + r.
-// The whole row goes out as aligned 16-byte stores read straight from the window, 1 KiB per wave-instruction,
-// with no expansion buffer and no dependence on bytes already written — which is what lets the stores be
-// issued a few at a time BETWEEN the BLAKE3 compressions of the tile (the hash reads the same windows, not
-// the output): the write traffic of a tile is spread over its hash instead of arriving as one burst that
-// every wave of the chip issues at the same moment.
+// Writing a recognised row from its window: out[i] = Y[i] for i < L0, Y[B + (i - B) mod off] after that
+// (B = L0 - off), with Y = the row's literals in the staged window, extended by 64 bytes of the period, so that
+// any 16 output bytes are 16 CONTIGUOUS bytes of Y — at i itself (i + 16 <= L0 + 64) or inside the period copy at
+// B + r.  The row goes out as aligned 16-byte stores read straight from the window, 1 KiB per wave-instruction,
+// with no expansion buffer and no dependence on bytes already written.  Used for tiles with a ragged leaf (their
+// rows are hashed from the output); in a tile of whole leaves the hash lanes write the rows themselves
+// (LdsSrc::store_mask) and only prepare() runs.
 struct Emitter {
     uint8_t *WL;       // this wave's staged windows
     uint8_t *outbase;  // output region
@@ -695,8 +699,6 @@ struct Emitter {
     uint64_t c_oo;
     // schedule (wave-uniform)
     uint32_t todo;   // bit u: recognised row u not opened yet
-    uint32_t total;  // trips of all rows (pacing)
-    uint32_t done;
     // the open row (wave-uniform) and this lane's position in it
     uint32_t open_, i0, body16, off, step, B, lim;
     uint8_t *Y, *out;
@@ -704,14 +706,13 @@ struct Emitter {
 
     // extend every recognised row's window by 64 period bytes (the hash and the trips both rely on it)
     __device__ __forceinline__ void prepare(uint32_t mask) {
-        todo = mask; total = 0; done = 0; open_ = 0;
+        todo = mask; open_ = 0;
         for (uint32_t m = mask; m; m &= m - 1) {
             const uint32_t u = (uint32_t)__builtin_ctz(m);
             const uint32_t lit_at = __builtin_amdgcn_readlane(f_lit, u), L0 = __builtin_amdgcn_readlane(f_L0, u),
                            o = __builtin_amdgcn_readlane(f_off, u);
             uint8_t *y = WL + u * WSTRIDE + lit_at;
             y[L0 + lane] = y[L0 - o + lmod(lane, o, 1.0f / (float)o)];
-            total += (__builtin_amdgcn_readlane(c_len_lo, u) + 4095) >> 12;
         }
     }
     // one step = (open the next row: head and tail bytes) + one trip of up to four 1 KiB stores
@@ -959,7 +960,7 @@ __device__ __forceinline__ void lds_barrier() {  // workgroup barrier that order
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
-__global__ __launch_bounds__(256, 4) void k_fused_small(FusedArgs a) {
+__global__ __launch_bounds__(256, 5) void k_fused_small(FusedArgs a) {
     __shared__ __attribute__((aligned(16))) uint32_t s_nodes[4 * 64 * 8];
     __shared__ uint32_t s_tab[3][4 * FOLD_UNITS];
     const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6;

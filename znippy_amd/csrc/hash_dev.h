@@ -117,14 +117,8 @@ struct LeafOut {
 
 // Leaf phase of one tile: every active lane compresses its 1 KiB leaf (16 blocks).  Every lane of the wave
 // must call it.
-// `hook(b)`: optional wave-wide side work between the compressions of the full-leaf path (all 64 lanes call
-// it, after block b's compression was issued); the fused kernel streams its decoded rows out there.
-struct NoHook {
-    static constexpr bool enabled = false;
-    __device__ __forceinline__ void operator()(uint32_t) const {}
-};
-template <bool COPY, bool LDSRC = false, class Hook = NoHook>
-__device__ __forceinline__ void hash_tile_leaves(const HashArgs &a, const Tile &t, const LdsSrc *ls, LeafOut &out, Hook hook = Hook()) {
+template <bool COPY, bool LDSRC = false>
+__device__ __forceinline__ void hash_tile_leaves(const HashArgs &a, const Tile &t, const LdsSrc *ls, LeafOut &out) {
     const uint32_t lane = threadIdx.x & 63;
     uint32_t unit, k, unit_leaves, seg_start, local = 0xFFFFFFFFu;
     bool active = lane < t.n_leaves;
@@ -264,19 +258,10 @@ __device__ __forceinline__ void hash_tile_leaves(const HashArgs &a, const Tile &
                                        (b == 15 ? (b3::CHUNK_END | (single ? b3::ROOT : 0u)) : 0u);
                 b3::compress(cv, m, k, 0, 64, flags);
             };
-            if constexpr (Hook::enabled) {
-                if (active) fetch(0);
+            if (active) {
+                fetch(0);
 #pragma unroll 1
-                for (uint32_t b = 0; b < 16; b++) {
-                    if (active) block(b);
-                    hook(b);
-                }
-            } else {
-                if (active) {
-                    fetch(0);
-#pragma unroll 1
-                    for (uint32_t b = 0; b < 16; b++) block(b);
-                }
+                for (uint32_t b = 0; b < 16; b++) block(b);
             }
         };
         if (LDSRC && __ballot(active && !Y) == 0ull) run(std::true_type{});
@@ -324,10 +309,10 @@ __device__ __forceinline__ void fold_tile_now(const HashArgs &a, const Tile &t, 
 }
 
 // Hash one tile with the calling wavefront.  Every lane of the wave must call it.
-template <bool COPY, bool LDSRC = false, class Hook = NoHook>
-__device__ __forceinline__ void hash_tile(const HashArgs &a, const Tile &t, const LdsSrc *ls = nullptr, Hook hook = Hook()) {
+template <bool COPY, bool LDSRC = false>
+__device__ __forceinline__ void hash_tile(const HashArgs &a, const Tile &t, const LdsSrc *ls = nullptr) {
     LeafOut lo;
-    hash_tile_leaves<COPY, LDSRC, Hook>(a, t, ls, lo, hook);
+    hash_tile_leaves<COPY, LDSRC>(a, t, ls, lo);
     fold_tile_now(a, t, lo);
 }
 
