@@ -117,8 +117,17 @@ struct LeafOut {
 
 // Leaf phase of one tile: every active lane compresses its 1 KiB leaf (16 blocks).  Every lane of the wave
 // must call it.
+// `stage` (COPY only): 64 x STAGE_SLOT bytes of wave-private LDS.  A lane's copy of its 64-byte block is four
+// 16-byte stores 1 KiB away from every other lane's — 64 different cache lines per store instruction, which
+// measured ~60 ns of SIMD time each (tools/ubench_b3.hip).  With a stage the block goes through LDS instead and
+// leaves transposed: four lanes write one leaf's 64 contiguous bytes, 16 leaves per instruction.
+constexpr uint32_t STAGE_SLOT = 80;  // 64 + 16: consecutive lanes' slots start 20 banks apart (conflict-free b128)
+constexpr uint32_t STAGE_BYTES = 64 * STAGE_SLOT;
+typedef __attribute__((address_space(3))) u4v lds_u4a;  // 16-byte aligned LDS vector
+
 template <bool COPY, bool LDSRC = false>
-__device__ __forceinline__ void hash_tile_leaves(const HashArgs &a, const Tile &t, const LdsSrc *ls, LeafOut &out) {
+__device__ __forceinline__ void hash_tile_leaves(const HashArgs &a, const Tile &t, const LdsSrc *ls, LeafOut &out,
+                                                 uint8_t *stage = nullptr) {
     const uint32_t lane = threadIdx.x & 63;
     uint32_t unit, k, unit_leaves, seg_start, local = 0xFFFFFFFFu;
     bool active = lane < t.n_leaves;
@@ -258,7 +267,51 @@ __device__ __forceinline__ void hash_tile_leaves(const HashArgs &a, const Tile &
                                        (b == 15 ? (b3::CHUNK_END | (single ? b3::ROOT : 0u)) : 0u);
                 b3::compress(cv, m, k, 0, 64, flags);
             };
-            if (active) {
+            if (COPY && stage) {
+                // the copy goes out transposed: every lane leaves its block in its stage slot, then lane l stores
+                // piece l%4 of leaves 16j + l/4 (j = 0..3) — 16 leaves x 64 contiguous bytes per store instruction.
+                // (Staging the LOADS the same way measured slower: the LDS round trip lands in front of every
+                // compression and the scattered loads are cheap to begin with.)
+                const uint64_t has = __ballot(active && dst != nullptr);
+                uint8_t *pj[4];
+                bool onj[4];
+                const lds_u4a *rs[4];
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const uint32_t leaf = 16 * j + (lane >> 2);
+                    const uint64_t d64 = (uint64_t)(uintptr_t)dst;
+                    const uint64_t g = ((uint64_t)__shfl((uint32_t)(d64 >> 32), leaf) << 32) | __shfl((uint32_t)d64, leaf);
+                    pj[j] = reinterpret_cast<uint8_t *>((uintptr_t)g) + 16 * (lane & 3);
+                    onj[j] = (has >> leaf) & 1;
+                    rs[j] = (const lds_u4a *)(stage + leaf * STAGE_SLOT + 16 * (lane & 3));
+                }
+                lds_u4a *ws = (lds_u4a *)(stage + lane * STAGE_SLOT);
+                if (active) fetch(0);
+#pragma unroll 1
+                for (uint32_t b = 0; b < 16; b++) {
+                    uint32_t m[16];
+                    if (active) {
+                        m[0] = n0.x; m[1] = n0.y; m[2] = n0.z; m[3] = n0.w; m[4] = n1.x; m[5] = n1.y; m[6] = n1.z; m[7] = n1.w;
+                        m[8] = n2.x; m[9] = n2.y; m[10] = n2.z; m[11] = n2.w; m[12] = n3.x; m[13] = n3.y; m[14] = n3.z; m[15] = n3.w;
+                        if (b < 15) fetch(b + 1);
+                        if (dst) {
+                            ws[0] = u4v{m[0], m[1], m[2], m[3]}; ws[1] = u4v{m[4], m[5], m[6], m[7]};
+                            ws[2] = u4v{m[8], m[9], m[10], m[11]}; ws[3] = u4v{m[12], m[13], m[14], m[15]};
+                        }
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; j++)
+                        if (onj[j]) {
+                            const u4v v = *rs[j];
+                            st16(pj[j] + b * 64, make_uint4(v.x, v.y, v.z, v.w));
+                        }
+                    if (active) {
+                        const uint32_t flags = (b == 0 ? b3::CHUNK_START : 0u) |
+                                               (b == 15 ? (b3::CHUNK_END | (single ? b3::ROOT : 0u)) : 0u);
+                        b3::compress(cv, m, k, 0, 64, flags);
+                    }
+                }
+            } else if (active) {
                 fetch(0);
 #pragma unroll 1
                 for (uint32_t b = 0; b < 16; b++) block(b);
