@@ -294,3 +294,44 @@ def test_periodic_rows_from_this_encoder(gpu_ctx, oracle):
     assert np.array_equal(d_out.cpu().numpy()[:len(src)], src)
     for i in (0, 5, 40, len(entries) - 1):
         assert bytes(enc["checksum"][i]) == oracle.blake3(entries[i])
+
+
+def test_big_rows_block_items_fused(gpu_ctx, oracle):
+    """Big rows whose 128 KiB blocks are 'literals + one periodic match' or raw are written and hashed by the fused
+    block kernel; short last blocks, other shapes and mixed frames take the block decoder + second hash pass.
+    Bytes and digests must not depend on which path a block took."""
+    import torch
+    from znippy_amd import hip
+    rng = np.random.default_rng(9)
+    BLK = 128 * 1024
+    entries = [
+        _periodic(45, 8 * BLK, 1),                     # whole blocks, all recognised
+        _periodic(7, 3 * BLK + 12345, 2),              # short last block
+        _periodic(600, 2 * BLK + 1, 3),
+        gen.incompressible(4, 4 * BLK),                # raw blocks
+        gen.incompressible(5, 2 * BLK + 999),
+        _periodic(13, BLK, 6) + gen.incompressible(7, BLK) + gen.pseudo_text(BLK, seed=8) + _periodic(200, BLK + 77, 9),  # mixed frame
+        gen.pseudo_text(3 * BLK + 5, seed=10),         # entropy-coded blocks: not for the fused kernel
+        _periodic(1, 5 * BLK, 11),
+        gen.text(10240), gen.text(70000),
+    ]
+    src = np.frombuffer(b"".join(entries), dtype=np.uint8)
+    lens = np.array([len(e) for e in entries], dtype=np.uint64)
+    offs = np.concatenate([[0], np.cumsum(lens)[:-1]]).astype(np.uint64)
+    d_src = torch.from_numpy(src.copy()).cuda()
+    rounds = hip.RoundTable(gpu_ctx, offs, lens)
+    d_blob = torch.zeros(rounds.blob_bound() + 64, dtype=torch.uint8, device="cuda")
+    enc = rounds.encode_hash(d_src, d_blob)
+    for i, e in enumerate(entries):
+        assert bytes(enc["checksum"][i]) == oracle.blake3(e)
+    rows = hip.RowTable(gpu_ctx, enc["blob_offset"], enc["blob_size"], lens, offs, None, enc["checksum"])
+    d_out = torch.zeros(len(src) + 64, dtype=torch.uint8, device="cuda")
+    for _ in range(2):  # the second run reuses the row table (done flags are reset per run)
+        d_out.zero_()
+        counters, corrupt, status = rows.decode_verify(d_blob, d_out)
+        assert (status == 0).all() and len(corrupt) == 0
+        assert counters["verified_bytes"] == len(src)
+        assert np.array_equal(d_out.cpu().numpy()[:len(src)], src)
+    assert np.array_equal(rows.digests(), enc["checksum"])
+    names = [k for k, _ in gpu_ctx.kernel_times()]
+    assert "decode_verify_fused_blocks" in names

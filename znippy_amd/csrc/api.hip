@@ -150,6 +150,11 @@ struct znippy_rows {
     uint32_t n_cand = 0, n_items = 0;
     uint32_t *cand_row = nullptr, *cand_base = nullptr, *cand_nblocks = nullptr, *pending2 = nullptr;
     uint32_t *item_row = nullptr, *item_k = nullptr, *item_src = nullptr, *row_flag = nullptr;
+    // fused block kernel: big-slice tiles of the candidate rows, the item each belongs to, and what it got done
+    uint32_t n_bt = 0;
+    uint32_t *bt_tile = nullptr, *bt_item = nullptr;
+    uint8_t *tile_done = nullptr, *item_done = nullptr;
+    uint32_t *todo = nullptr;  // items left to the block decoder (count: third word of the control block)
     DevPlan plan;
 };
 
@@ -343,7 +348,8 @@ void znippy_rows_destroy(znippy_rows *r) {
     (void)hipSetDevice(r->ctx->device);
     void *ptrs[] = {r->blob_off, r->blob_size, r->usize, r->out_off, r->compressed, r->checksum,
                     r->status, r->digests, r->counters, r->corrupt, r->list_a, r->pending,
-                    r->cand_row, r->cand_base, r->cand_nblocks, r->item_row, r->item_k, r->item_src, r->row_flag, r->pending2};
+                    r->cand_row, r->cand_base, r->cand_nblocks, r->item_row, r->item_k, r->item_src, r->row_flag, r->pending2,
+                    r->bt_tile, r->bt_item, r->tile_done, r->item_done, r->todo};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (r->h_counters) (void)hipHostFree(r->h_counters);
@@ -439,6 +445,29 @@ int znippy_rows_create(znippy_ctx *ctx, const uint64_t *blob_offset, const uint6
             return ZNIPPY_E_NOMEM;
         }
     }
+    if (r->n_cand && !getenv("ZNIPPY_NO_FUSED_BLOCKS")) {
+        std::vector<uint32_t> row_base(n, 0xFFFFFFFFu), bt_tile, bt_item;
+        for (size_t c = 0; c < cand_row.size(); c++) row_base[cand_row[c]] = cand_base[c];
+        for (uint32_t ti = 0; ti < (uint32_t)p.tiles.size(); ti++) {
+            const Tile &t = p.tiles[ti];
+            if (t.n_units == 0 && row_base[t.first_unit] != 0xFFFFFFFFu) {
+                bt_tile.push_back(ti);
+                bt_item.push_back(row_base[t.first_unit] + (t.first_leaf >> 7));
+            }
+        }
+        r->n_bt = (uint32_t)bt_tile.size();
+        if ((rc = dev_upload(ctx, &r->bt_tile, bt_tile.data(), bt_tile.size())) ||
+            (rc = dev_upload(ctx, &r->bt_item, bt_item.data(), bt_item.size()))) {
+            znippy_rows_destroy(r);
+            return rc;
+        }
+        if (hipMalloc(&r->tile_done, std::max<size_t>(p.tiles.size(), 16)) != hipSuccess ||
+            hipMalloc(&r->item_done, std::max<size_t>(r->n_items, 16)) != hipSuccess ||
+            hipMalloc(&r->todo, std::max<size_t>(4 * (size_t)r->n_items, 16)) != hipSuccess) {
+            znippy_rows_destroy(r);
+            return ZNIPPY_E_NOMEM;
+        }
+    }
     if ((rc = dev_upload(ctx, &r->list_a, la.data(), la.size()))) {
         znippy_rows_destroy(r);
         return rc;
@@ -519,9 +548,27 @@ int znippy_decode_verify_rows_async(znippy_ctx *ctx, znippy_rows *r, const void 
         ktime_begin(ctx, "zstd_block_scan", ctx->aux);
         launch_scan_blocks(b, ctx->aux);
         ktime_end(ctx, ctx->aux);
+        if (r->n_bt) {  // blocks of the common shape: written and hashed in one go, skipped by the two passes below
+            HIPCHK(ctx, hipMemsetAsync(r->tile_done, 0, r->plan.n_tiles, ctx->aux));
+            HIPCHK(ctx, hipMemsetAsync(r->item_done, 0, r->n_items, ctx->aux));
+            FusedBlocksArgs fb{};
+            fb.h = h;
+            fb.h.pass = 0;  // PASS_ALL
+            fb.blob_size = r->blob_size;
+            fb.bt_tile = r->bt_tile; fb.bt_item = r->bt_item; fb.n_bt = r->n_bt;
+            fb.item_src = r->item_src; fb.row_flag = r->row_flag;
+            fb.tile_done = r->tile_done; fb.item_done = r->item_done;
+            { const char *e = getenv("ZNIPPY_DBG"); fb.dbg = e ? atoi(e) : 0; }
+            ktime_begin(ctx, "decode_verify_fused_blocks", ctx->aux);
+            launch_fused_blocks(fb, ctx->aux);
+            ktime_end(ctx, ctx->aux);
+            launch_compact_items(r->item_done, r->n_items, r->todo, r->pending_count + 2, ctx->aux);
+        }
         DecodeArgs a{};
         a.block_mode = 1;
         a.item_row = r->item_row; a.item_k = r->item_k; a.item_src = r->item_src; a.n_items = r->n_items; a.row_flag = r->row_flag;
+        a.item_done = r->n_bt ? r->item_done : nullptr;
+        a.todo = r->n_bt ? r->todo : nullptr; a.n_todo = r->pending_count + 2;
         a.pending_count = r->pending_count;
         a.blobs = (const uint8_t *)d_blobs;
         a.blob_base = blob_base;
@@ -574,6 +621,7 @@ int znippy_decode_verify_rows_async(znippy_ctx *ctx, znippy_rows *r, const void 
     }
     // 3) second hash pass: slices of big rows + rows the general decoder finished
     h.pass = 2;  // PASS_SECOND
+    h.tile_done = r->n_bt ? r->tile_done : nullptr;
     ktime_begin(ctx, "blake3_second_pass");
     launch_hash_tiles(h, s);
     ktime_end(ctx);

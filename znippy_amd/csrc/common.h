@@ -50,6 +50,7 @@ struct HashArgs {
     uint32_t *digests;  // 8 words per unit
     uint32_t *tile_cv;  // 8 words per big-unit tile
     int fold_tiles_max;  // 0 = pick from the tile count; 1 = no deferred folding (no LDS: the launch shares the CUs with the encoder)
+    const uint8_t *tile_done;  // optional, PASS_SECOND: tiles already hashed by the fused block kernel
 };
 
 // Row status values on the read side: 0 = done (stored row, or decoded+hashed by the fused
@@ -80,6 +81,8 @@ struct DecodeArgs {
     const uint32_t *item_src;           // item -> offset of the block header inside the frame (0xFFFFFFFF: skip)
     uint32_t n_items;
     uint32_t *row_flag;                 // per row, != 0: decode this frame serially
+    const uint8_t *item_done;           // optional: items already written (and hashed) by the fused block kernel
+    const uint32_t *todo, *n_todo;      // optional: the items that are left (k_compact_items); n_work = *n_todo
     uint32_t *seq_scratch;
 };
 
@@ -97,6 +100,19 @@ struct FusedArgs {
     uint32_t *tile_cursor;  // atomic work cursor of the persistent blocks (zeroed before the launch)
     uint32_t grid;          // resident blocks: 4 per CU
 };
+
+// Block items of the common shape (fused_small.hip, k_fused_blocks): the big-slice tiles of block-candidate rows.
+struct FusedBlocksArgs {
+    HashArgs h;  // as for the fused small-row kernel, pass = PASS_ALL
+    const uint64_t *blob_size;
+    const uint32_t *bt_tile, *bt_item;  // tile index in the plan, block item the tile belongs to
+    uint32_t n_bt;
+    const uint32_t *item_src;  // written by k_scan_blocks
+    const uint32_t *row_flag;
+    uint8_t *tile_done, *item_done;  // zeroed before the launch
+    int dbg;
+};
+void launch_fused_blocks(const FusedBlocksArgs &a, hipStream_t s);
 
 void launch_hash_tiles(const HashArgs &a, hipStream_t s);
 void launch_fused_small(const FusedArgs &a, hipStream_t s);
@@ -121,6 +137,7 @@ struct BlockScanArgs {
     uint32_t *pending, *pending_count;
 };
 void launch_scan_blocks(const BlockScanArgs &a, hipStream_t s);
+void launch_compact_items(const uint8_t *item_done, uint32_t n_items, uint32_t *todo, uint32_t *n_todo, hipStream_t s);
 void launch_finish_blocks(const BlockScanArgs &a, hipStream_t s);
 
 }  // namespace zn

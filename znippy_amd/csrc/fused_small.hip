@@ -599,26 +599,17 @@ __device__ __forceinline__ uint4 lds16(const uint8_t *p) {
     __builtin_memcpy(&v, p, 16);
     return v;
 }
-__device__ __forceinline__ FastRow parse_fast(const uint8_t *w, uint32_t n, uint64_t usize, bool want, const FastTabs &T) {
-    bool ok = want && n >= 12 && n <= WIN && usize >= 65 && usize <= 0xFFFFFFull;
-    const uint64_t h0 = lds8(w);
-    ok &= (uint32_t)h0 == 0xFD2FB528u;
-    const uint32_t fhd = (uint32_t)(h0 >> 32) & 0xFF;
-    ok &= (fhd & 0x0F) == 0;  // no reserved bit, no content checksum, no dictionary id
-    const uint32_t single = (fhd >> 5) & 1, fcs_flag = fhd >> 6;
-    const uint32_t fcs_bytes = fcs_flag == 0 ? single : (1u << fcs_flag);
-    ok &= fcs_bytes != 0;
-    uint32_t pos = 6 - single;
-    uint64_t f = lds8(w + pos);
-    if (fcs_bytes < 8) f &= (1ull << (8 * fcs_bytes)) - 1;
-    if (fcs_bytes == 2) f += 256;
-    ok &= f == usize;
-    pos += fcs_bytes;  // <= 14
+// The block part: `pos` = position of the block header in the window, `n` = bytes of the frame that the window
+// holds.  FRAME_END: the block must be the frame's last one and end exactly at n (a whole small frame); otherwise it
+// may be any compressed block that ends inside the window (one block item of a big frame, zstd_decode.hip).
+template <bool FRAME_END>
+__device__ __forceinline__ FastRow parse_fast_block(const uint8_t *w, uint32_t pos, uint32_t n, uint64_t usize, bool ok, const FastTabs &T) {
     const uint64_t b = lds8(w + pos);  // block header (3 bytes) + literals header (<= 3)
     const uint32_t bh = (uint32_t)b & 0xFFFFFF;
-    ok &= (bh & 7) == 5;  // last block, compressed
+    ok &= FRAME_END ? (bh & 7) == 5 : ((bh >> 1) & 3) == 2;  // compressed (and the last block)
     pos += 3;
-    ok &= pos + (bh >> 3) == n;
+    const uint32_t bend = pos + (bh >> 3);
+    ok &= FRAME_END ? bend == n : bend <= n;
     const uint32_t lh = (uint32_t)(b >> 24);
     ok &= (lh & 3) == 0;  // raw literals
     const uint32_t sf = (lh >> 2) & 3;
@@ -626,7 +617,7 @@ __device__ __forceinline__ FastRow parse_fast(const uint8_t *w, uint32_t n, uint
     const uint32_t lit_at = pos + ((sf & 1) == 0 ? 1u : sf);
     ok &= regen <= WIN;
     uint32_t sp = lit_at + regen;  // sequences section
-    ok &= sp + 3 <= n;
+    ok &= sp + 3 <= bend;
     sp = ok ? sp : 0;
     const uint64_t sh = lds8(w + sp);
     ok &= (sh & 0xFF) == 1;  // one sequence
@@ -642,9 +633,9 @@ __device__ __forceinline__ FastRow parse_fast(const uint8_t *w, uint32_t n, uint
     q += m_ml & 1;
     ok &= (!m_ll || s_ll <= 35) && (!m_of || s_of <= 31) && (!m_ml || s_ml <= 52);
     const uint32_t bs = sp + q;  // the bitstream: at most 8 bytes, held in one register
-    ok &= bs < n && n - bs <= 8;
-    const uint32_t slen = ok ? n - bs : 1;
-    const uint64_t cw = lds8(w + (ok ? n - 8 : 0));
+    ok &= bs < bend && bend - bs <= 8 && bend >= 8;
+    const uint32_t slen = ok ? bend - bs : 1;
+    const uint64_t cw = lds8(w + (ok ? bend - 8 : 0));
     const uint32_t lastb = (uint32_t)(cw >> 56);
     ok &= lastb != 0;
     int32_t bp = (int32_t)(slen * 8) - (int32_t)(8 - fhib(lastb | 1));
@@ -665,13 +656,34 @@ __device__ __forceinline__ FastRow parse_fast(const uint8_t *w, uint32_t n, uint
     const uint32_t ml = (e_ml & 0xFFFFFF) + rd(e_ml >> 24);
     const uint32_t ll = (e_ll & 0xFFFFFF) + rd(e_ll >> 24);
     ok &= bp == 0;
-    // first sequence of the frame, ll > 0: repeat codes 1..3 mean the initial offsets 1, 4, 8 (RFC 8878 3.1.1.5)
+    // first sequence of the frame / of a self-contained block, ll > 0: repeat codes 1..3 mean the initial offsets
+    // 1, 4, 8 (RFC 8878 3.1.1.5).  A block item that uses one is not self-contained: left to the block decoder,
+    // which flags the frame.
     const uint32_t off = ov > 3 ? ov - 3 : (ov == 1 ? 1u : (ov == 2 ? 4u : 8u));
+    ok &= FRAME_END || ov > 3;
     ok &= ll == regen && ll >= 1 && (uint64_t)ll + ml == usize && off <= ll && off < ml && off <= EOFF_MAX && ml >= 64 &&
           lit_at + ll + 64 <= WSTRIDE;
     FastRow r;
     r.ok = ok ? 1u : 0u; r.lit_at = lit_at; r.L0 = ll; r.off = off;
     return r;
+}
+
+__device__ __forceinline__ FastRow parse_fast(const uint8_t *w, uint32_t n, uint64_t usize, bool want, const FastTabs &T) {
+    bool ok = want && n >= 12 && n <= WIN && usize >= 65 && usize <= 0xFFFFFFull;
+    const uint64_t h0 = lds8(w);
+    ok &= (uint32_t)h0 == 0xFD2FB528u;
+    const uint32_t fhd = (uint32_t)(h0 >> 32) & 0xFF;
+    ok &= (fhd & 0x0F) == 0;  // no reserved bit, no content checksum, no dictionary id
+    const uint32_t single = (fhd >> 5) & 1, fcs_flag = fhd >> 6;
+    const uint32_t fcs_bytes = fcs_flag == 0 ? single : (1u << fcs_flag);
+    ok &= fcs_bytes != 0;
+    uint32_t pos = 6 - single;
+    uint64_t f = lds8(w + pos);
+    if (fcs_bytes < 8) f &= (1ull << (8 * fcs_bytes)) - 1;
+    if (fcs_bytes == 2) f += 256;
+    ok &= f == usize;
+    pos += fcs_bytes;  // <= 14
+    return parse_fast_block<true>(w, pos, n, usize, ok, T);
 }
 
 // x mod d for per-lane x < 2^22 and wave-uniform d >= 1 (inv = 1/d): float quotient, off by at most one
@@ -980,6 +992,110 @@ __global__ __launch_bounds__(256, 5) void k_fused_small(FusedArgs a) {
     fq.tb_root = 1;
     if (__ballot(fq.tb_n != 0) == 0ull) return;
     fq.fold_and_write(s_nodes, a.h);
+}
+
+// ---- big rows: block items of the common shape --------------------------------------------------------
+// A frame written block by block from periodic data (a 2 GiB text file in 8 MiB or 200 MiB rounds) is thousands of
+// 128 KiB blocks, each "literals + one sequence repeating a period inside them" — the shape parse_fast_block
+// recognises.  One wave takes one 64 KiB slice tile of such a block: it stages the first bytes of the BLOCK, parses
+// them, and hashes its 64 leaves straight from that window while storing the message registers, exactly as the
+// small-row kernel does for whole rows; the slice's chaining value goes to tile_cv for k_merge_big.  A block done
+// this way is skipped by the block decoder and its two tiles by the second hash pass, so the row's bytes are
+// written once and never read back.  Anything else about the block (another shape, a short last block, a frame the
+// scan gave up on) leaves it to those kernels, untouched.
+__global__ __launch_bounds__(256, 5) void k_fused_blocks(FusedBlocksArgs a) {
+    __shared__ __attribute__((aligned(16))) uint32_t s_nodes[4 * 64 * 8];
+    __shared__ uint32_t s_tab[3][4 * FOLD_UNITS];
+    __shared__ __attribute__((aligned(16))) uint8_t s_Wb[4][WSTRIDE];
+    __shared__ __attribute__((aligned(16))) uint8_t s_stage[4][STAGE_BYTES];
+    __shared__ uint16_t s_d[4][3];
+    const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane < FOLD_UNITS) s_tab[0][w * FOLD_UNITS + lane] = 0;
+    const uint32_t idx = blockIdx.x * 4 + w;
+    if (idx < a.n_bt) {
+        const uint32_t ti = a.bt_tile[idx], item = a.bt_item[idx];
+        const Tile t = a.h.tiles[ti];
+        const uint32_t row = t.first_unit;
+        const uint32_t src_pos = a.item_src[item];
+        const uint64_t usize = a.h.len[row];
+        const uint64_t origin = (uint64_t)(t.first_leaf >> 7) << 17;
+        if (src_pos != 0xFFFFFFFFu && a.row_flag[row] == 0 && t.n_leaves == 64 && usize - origin >= 128 * 1024) {
+            uint8_t *const WL = s_Wb[w];
+            const uint64_t n = a.blob_size[row];
+            const uint8_t *const src = a.h.srcA + (a.h.offA[row] - a.h.baseA) + src_pos;
+            const uint32_t avail = n - src_pos < WIN ? (uint32_t)(n - src_pos) : WIN;
+            {
+                const uint32_t o = 8 * lane;
+                uint64_t v = 0;
+                if (o + 8 <= avail) __builtin_memcpy(&v, src + o, 8);
+                else
+                    for (uint32_t k = 0; k < 8; k++)
+                        if (o + k < avail) v |= (uint64_t)src[o + k] << (8 * k);
+                *reinterpret_cast<uint64_t *>(WL + o) = v;
+                if (lane < (WSTRIDE - WIN) / 4) *reinterpret_cast<uint32_t *>(WL + WIN + 4 * lane) = 0;
+            }
+            FastTabs T;
+            {
+                const DTab eL = c_dll[lane], eM = c_dml[lane], eO = c_dof[lane & 31];
+                T.ll = eL.base | (uint32_t)eL.addbits << 24;
+                T.ml = eM.base | (uint32_t)eM.addbits << 24;
+                T.of = eO.addbits;
+                T.lls = lane < 36 ? c_llb[lane] | (uint32_t)c_lla[lane] << 24 : 0u;
+                T.mls = lane < 53 ? c_mlb[lane] | (uint32_t)c_mla[lane] << 24 : 0u;
+            }
+            const uint32_t bh = uni(*reinterpret_cast<const uint32_t *>(WL)) & 0xFFFFFF;
+            if (avail >= 3 && ((bh >> 1) & 3) == 0 && (bh >> 3) == 128 * 1024 && src_pos + 3 + 128 * 1024ull <= n) {
+                // raw block: its bytes sit in the frame — hash them while they are copied out (store-path loop)
+                LeafOut lo;
+                hash_tile_leaves<true, false>(a.h, t, nullptr, lo, s_stage[w], src + 3 - origin);
+                uint4 *d = reinterpret_cast<uint4 *>(s_nodes + (size_t)(w * 64 + lane) * 8);
+                d[0] = make_uint4(lo.cv[0], lo.cv[1], lo.cv[2], lo.cv[3]);
+                d[1] = make_uint4(lo.cv[4], lo.cv[5], lo.cv[6], lo.cv[7]);
+                if (lane == 0) {
+                    s_tab[0][w * FOLD_UNITS] = 64;
+                    s_tab[1][w * FOLD_UNITS] = w * 64;
+                    s_tab[2][w * FOLD_UNITS] = t.cv_index;
+                    a.tile_done[ti] = 1;
+                    a.item_done[item] = 1;
+                }
+            }
+            const FastRow fr = parse_fast_block<false>(WL, 0, avail, 128 * 1024, avail >= 12, T);  // every lane: the same block
+            if (uni(fr.ok)) {
+                const uint32_t lit_at = uni(fr.lit_at), L0 = uni(fr.L0), off = uni(fr.off);
+                uint8_t *y = WL + lit_at;
+                y[L0 + lane] = y[L0 - off + lmod(lane, off, 1.0f / (float)off)];
+                if (lane == 0) { s_d[w][0] = (uint16_t)lit_at; s_d[w][1] = (uint16_t)(L0 - off); s_d[w][2] = (uint16_t)off; }
+                LdsSrc ls{WL, &s_d[w][0], &s_d[w][1], &s_d[w][2], 1, nullptr, 0, 0, 0, 0, (a.dbg & 16) ? 0u : 1u, origin};
+                LeafOut lo;
+                hash_tile_leaves<true, true>(a.h, t, &ls, lo);
+                uint4 *d = reinterpret_cast<uint4 *>(s_nodes + (size_t)(w * 64 + lane) * 8);
+                d[0] = make_uint4(lo.cv[0], lo.cv[1], lo.cv[2], lo.cv[3]);
+                d[1] = make_uint4(lo.cv[4], lo.cv[5], lo.cv[6], lo.cv[7]);
+                if (lane == 0) {
+                    s_tab[0][w * FOLD_UNITS] = 64;
+                    s_tab[1][w * FOLD_UNITS] = w * 64;
+                    s_tab[2][w * FOLD_UNITS] = t.cv_index;
+                    a.tile_done[ti] = 1;
+                    a.item_done[item] = 1;  // the block's other tile comes to the same verdict (same block, same test)
+                }
+            }
+        }
+    }
+    lds_barrier();
+    if (w != (blockIdx.x * 2654435761u) >> 30) return;
+    FoldQueue<4> fq;
+    fq.n_tab = 4 * FOLD_UNITS;
+    fq.tb_n = s_tab[0][lane];
+    fq.tb_off = s_tab[1][lane];
+    fq.tb_out = s_tab[2][lane];
+    fq.tb_root = 0;  // slice CVs: the merge kernel finishes the row
+    if (__ballot(fq.tb_n != 0) == 0ull) return;
+    fq.fold_and_write(s_nodes, a.h);
+}
+
+void launch_fused_blocks(const FusedBlocksArgs &a, hipStream_t s) {
+    if (!a.n_bt) return;
+    hipLaunchKernelGGL(k_fused_blocks, dim3((a.n_bt + 3) / 4), dim3(256), 0, s, a);
 }
 
 void set_fused_dbg(unsigned long long *) {}

@@ -103,6 +103,9 @@ struct LdsSrc {
     // is in the message registers anyway), so writing such a row costs four store instructions per compression
     // and no data movement of its own
     uint32_t store_mask;
+    // big-slice tiles (t.n_units == 0, fused block kernel): descriptor 0 describes the 128 KiB block the slice
+    // belongs to and `origin` is that block's position inside the row (window positions are block-relative)
+    uint64_t origin;
 };
 
 // What the leaf phase of one tile leaves in the wave: one chaining value per leaf lane plus the shape of
@@ -126,8 +129,10 @@ constexpr uint32_t STAGE_BYTES = 64 * STAGE_SLOT;
 typedef __attribute__((address_space(3))) u4v lds_u4a;  // 16-byte aligned LDS vector
 
 template <bool COPY, bool LDSRC = false>
+// `raw_src` (big-slice tiles, fused block kernel): the tile's bytes are copied from raw_src + leaf offset instead of
+// the unit's own source column (a raw block of a compressed frame: blob -> output while hashing).
 __device__ __forceinline__ void hash_tile_leaves(const HashArgs &a, const Tile &t, const LdsSrc *ls, LeafOut &out,
-                                                 uint8_t *stage = nullptr) {
+                                                 uint8_t *stage = nullptr, const uint8_t *raw_src = nullptr) {
     const uint32_t lane = threadIdx.x & 63;
     uint32_t unit, k, unit_leaves, seg_start, local = 0xFFFFFFFFu;
     bool active = lane < t.n_leaves;
@@ -193,6 +198,10 @@ __device__ __forceinline__ void hash_tile_leaves(const HashArgs &a, const Tile &
         src = from_b ? a.srcB + a.offB[unit] : a.srcA + (a.offA[unit] - a.baseA);
         dst = (COPY && !from_b && a.srcB) ? a.srcB + a.offB[unit] : nullptr;
     }
+    if (!LDSRC && COPY && raw_src) {
+        src = raw_src;
+        dst = a.srcB + a.offB[unit];
+    }
     const uint64_t leaf_off = (uint64_t)k << 10;
     uint32_t leaf_len = 0;
     if (active && ulen > leaf_off) leaf_len = (uint32_t)((ulen - leaf_off) < 1024 ? (ulen - leaf_off) : 1024);
@@ -210,19 +219,22 @@ __device__ __forceinline__ void hash_tile_leaves(const HashArgs &a, const Tile &
         // per-lane on-chip source (fused kernel, periodic rows): Y holds out[0 .. L0+64), L0 = B + off
         const uint8_t *Y = nullptr;
         uint32_t yB = 0, yoff = 1, yL0 = 0, r = 0, step64 = 0;
-        if (LDSRC && active && local < ls->rows && ls->ybase[local] != 0xFFFF) {
+        const uint32_t yl = (LDSRC && !t.n_units) ? 0u : local;  // descriptor of this lane's row / block
+        uint32_t p = (uint32_t)leaf_off;  // row position of the next block (LDS path)
+        if (LDSRC && active && yl < ls->rows && ls->ybase[yl] != 0xFFFF) {
+            const uint32_t local = yl;
             Y = ls->wl + ls->ybase[local];
             yB = ls->pB[local];
             yoff = ls->poff[local];
             yL0 = yB + yoff;
-            const uint32_t p0 = (uint32_t)leaf_off;
+            p = (uint32_t)(leaf_off - ls->origin);
+            const uint32_t p0 = p;
             const uint32_t p1 = p0 > yL0 ? p0 : ((yL0 >> 6) + 1) << 6;  // first block read through the period
             r = (p1 - yB) % yoff;
             step64 = 64 % yoff;
             if (COPY && (ls->store_mask >> local & 1)) dst = const_cast<uint8_t *>(src);  // src = the row's place in the output + leaf_off
         }
         uint4 n0, n1, n2, n3;
-        uint32_t p = (uint32_t)leaf_off;  // row position of the next block (LDS path)
         // ALL_LDS: every active lane reads its leaf from the staged windows.  The loop is then compiled with LDS
         // instructions only (ds_read_b128, counted by lgkmcnt): with one loop for both sources the compiler has to
         // use flat loads, which count on vmcnt as well, complete in order behind every earlier global STORE of the

@@ -29,6 +29,7 @@ __global__ __launch_bounds__(256) void k_hash_tiles(HashArgs a) {
     uint32_t *nodes = s_nodes[FOLD_G > 1 ? w : 0];
     for (uint32_t g = 0; g < FOLD_G && first + g < a.n_tiles; g++) {
         const Tile t = a.tiles[first + g];
+        if (a.pass == PASS_SECOND && a.tile_done && a.tile_done[first + g]) continue;  // hashed by the fused block kernel
         if (a.pass == PASS_SECOND && t.n_units) {
             // second pass: a small tile matters only if the general decoder finished one of its rows
             if (*a.pending_count == 0) continue;

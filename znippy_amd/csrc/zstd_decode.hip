@@ -75,7 +75,7 @@ struct SharedT {
     __attribute__((aligned(16))) uint8_t ebuf[(NW == 4 ? WIN_HIST + WIN_CAP : EXP_OFF_MAX + 16 * 64 * NW) + 64];
     // per-row / per-block state broadcast from lane 0
     int32_t err;
-    uint32_t row, skip;
+    uint32_t row, skip, claim;
     uint32_t blk_type, blk_size, blk_last;
     uint32_t lit_kind;  // 0 raw (pointer into src), 1 rle, 2 scratch
     uint32_t lit_len, lit_rle;
@@ -635,7 +635,9 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES == 4 ? 4 : 1) void k_zstd_decod
 
     // nothing routed here (every row was handled by the fused small-row kernel): leave at once
     if (!a.block_mode && a.n_list_a == 0 && *a.pending_count == 0) return;
-    const uint32_t n_work = a.block_mode ? a.n_items : a.n_list_a + *a.pending_count;
+    // block items: with a to-do list (k_compact_items) only the items the fused block kernel left are dequeued
+    const uint32_t n_work = a.block_mode ? (a.todo ? *a.n_todo : a.n_items) : a.n_list_a + *a.pending_count;
+    if (a.block_mode && n_work == 0) return;
 
     // predefined tables, once per workgroup (lane 0; tiny)
     if (tid == 0) {
@@ -651,14 +653,17 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES == 4 ? 4 : 1) void k_zstd_decod
     for (;;) {
         if (tid == 0) {
             const uint32_t w = atomicAdd(a.cursor, 1u);
-            S.row = w;
+            S.row = (a.block_mode && a.todo && w < n_work) ? a.todo[w] : w;
+            S.claim = w;
             // block items: one thread decides for the workgroup whether the item is still worth decoding (the flag is
             // raised concurrently by other workgroups, so it must be sampled once)
-            S.skip = a.block_mode && w < n_work && (a.item_src[w] == 0xFFFFFFFFu || a.row_flag[a.item_row[w]] != 0);
+            const uint32_t it = S.row;
+            S.skip = a.block_mode && w < n_work && (a.item_src[it] == 0xFFFFFFFFu || a.row_flag[a.item_row[it]] != 0 ||
+                                                    (a.item_done && a.item_done[it]));
         }
         __syncthreads();
         const uint32_t widx = S.row;
-        if (widx >= n_work) break;
+        if (S.claim >= n_work) break;
         uint32_t row, item_k = 0, item_src = 0;
         if (a.block_mode) {
             if (S.skip) { __syncthreads(); continue; }  // not eligible / the frame was already given up
@@ -1413,6 +1418,22 @@ __global__ __launch_bounds__(64) void k_finish_blocks(BlockScanArgs a) {
         a.status[row] = 1;  // handed to the general decoder, like a row the fused kernel gave up on
         a.pending[atomicAdd(a.pending_count, 1u)] = row;
     } else a.status[row] = 2;
+}
+
+// to-do list of the block decoder: the items the fused block kernel did not take
+__global__ __launch_bounds__(256) void k_compact_items(const uint8_t *item_done, uint32_t n_items, uint32_t *todo, uint32_t *n_todo) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    const bool keep = i < n_items && !item_done[i];
+    const uint64_t m = __ballot(keep);
+    if (!m) return;
+    const uint32_t lane = threadIdx.x & 63;
+    uint32_t base = 0;
+    if (lane == 0) base = atomicAdd(n_todo, (uint32_t)__popcll(m));
+    base = __shfl(base, 0);
+    if (keep) todo[base + __popcll(m & ((1ull << lane) - 1))] = i;
+}
+void launch_compact_items(const uint8_t *item_done, uint32_t n_items, uint32_t *todo, uint32_t *n_todo, hipStream_t s) {
+    if (n_items) hipLaunchKernelGGL(k_compact_items, dim3((n_items + 255) / 256), dim3(256), 0, s, item_done, n_items, todo, n_todo);
 }
 
 void launch_scan_blocks(const BlockScanArgs &a, hipStream_t s) {
