@@ -211,9 +211,13 @@ def main():
             "decode_verify_fused": path_alg,             # one launch does the whole path for small rows
             "zstd_decode_general": blob_bytes + total_in + 57 * n,
             "zstd_decode_blocks": blob_bytes + total_in + 57 * n,   # block items: same bytes, one work item per block
+            "decode_verify_fused_blocks": blob_bytes + total_in + 57 * n,  # block items written + hashed in one go
             "blake3_second_pass": total_in + 32 * n + (0 if skip is None else total_in),  # read (+ copy on the store path)
         }
-        dom = max((k for k in k_read if k in alg), key=lambda k: k_read[k]) if k_read else None
+        # (a launch that only waits for CUs while the other stream's kernel runs — the general decoder with nothing
+        # routed to it — is not a candidate: its interval measures its neighbour)
+        idle = {"zstd_decode_general"} if "decode_verify_fused_blocks" in k_read else set()
+        dom = max((k for k in k_read if k in alg and k not in idle), key=lambda k: k_read[k]) if k_read else None
         roofline = None
         if dom:
             ach = alg[dom] / (k_read[dom] * 1e-3) / 1e9
