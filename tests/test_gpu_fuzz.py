@@ -35,17 +35,18 @@ def _mutants(frame: bytes, rng, count):
     return out
 
 
-def _run(gpu_ctx, oracle, bases, per_base, seed, min_ok, min_rej):
+def _run(gpu_ctx, oracle, bases, per_base, seed, min_ok, min_rej, mutants=None):
     import torch
     from znippy_amd import hip
     rng = np.random.default_rng(seed)
+    _m = mutants or _mutants
     frames, sizes, originals = [], [], []
     for data, lvl in bases:
         f = oracle.libzstd_compress(data, lvl)
         g = gpu_ctx.compress(data)                       # this build's own frames too
         for base in (f, g):
             frames.append(base); sizes.append(len(data)); originals.append(data)   # the intact frame as control
-            for m in _mutants(base, rng, per_base):
+            for m in _m(base, rng, per_base):
                 frames.append(m); sizes.append(len(data)); originals.append(data)
     n = len(frames)
     bs = np.array([len(f) for f in frames], dtype=np.uint64)
@@ -95,3 +96,37 @@ def test_mutated_multi_block_frames(gpu_ctx, oracle):
     bases = [(gen.pseudo_text(300_000, 11), 3), (gen.binary(280_000), 19), (gen.text(400_000), 3),
              (gen.incompressible(6, 270_000), 1), (gen.pseudo_text(131_073, 12), 19)]
     _run(gpu_ctx, oracle, bases, 50, 77, 10, 60)
+
+
+def _all_bit_flips(frame: bytes, rng, limit):
+    """Every single-bit flip of the first `limit` bytes and of the last 16 (headers, literals, sequence section)."""
+    n = len(frame)
+    pos = sorted(set(range(min(n, limit))) | set(range(max(0, n - 16), n)))
+    out = []
+    for p in pos:
+        for bit in range(8):
+            b = bytearray(frame); b[p] ^= 1 << bit
+            out.append(bytes(b))
+    return out
+
+
+def _periodic(period, n, seed):
+    rng = np.random.default_rng(seed)
+    p = rng.integers(32, 127, size=period, dtype=np.uint8).tobytes()
+    return (p * (n // period + 1))[:n]
+
+
+def test_every_bit_of_recognised_small_frames(gpu_ctx, oracle):
+    """The lane-parallel recogniser of the fused kernel (parse_fast) against the oracle, exhaustively: every
+    single-bit flip of whole small frames of the shape it takes (literals + one periodic match) — frame header,
+    block header, literals header, the literals, sequence count, modes, bitstream."""
+    bases = [(gen.text(10240), 19), (gen.text(10240), 1), (_periodic(7, 4096, 1), 3), (_periodic(200, 20480, 2), 19),
+             (_periodic(1, 2048, 3), 3), (gen.binary(10240), 3)]
+    _run(gpu_ctx, oracle, bases, 400, 5, 100, 300, mutants=_all_bit_flips)
+
+
+def test_every_bit_of_block_heads_in_big_frames(gpu_ctx, oracle):
+    """Same for the block half of the recogniser (fused block kernel): every bit of the first 96 bytes (frame
+    header + first block) and of the tail of multi-block frames of periodic and raw data."""
+    bases = [(_periodic(45, 3 * 128 * 1024, 4), 3), (gen.incompressible(8, 2 * 128 * 1024 + 5000), 1)]
+    _run(gpu_ctx, oracle, bases, 96, 6, 20, 100, mutants=_all_bit_flips)
