@@ -59,7 +59,37 @@ struct znippy_ctx {
     // kernel timing
     std::vector<KTime> ktimes;
     int n_ktimes = 0;
+    // page-locked host buffers handed back by destroyed tables: locking pages costs ~1 ms per 4 MB, more than a
+    // whole C2 encode pass, so a table takes its result mirror from here when one is big enough
+    std::vector<std::pair<size_t, void *>> pinned_pool;
+    size_t pinned_pool_bytes = 0;
 };
+
+static void *pinned_take(znippy_ctx *ctx, size_t bytes, size_t *cap) {
+    size_t best = ctx->pinned_pool.size();
+    for (size_t i = 0; i < ctx->pinned_pool.size(); i++)
+        if (ctx->pinned_pool[i].first >= bytes && ctx->pinned_pool[i].first <= 4 * bytes + 4096 &&
+            (best == ctx->pinned_pool.size() || ctx->pinned_pool[i].first < ctx->pinned_pool[best].first))
+            best = i;
+    if (best != ctx->pinned_pool.size()) {
+        void *p = ctx->pinned_pool[best].second;
+        *cap = ctx->pinned_pool[best].first;
+        ctx->pinned_pool_bytes -= *cap;
+        ctx->pinned_pool.erase(ctx->pinned_pool.begin() + best);
+        return p;
+    }
+    void *p = nullptr;
+    if (hipHostMalloc(&p, bytes) != hipSuccess) return nullptr;
+    *cap = bytes;
+    return p;
+}
+static void pinned_give(znippy_ctx *ctx, void *p, size_t cap) {
+    if (!p) return;
+    if (ctx->pinned_pool.size() < 16 && ctx->pinned_pool_bytes + cap <= (256ull << 20)) {
+        ctx->pinned_pool.emplace_back(cap, p);
+        ctx->pinned_pool_bytes += cap;
+    } else (void)hipHostFree(p);
+}
 
 struct PlanBuf {
     std::vector<Tile> tiles;
@@ -183,6 +213,7 @@ struct znippy_rounds {
     uint64_t *piece_start = nullptr, *local_excl = nullptr, *block_tot = nullptr;
     // results live in ONE device slab (one D2H per call): [total u64][overflow u64][blob_offset n][blob_size n][digests 32n]
     uint8_t *res = nullptr, *h_res = nullptr;  // device slab + pinned host mirror
+    size_t h_res_cap = 0, h_stored_cap = 0;
     size_t res_bytes = 0;
     bool h_valid = false;
     bool store_incompressible = false;  // opt-in (znippy_rounds_set_store_incompressible)
@@ -283,6 +314,7 @@ void znippy_ctx_destroy(znippy_ctx *ctx) {
     if (ctx->enc_seq) (void)hipFree(ctx->enc_seq);
     if (ctx->enc_tabs) (void)hipFree(ctx->enc_tabs);
     if (ctx->aux) { (void)hipStreamSynchronize(ctx->aux); (void)hipStreamDestroy(ctx->aux); }
+    for (auto &e : ctx->pinned_pool) (void)hipHostFree(e.second);
     if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
     if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
@@ -688,8 +720,8 @@ void znippy_rounds_destroy(znippy_rounds *r) {
     (void)hipSetDevice(r->ctx->device);
     void *ptrs[] = {r->src_off, r->len, r->skip, r->res, r->items, r->piece_len, r->piece_len_init,
                     r->piece_start, r->local_excl, r->block_tot, r->first_item, r->stored, r->order_small, r->order_wide, r->retry_list, r->retry_count};
-    if (r->h_res) (void)hipHostFree(r->h_res);
-    if (r->h_stored) (void)hipHostFree(r->h_stored);
+    pinned_give(r->ctx, r->h_res, r->h_res_cap);
+    pinned_give(r->ctx, r->h_stored, r->h_stored_cap);
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     free_plan(r->plan);
@@ -719,7 +751,8 @@ int znippy_rounds_create(znippy_ctx *ctx, const uint64_t *src_offset, const uint
         return rc;
     }
     r->res_bytes = 16 + (size_t)n * (8 + 8 + 32);
-    if (hipMalloc(&r->res, r->res_bytes) != hipSuccess || hipHostMalloc(&r->h_res, r->res_bytes) != hipSuccess) {
+    if (hipMalloc(&r->res, r->res_bytes) != hipSuccess ||
+        !(r->h_res = (uint8_t *)pinned_take(ctx, r->res_bytes, &r->h_res_cap))) {
         znippy_rounds_destroy(r);
         return ZNIPPY_E_NOMEM;
     }
@@ -774,7 +807,8 @@ int znippy_rounds_create(znippy_ctx *ctx, const uint64_t *src_offset, const uint
     }
     const size_t ni = std::max<size_t>(r->n_items, 1), nsb = (ni + 255) / 256;
     if ((rc = dev_upload(ctx, &r->first_item, first_item.data(), first_item.size())) ||
-        hipMalloc(&r->stored, std::max<size_t>(n, 16)) != hipSuccess || hipHostMalloc(&r->h_stored, std::max<size_t>(n, 16)) != hipSuccess) {
+        hipMalloc(&r->stored, std::max<size_t>(n, 16)) != hipSuccess ||
+        !(r->h_stored = (uint8_t *)pinned_take(ctx, std::max<size_t>(n, 16), &r->h_stored_cap))) {
         znippy_rounds_destroy(r);
         return rc ? rc : ZNIPPY_E_NOMEM;
     }
