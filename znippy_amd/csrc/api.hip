@@ -11,6 +11,7 @@
 #include <cstring>
 #include <string>
 #include <vector>
+#include <unordered_map>
 
 namespace zn {
 size_t decode_lit_scratch_bytes(int grid);
@@ -63,6 +64,9 @@ struct znippy_ctx {
     // whole C2 encode pass, so a table takes its result mirror from here when one is big enough
     std::vector<std::pair<size_t, void *>> pinned_pool;
     size_t pinned_pool_bytes = 0;
+    std::vector<std::pair<size_t, void *>> dev_pool;  // device buffers handed back by destroyed tables
+    std::unordered_map<void *, size_t> dev_sizes;     // capacity of every pooled-kind buffer that is in use
+    size_t dev_pool_bytes = 0;
 };
 
 static void *pinned_take(znippy_ctx *ctx, size_t bytes, size_t *cap) {
@@ -89,6 +93,44 @@ static void pinned_give(znippy_ctx *ctx, void *p, size_t cap) {
         ctx->pinned_pool.emplace_back(cap, p);
         ctx->pinned_pool_bytes += cap;
     } else (void)hipHostFree(p);
+}
+
+// Device memory of the tables (index columns, plans, per-run scratch) comes from a per-context pool: a table is
+// built and torn down per hand-off in the host pipelines, and ~15 hipMalloc + hipFree pairs cost more than the
+// kernels of a small hand-off.  Nothing in a table relies on fresh memory: every array is either uploaded, reset by
+// the run (memset) or written before it is read.
+template <class T>
+static hipError_t tmalloc(znippy_ctx *ctx, T **out, size_t bytes) {
+    bytes = std::max<size_t>(bytes, 16);
+    size_t best = ctx->dev_pool.size();
+    for (size_t i = 0; i < ctx->dev_pool.size(); i++)
+        if (ctx->dev_pool[i].first >= bytes && ctx->dev_pool[i].first <= 2 * bytes + 4096 &&
+            (best == ctx->dev_pool.size() || ctx->dev_pool[i].first < ctx->dev_pool[best].first))
+            best = i;
+    if (best != ctx->dev_pool.size()) {
+        *out = (T *)ctx->dev_pool[best].second;
+        ctx->dev_sizes[*out] = ctx->dev_pool[best].first;
+        ctx->dev_pool_bytes -= ctx->dev_pool[best].first;
+        ctx->dev_pool.erase(ctx->dev_pool.begin() + best);
+        return hipSuccess;
+    }
+    void *p = nullptr;
+    const hipError_t e = hipMalloc(&p, bytes);
+    if (e != hipSuccess) return e;
+    *out = (T *)p;
+    ctx->dev_sizes[p] = bytes;
+    return hipSuccess;
+}
+static void tfree(znippy_ctx *ctx, void *p) {
+    if (!p) return;
+    auto it = ctx->dev_sizes.find(p);
+    if (it == ctx->dev_sizes.end()) { (void)hipFree(p); return; }
+    const size_t cap = it->second;
+    ctx->dev_sizes.erase(it);
+    if (ctx->dev_pool.size() < 96 && ctx->dev_pool_bytes + cap <= (1ull << 30)) {
+        ctx->dev_pool.emplace_back(cap, p);
+        ctx->dev_pool_bytes += cap;
+    } else (void)hipFree(p);
 }
 
 struct PlanBuf {
@@ -140,21 +182,21 @@ static int upload_plan(znippy_ctx *ctx, const PlanBuf &p, DevPlan &d) {
     d.n_tiles = (uint32_t)p.tiles.size();
     d.n_big = (uint32_t)p.big.size();
     if (d.n_tiles) {
-        HIPCHK(ctx, hipMalloc(&d.tiles, sizeof(Tile) * d.n_tiles));
+        HIPCHK(ctx, tmalloc(ctx, &d.tiles, sizeof(Tile) * d.n_tiles));
         HIPCHK(ctx, hipMemcpy(d.tiles, p.tiles.data(), sizeof(Tile) * d.n_tiles, hipMemcpyHostToDevice));
     }
     if (d.n_big) {
-        HIPCHK(ctx, hipMalloc(&d.big, sizeof(BigUnit) * d.n_big));
+        HIPCHK(ctx, tmalloc(ctx, &d.big, sizeof(BigUnit) * d.n_big));
         HIPCHK(ctx, hipMemcpy(d.big, p.big.data(), sizeof(BigUnit) * d.n_big, hipMemcpyHostToDevice));
-        HIPCHK(ctx, hipMalloc(&d.tile_cv, 32 * (size_t)p.n_tile_cv));
+        HIPCHK(ctx, tmalloc(ctx, &d.tile_cv, 32 * (size_t)p.n_tile_cv));
     }
     return ZNIPPY_OK;
 }
 
-static void free_plan(DevPlan &d) {
-    if (d.tiles) (void)hipFree(d.tiles);
-    if (d.big) (void)hipFree(d.big);
-    if (d.tile_cv) (void)hipFree(d.tile_cv);
+static void free_plan(znippy_ctx *ctx, DevPlan &d) {
+    tfree(ctx, d.tiles);
+    tfree(ctx, d.big);
+    tfree(ctx, d.tile_cv);
     d = DevPlan();
 }
 
@@ -241,7 +283,7 @@ static void ktime_end(znippy_ctx *ctx, hipStream_t on = nullptr) {
 
 template <class T>
 static int dev_upload(znippy_ctx *ctx, T **d, const T *h, size_t n) {
-    HIPCHK(ctx, hipMalloc(d, std::max<size_t>(sizeof(T) * n, 16)));
+    HIPCHK(ctx, tmalloc(ctx, d, sizeof(T) * n));
     if (n) HIPCHK(ctx, hipMemcpy(*d, h, sizeof(T) * n, hipMemcpyHostToDevice));
     return ZNIPPY_OK;
 }
@@ -315,6 +357,7 @@ void znippy_ctx_destroy(znippy_ctx *ctx) {
     if (ctx->enc_tabs) (void)hipFree(ctx->enc_tabs);
     if (ctx->aux) { (void)hipStreamSynchronize(ctx->aux); (void)hipStreamDestroy(ctx->aux); }
     for (auto &e : ctx->pinned_pool) (void)hipHostFree(e.second);
+    for (auto &e : ctx->dev_pool) (void)hipFree(e.second);
     if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
     if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
@@ -383,9 +426,9 @@ void znippy_rows_destroy(znippy_rows *r) {
                     r->cand_row, r->cand_base, r->cand_nblocks, r->item_row, r->item_k, r->item_src, r->row_flag, r->pending2,
                     r->bt_tile, r->bt_item, r->tile_done, r->item_done, r->todo};
     for (void *p : ptrs)
-        if (p) (void)hipFree(p);
+        tfree(r->ctx, p);
     if (r->h_counters) (void)hipHostFree(r->h_counters);
-    free_plan(r->plan);
+    free_plan(r->ctx, r->plan);
     delete r;
 }
 
@@ -422,11 +465,11 @@ int znippy_rows_create(znippy_ctx *ctx, const uint64_t *blob_offset, const uint6
         return rc;
     }
     r->corrupt_cap = std::max<uint32_t>(n, 1);
-    if (hipMalloc(&r->status, std::max<size_t>(4 * (size_t)n, 16)) != hipSuccess ||
-        hipMalloc(&r->digests, std::max<size_t>(32 * (size_t)n, 32)) != hipSuccess ||
-        hipMalloc(&r->counters, 128) != hipSuccess ||  // [counters 8 x u64][pending_count] : one memset per run
+    if (tmalloc(ctx, &r->status, std::max<size_t>(4 * (size_t)n, 16)) != hipSuccess ||
+        tmalloc(ctx, &r->digests, std::max<size_t>(32 * (size_t)n, 32)) != hipSuccess ||
+        tmalloc(ctx, &r->counters, 128) != hipSuccess ||  // [counters 8 x u64][pending_count] : one memset per run
         hipHostMalloc(&r->h_counters, 64) != hipSuccess ||
-        hipMalloc(&r->corrupt, 8 * (size_t)r->corrupt_cap) != hipSuccess) {
+        tmalloc(ctx, &r->corrupt, 8 * (size_t)r->corrupt_cap) != hipSuccess) {
         znippy_rows_destroy(r);
         return ZNIPPY_E_NOMEM;
     }
@@ -471,8 +514,8 @@ int znippy_rows_create(znippy_ctx *ctx, const uint64_t *blob_offset, const uint6
             znippy_rows_destroy(r);
             return rc;
         }
-        if (hipMalloc(&r->item_src, 4 * (size_t)r->n_items) != hipSuccess || hipMalloc(&r->row_flag, std::max<size_t>(4 * (size_t)n, 16)) != hipSuccess ||
-            hipMalloc(&r->pending2, std::max<size_t>(4 * (size_t)r->n_cand, 16)) != hipSuccess) {
+        if (tmalloc(ctx, &r->item_src, 4 * (size_t)r->n_items) != hipSuccess || tmalloc(ctx, &r->row_flag, std::max<size_t>(4 * (size_t)n, 16)) != hipSuccess ||
+            tmalloc(ctx, &r->pending2, std::max<size_t>(4 * (size_t)r->n_cand, 16)) != hipSuccess) {
             znippy_rows_destroy(r);
             return ZNIPPY_E_NOMEM;
         }
@@ -493,9 +536,9 @@ int znippy_rows_create(znippy_ctx *ctx, const uint64_t *blob_offset, const uint6
             znippy_rows_destroy(r);
             return rc;
         }
-        if (hipMalloc(&r->tile_done, std::max<size_t>(p.tiles.size(), 16)) != hipSuccess ||
-            hipMalloc(&r->item_done, std::max<size_t>(r->n_items, 16)) != hipSuccess ||
-            hipMalloc(&r->todo, std::max<size_t>(4 * (size_t)r->n_items, 16)) != hipSuccess) {
+        if (tmalloc(ctx, &r->tile_done, std::max<size_t>(p.tiles.size(), 16)) != hipSuccess ||
+            tmalloc(ctx, &r->item_done, std::max<size_t>(r->n_items, 16)) != hipSuccess ||
+            tmalloc(ctx, &r->todo, std::max<size_t>(4 * (size_t)r->n_items, 16)) != hipSuccess) {
             znippy_rows_destroy(r);
             return ZNIPPY_E_NOMEM;
         }
@@ -505,7 +548,7 @@ int znippy_rows_create(znippy_ctx *ctx, const uint64_t *blob_offset, const uint6
         return rc;
     }
     r->pending_count = reinterpret_cast<uint32_t *>(r->counters + 8);
-    if (hipMalloc(&r->pending, std::max<size_t>(4 * (size_t)n, 16)) != hipSuccess ||
+    if (tmalloc(ctx, &r->pending, std::max<size_t>(4 * (size_t)n, 16)) != hipSuccess ||
         false) {
         znippy_rows_destroy(r);
         return ZNIPPY_E_NOMEM;
@@ -723,8 +766,8 @@ void znippy_rounds_destroy(znippy_rounds *r) {
     pinned_give(r->ctx, r->h_res, r->h_res_cap);
     pinned_give(r->ctx, r->h_stored, r->h_stored_cap);
     for (void *p : ptrs)
-        if (p) (void)hipFree(p);
-    free_plan(r->plan);
+        tfree(r->ctx, p);
+    free_plan(r->ctx, r->plan);
     delete r;
 }
 
@@ -751,7 +794,7 @@ int znippy_rounds_create(znippy_ctx *ctx, const uint64_t *src_offset, const uint
         return rc;
     }
     r->res_bytes = 16 + (size_t)n * (8 + 8 + 32);
-    if (hipMalloc(&r->res, r->res_bytes) != hipSuccess ||
+    if (tmalloc(ctx, &r->res, r->res_bytes) != hipSuccess ||
         !(r->h_res = (uint8_t *)pinned_take(ctx, r->res_bytes, &r->h_res_cap))) {
         znippy_rounds_destroy(r);
         return ZNIPPY_E_NOMEM;
@@ -801,13 +844,13 @@ int znippy_rounds_create(znippy_ctx *ctx, const uint64_t *src_offset, const uint
         znippy_rounds_destroy(r);
         return rc;
     }
-    if (hipMalloc(&r->retry_list, std::max<size_t>(4 * (size_t)r->n_small, 16)) != hipSuccess || hipMalloc(&r->retry_count, 64) != hipSuccess) {
+    if (tmalloc(ctx, &r->retry_list, std::max<size_t>(4 * (size_t)r->n_small, 16)) != hipSuccess || tmalloc(ctx, &r->retry_count, 64) != hipSuccess) {
         znippy_rounds_destroy(r);
         return ZNIPPY_E_NOMEM;
     }
     const size_t ni = std::max<size_t>(r->n_items, 1), nsb = (ni + 255) / 256;
     if ((rc = dev_upload(ctx, &r->first_item, first_item.data(), first_item.size())) ||
-        hipMalloc(&r->stored, std::max<size_t>(n, 16)) != hipSuccess ||
+        tmalloc(ctx, &r->stored, std::max<size_t>(n, 16)) != hipSuccess ||
         !(r->h_stored = (uint8_t *)pinned_take(ctx, std::max<size_t>(n, 16), &r->h_stored_cap))) {
         znippy_rounds_destroy(r);
         return rc ? rc : ZNIPPY_E_NOMEM;
@@ -817,8 +860,8 @@ int znippy_rounds_create(znippy_ctx *ctx, const uint64_t *src_offset, const uint
         znippy_rounds_destroy(r);
         return rc;
     }
-    if (hipMalloc(&r->piece_len, 4 * ni) != hipSuccess || hipMalloc(&r->piece_start, 8 * ni) != hipSuccess ||
-        hipMalloc(&r->local_excl, 8 * ni) != hipSuccess || hipMalloc(&r->block_tot, 8 * nsb) != hipSuccess ||
+    if (tmalloc(ctx, &r->piece_len, 4 * ni) != hipSuccess || tmalloc(ctx, &r->piece_start, 8 * ni) != hipSuccess ||
+        tmalloc(ctx, &r->local_excl, 8 * ni) != hipSuccess || tmalloc(ctx, &r->block_tot, 8 * nsb) != hipSuccess ||
         false) {
         znippy_rounds_destroy(r);
         return ZNIPPY_E_NOMEM;
