@@ -597,11 +597,8 @@ int znippy_decode_verify_rows_async(znippy_ctx *ctx, znippy_rows *r, const void 
             (void)hipMemset(dbg, 0, 64);
             f.dbg_buf = dbg;
         }
-        { const char *e = getenv("ZNIPPY_STAGGER"); f.stagger = e ? (uint32_t)atoi(e) : 0; }
         if (f.dbg & (16 | 32 | 64)) set_fused_abl(f.dbg);
         { const char *e = getenv("ZNIPPY_LDS_PAD"); f.lds_pad = e ? (uint32_t)atoi(e) : 0; }
-        f.tile_cursor = ctx->cursor + 2;
-        f.grid = (uint32_t)ctx->decode_grid;
         ktime_begin(ctx, "decode_verify_fused");
         launch_fused_small(f, s);
         ktime_end(ctx);

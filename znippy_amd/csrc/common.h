@@ -93,12 +93,12 @@ struct FusedArgs {
     int32_t *status;
     uint32_t *pending;
     uint32_t *pending_count;
-    int dbg;  // diagnostic builds only (ZNIPPY_DBG): 1 = skip hash, 2 = skip decode
+    // diagnostic only (ZNIPPY_DBG, bit set): 1 skip the hash, 2 skip the decode, 4 hash recognised rows from the output
+    // instead of their windows, 8 phase stamps -> dbg_buf, 16 no row stores, 32 no pattern expansion (scalar decoder),
+    // 64 no s_setprio on the scalar decoder, 128 no lane-parallel recognition, 256 parent trees folded per wave
+    int dbg;
     unsigned long long *dbg_buf;  // diagnostic stamps (ZNIPPY_DBG & 8)
     uint32_t lds_pad;  // extra dynamic LDS per block: caps blocks/CU (in-flight footprint vs Infinity Cache)
-    uint32_t stagger;  // start-up skew per hardware wave slot, in units of 127*64 cycles
-    uint32_t *tile_cursor;  // atomic work cursor of the persistent blocks (zeroed before the launch)
-    uint32_t grid;          // resident blocks: 4 per CU
 };
 
 // Block items of the common shape (fused_small.hip, k_fused_blocks): the big-slice tiles of block-candidate rows.
