@@ -137,6 +137,10 @@ struct PlanBuf {
     std::vector<Tile> tiles;
     std::vector<BigUnit> big;
     uint32_t n_tile_cv = 0;
+    // units with more than 64 tile CVs: their CVs are first folded in groups of 64 by independent waves
+    // (group g of big unit b: grp_big[g] = b, first CV = big[b].cv_base + 64 * grp_k[g]); results live behind the
+    // tile CVs, from BigUnit::pad on
+    std::vector<uint32_t> grp_big, grp_k;
 };
 
 // Greedy tile plan over unit lengths: whole small units are packed until a wave's 64 lanes are
@@ -154,6 +158,8 @@ static void build_plan(const uint64_t *len, uint32_t n, PlanBuf &p) {
             flush();
             uint32_t n_cvs = (uint32_t)((leaves64 + 63) / 64);
             p.big.push_back(BigUnit{u, p.n_tile_cv, n_cvs, 0});
+            if (n_cvs > 64)
+                for (uint32_t g = 0; g < (n_cvs + 63) / 64; g++) { p.grp_big.push_back((uint32_t)p.big.size() - 1); p.grp_k.push_back(g); }
             for (uint32_t t = 0; t < n_cvs; t++) {
                 uint32_t first = t * 64;
                 uint32_t nl = (uint32_t)std::min<uint64_t>(64, leaves64 - first);
@@ -169,12 +175,17 @@ static void build_plan(const uint64_t *len, uint32_t n, PlanBuf &p) {
         }
     }
     flush();
+    uint32_t gb = 0;  // where each grouped unit's group CVs start (behind all tile CVs)
+    for (BigUnit &b : p.big)
+        if (b.n_cvs > 64) { b.pad = p.n_tile_cv + gb; gb += (b.n_cvs + 63) / 64; }
 }
 
 struct DevPlan {
     Tile *tiles = nullptr;
     BigUnit *big = nullptr;
     uint32_t *tile_cv = nullptr;
+    uint32_t *grp_big = nullptr, *grp_k = nullptr;
+    uint32_t n_grp = 0;
     uint32_t n_tiles = 0, n_big = 0;
 };
 
@@ -188,7 +199,14 @@ static int upload_plan(znippy_ctx *ctx, const PlanBuf &p, DevPlan &d) {
     if (d.n_big) {
         HIPCHK(ctx, tmalloc(ctx, &d.big, sizeof(BigUnit) * d.n_big));
         HIPCHK(ctx, hipMemcpy(d.big, p.big.data(), sizeof(BigUnit) * d.n_big, hipMemcpyHostToDevice));
-        HIPCHK(ctx, tmalloc(ctx, &d.tile_cv, 32 * (size_t)p.n_tile_cv));
+        HIPCHK(ctx, tmalloc(ctx, &d.tile_cv, 32 * ((size_t)p.n_tile_cv + p.grp_big.size())));
+        d.n_grp = (uint32_t)p.grp_big.size();
+        if (d.n_grp) {
+            HIPCHK(ctx, tmalloc(ctx, &d.grp_big, 4 * (size_t)d.n_grp));
+            HIPCHK(ctx, tmalloc(ctx, &d.grp_k, 4 * (size_t)d.n_grp));
+            HIPCHK(ctx, hipMemcpy(d.grp_big, p.grp_big.data(), 4 * (size_t)d.n_grp, hipMemcpyHostToDevice));
+            HIPCHK(ctx, hipMemcpy(d.grp_k, p.grp_k.data(), 4 * (size_t)d.n_grp, hipMemcpyHostToDevice));
+        }
     }
     return ZNIPPY_OK;
 }
@@ -197,6 +215,8 @@ static void free_plan(znippy_ctx *ctx, DevPlan &d) {
     tfree(ctx, d.tiles);
     tfree(ctx, d.big);
     tfree(ctx, d.tile_cv);
+    tfree(ctx, d.grp_big);
+    tfree(ctx, d.grp_k);
     d = DevPlan();
 }
 
@@ -699,7 +719,7 @@ int znippy_decode_verify_rows_async(znippy_ctx *ctx, znippy_rows *r, const void 
     ktime_end(ctx);
     if (r->plan.n_big) {
         ktime_begin(ctx, "blake3_merge_big");
-        launch_merge_big(r->plan.big, r->plan.n_big, r->plan.tile_cv, r->digests, s);
+        launch_merge_big(r->plan.big, r->plan.n_big, r->plan.tile_cv, r->digests, r->plan.grp_big, r->plan.grp_k, r->plan.n_grp, s);
         ktime_end(ctx);
     }
     ktime_begin(ctx, "verify");
@@ -886,7 +906,7 @@ static int hash_rounds_async(znippy_ctx *ctx, znippy_rounds *r, const void *d_sr
     ktime_end(ctx, s);
     if (r->plan.n_big) {
         ktime_begin(ctx, "blake3_merge_big", s);
-        launch_merge_big(r->plan.big, r->plan.n_big, r->plan.tile_cv, r->digests, s);
+        launch_merge_big(r->plan.big, r->plan.n_big, r->plan.tile_cv, r->digests, r->plan.grp_big, r->plan.grp_k, r->plan.n_grp, s);
         ktime_end(ctx, s);
     }
     HIPCHK(ctx, hipGetLastError());

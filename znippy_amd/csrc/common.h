@@ -26,7 +26,7 @@ struct BigUnit {  // a unit with more than 64 leaves
     uint32_t unit;
     uint32_t cv_base;  // first tile CV of this unit in tile_cv
     uint32_t n_cvs;    // ceil(leaves/64) >= 2
-    uint32_t pad;
+    uint32_t pad;      // n_cvs > 64: index (in CVs) of this unit's group CVs in tile_cv, ceil(n_cvs/64) of them
 };
 
 // Where each unit's bytes live.  Units with sel==0 (or all units when sel==nullptr) are hashed
@@ -117,7 +117,8 @@ void launch_fused_blocks(const FusedBlocksArgs &a, hipStream_t s);
 void launch_hash_tiles(const HashArgs &a, hipStream_t s);
 void launch_fused_small(const FusedArgs &a, hipStream_t s);
 void init_fused_tables();
-void launch_merge_big(const BigUnit *big, uint32_t n_big, uint32_t *tile_cv, uint32_t *digests, hipStream_t s);
+void launch_merge_big(const BigUnit *big, uint32_t n_big, uint32_t *tile_cv, uint32_t *digests, const uint32_t *grp_big,
+                      const uint32_t *grp_k, uint32_t n_grp, hipStream_t s);
 void launch_verify(const uint32_t *digests, const uint8_t *checksum, const uint64_t *usize,
                    const int32_t *status, uint32_t n_rows, uint64_t row_begin, uint64_t *counters,
                    uint64_t *corrupt_rows, uint32_t corrupt_cap, hipStream_t s);

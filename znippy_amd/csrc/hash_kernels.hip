@@ -71,13 +71,37 @@ void launch_hash_tiles(const HashArgs &a, hipStream_t s) {
 // Finish units with more than 64 leaves: one wave folds the unit's tile CVs (each the root of
 // a complete 64-leaf subtree, the last possibly partial) level by level, in place, then the
 // last <= 64 nodes in registers.
+// Units with more than 64 tile CVs (rows above 4 MiB): the level-by-level fold of one wave is a chain of
+// n_cvs / 32 dependent compress passes (a 200 MiB row: 100 of them, a 2 GiB row: 1,000).  Six levels of pairing turn
+// every aligned group of 64 CVs — the last, shorter one included, with the odd node carried as in the tree — into
+// one node whatever its neighbours are, so the groups are folded by independent waves first and the per-unit wave
+// starts from ceil(n_cvs / 64) nodes.
+__global__ __launch_bounds__(64) void k_merge_groups(const BigUnit *big, const uint32_t *grp_big, const uint32_t *grp_k,
+                                                    uint32_t n_grp, uint32_t *tile_cv) {
+    const uint32_t lane = threadIdx.x;
+    if (blockIdx.x >= n_grp) return;
+    const BigUnit u = big[grp_big[blockIdx.x]];
+    const uint32_t g = grp_k[blockIdx.x];
+    const uint32_t cnt = u.n_cvs - 64 * g < 64 ? u.n_cvs - 64 * g : 64;
+    const uint32_t *base = tile_cv + ((size_t)u.cv_base + 64 * g) * 8;
+    uint32_t cv[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) cv[i] = lane < cnt ? base[(size_t)lane * 8 + i] : 0u;
+    fold_segments(cv, 0, lane < cnt ? cnt : 0, false);
+    if (lane == 0) {
+#pragma unroll
+        for (int i = 0; i < 8; i++) tile_cv[((size_t)u.pad + g) * 8 + i] = cv[i];
+    }
+}
+
 __global__ __launch_bounds__(64) void k_merge_big(const BigUnit *big, uint32_t n_big, uint32_t *tile_cv,
                                                  uint32_t *digests) {
     const uint32_t lane = threadIdx.x;
     if (blockIdx.x >= n_big) return;
     const BigUnit u = big[blockIdx.x];
-    uint32_t *base = tile_cv + (size_t)u.cv_base * 8;
-    uint32_t m = u.n_cvs;
+    const bool grouped = u.n_cvs > 64;  // k_merge_groups has been over this unit
+    uint32_t *base = tile_cv + (size_t)(grouped ? u.pad : u.cv_base) * 8;
+    uint32_t m = grouped ? (u.n_cvs + 63) / 64 : u.n_cvs;
     while (m > 64) {
         uint32_t half = (m + 1) / 2;
         for (uint32_t p = 0; p * 64 < half; p++) {
@@ -116,8 +140,10 @@ __global__ __launch_bounds__(64) void k_merge_big(const BigUnit *big, uint32_t n
     }
 }
 
-void launch_merge_big(const BigUnit *big, uint32_t n_big, uint32_t *tile_cv, uint32_t *digests, hipStream_t s) {
+void launch_merge_big(const BigUnit *big, uint32_t n_big, uint32_t *tile_cv, uint32_t *digests, const uint32_t *grp_big,
+                      const uint32_t *grp_k, uint32_t n_grp, hipStream_t s) {
     if (!n_big) return;
+    if (n_grp) hipLaunchKernelGGL(k_merge_groups, dim3(n_grp), dim3(64), 0, s, big, grp_big, grp_k, n_grp, tile_cv);
     hipLaunchKernelGGL(k_merge_big, dim3(n_big), dim3(64), 0, s, big, n_big, tile_cv, digests);
 }
 
