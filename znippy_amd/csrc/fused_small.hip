@@ -835,6 +835,56 @@ __device__ __forceinline__ void fused_tile(const FusedArgs &a, const uint32_t wa
     l_st[lane] = 0;
     uint32_t need_reread = 0;  // some compressed row of the tile must be hashed from its global output
 
+    // A tile of many small rows has windows for WROWS of them at a time: rows WROWS.. are taken group by group
+    // first — staged, recognised lane-parallel, written straight from their windows, hashed later from the output —
+    // and the windows are then reused for the tile's first rows, which are hashed from them.
+    uint64_t done64 = 0;  // rows already written by this pre-pass
+    if (t.n_units > WROWS && !(a.dbg & (2 | 128))) {
+        FastTabs T;
+        {
+            const DTab eL = c_dll[lane], eM = c_dml[lane], eO = c_dof[lane & 31];
+            T.ll = eL.base | (uint32_t)eL.addbits << 24;
+            T.ml = eM.base | (uint32_t)eM.addbits << 24;
+            T.of = eO.addbits;
+            T.lls = lane < 36 ? c_llb[lane] | (uint32_t)c_lla[lane] << 24 : 0u;
+            T.mls = lane < 53 ? c_mlb[lane] | (uint32_t)c_mla[lane] << 24 : 0u;
+        }
+#pragma unroll 1
+        for (uint32_t g0 = WROWS; g0 < t.n_units; g0 += WROWS) {
+#pragma unroll 1
+            for (uint32_t u = 0; u < WROWS && g0 + u < t.n_units; u++) {
+                const uint64_t so = ((uint64_t)__shfl((uint32_t)(c_src >> 32), g0 + u) << 32) | __shfl((uint32_t)c_src, g0 + u);
+                const uint32_t n = __shfl(c_bs, g0 + u), o = 8 * lane;
+                const uint8_t *p = a.h.srcA + so + o;
+                uint64_t v = 0;
+                if (__shfl(c_sel, g0 + u)) {
+                    if (o + 8 <= n) __builtin_memcpy(&v, p, 8);
+                    else
+                        for (uint32_t k = 0; k < 8; k++)
+                            if (o + k < n) v |= (uint64_t)p[k] << (8 * k);
+                }
+                *reinterpret_cast<uint64_t *>(WL + u * WSTRIDE + 8 * lane) = v;
+                if (lane < (WSTRIDE - WIN) / 4) *reinterpret_cast<uint32_t *>(WL + u * WSTRIDE + WIN + 4 * lane) = 0;
+            }
+            const uint32_t gl = g0 + lane < 64 ? g0 + lane : 63;
+            const uint32_t g_sel = __shfl(c_sel, gl), g_bs = __shfl(c_bs, gl);
+            const uint64_t g_len = ((uint64_t)__shfl((uint32_t)(c_len >> 32), gl) << 32) | __shfl((uint32_t)c_len, gl);
+            const uint64_t g_oo = ((uint64_t)__shfl((uint32_t)(c_oo >> 32), gl) << 32) | __shfl((uint32_t)c_oo, gl);
+            const bool want = lane < WROWS && g0 + lane < t.n_units && g_sel && g_oo + g_len <= a.out_cap;
+            const FastRow f = parse_fast(WL + (lane < WROWS ? lane : 0) * WSTRIDE, g_bs, g_len, want, T);
+            const uint32_t m = (uint32_t)__ballot(f.ok != 0);
+            if (m) {
+                Emitter e2;
+                e2.WL = WL; e2.outbase = a.h.srcB; e2.lane = lane;
+                e2.f_lit = f.lit_at; e2.f_L0 = f.L0; e2.f_off = f.off; e2.c_len_lo = (uint32_t)g_len; e2.c_oo = g_oo;
+                e2.prepare(m);
+                e2.drain();
+                done64 |= (uint64_t)m << g0;
+                need_reread = 1;
+            }
+        }
+    }
+
     if (!(a.dbg & 2)) {
         const uint32_t nw = t.n_units < WROWS ? t.n_units : WROWS;
         uint2 wv[WROWS];
@@ -906,7 +956,7 @@ __device__ __forceinline__ void fused_tile(const FusedArgs &a, const uint32_t wa
         const uint64_t ooff = ((uint64_t)uni((uint32_t)(__shfl(c_oo, u) >> 32)) << 32) | uni((uint32_t)__shfl(c_oo, u));
         const uint64_t soff = ((uint64_t)uni((uint32_t)(__shfl(c_src, u) >> 32)) << 32) | uni((uint32_t)__shfl(c_src, u));
         const uint32_t bsz = uni(__shfl(c_bs, u));
-        if (fmask >> u & 1) continue;  // recognised row: written by the emitter
+        if ((u < 32 && (fmask >> u & 1)) || (done64 >> u & 1)) continue;  // recognised row: written from its window
         int rc;
         Periodic per;
         per.ok = 0;
