@@ -124,6 +124,9 @@ struct LeafOut {
 // 16-byte stores 1 KiB away from every other lane's — 64 different cache lines per store instruction, which
 // measured ~60 ns of SIMD time each (tools/ubench_b3.hip).  With a stage the block goes through LDS instead and
 // leaves transposed: four lanes write one leaf's 64 contiguous bytes, 16 leaves per instruction.
+#ifndef ZN_STAGE_LOADS
+#define ZN_STAGE_LOADS 1
+#endif
 constexpr uint32_t STAGE_SLOT = 80;  // 64 + 16: consecutive lanes' slots start 20 banks apart (conflict-free b128)
 constexpr uint32_t STAGE_BYTES = 64 * STAGE_SLOT;
 typedef __attribute__((address_space(3))) u4v lds_u4a;  // 16-byte aligned LDS vector
@@ -279,11 +282,61 @@ __device__ __forceinline__ void hash_tile_leaves(const HashArgs &a, const Tile &
                                        (b == 15 ? (b3::CHUNK_END | (single ? b3::ROOT : 0u)) : 0u);
                 b3::compress(cv, m, k, 0, 64, flags);
             };
-            if (COPY && stage) {
+            if (COPY && stage && !LDSRC && ZN_STAGE_LOADS) {
+                // both directions through the stage: lane l moves piece l%4 of leaves 16j + l/4 (j = 0..3), so a load
+                // or a store instruction covers 16 leaves x 64 contiguous bytes.  A block's registers are written to
+                // the stage (every lane then reads its own leaf's block back) and stored to the output as they are.
+                // Order inside a pass: stage write, NEXT block's loads, then this block's stores — vmcnt completes in
+                // order, so the wait for the next block must not have this block's stores in front of it.
+                const uint64_t has = __ballot(active && dst != nullptr), act = __ballot(active);
+                const uint8_t *sj[4];
+                uint8_t *pj[4];
+                bool onj[4], actj[4];
+                lds_u4a *rs[4];
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const uint32_t leaf = 16 * j + (lane >> 2);
+                    const uint64_t d64 = (uint64_t)(uintptr_t)dst, s64 = (uint64_t)(uintptr_t)src;
+                    const uint64_t g = ((uint64_t)__shfl((uint32_t)(d64 >> 32), leaf) << 32) | __shfl((uint32_t)d64, leaf);
+                    const uint64_t h = ((uint64_t)__shfl((uint32_t)(s64 >> 32), leaf) << 32) | __shfl((uint32_t)s64, leaf);
+                    pj[j] = reinterpret_cast<uint8_t *>((uintptr_t)g) + 16 * (lane & 3);
+                    sj[j] = reinterpret_cast<const uint8_t *>((uintptr_t)h) + 16 * (lane & 3);
+                    onj[j] = (has >> leaf) & 1;
+                    actj[j] = (act >> leaf) & 1;
+                    rs[j] = (lds_u4a *)(stage + leaf * STAGE_SLOT + 16 * (lane & 3));
+                }
+                const lds_u4a *ws = (const lds_u4a *)(stage + lane * STAGE_SLOT);
+                uint4 v[4], vn[4];
+#pragma unroll
+                for (int j = 0; j < 4; j++) { v[j] = make_uint4(0, 0, 0, 0); vn[j] = v[j]; if (actj[j]) v[j] = ld16(sj[j]); }
+#pragma unroll 1
+                for (uint32_t b = 0; b < 16; b++) {
+#pragma unroll
+                    for (int j = 0; j < 4; j++)
+                        if (actj[j]) *rs[j] = u4v{v[j].x, v[j].y, v[j].z, v[j].w};
+                    if (b < 15) {
+#pragma unroll
+                        for (int j = 0; j < 4; j++)
+                            if (actj[j]) vn[j] = ld16(sj[j] + (b + 1) * 64);
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; j++)
+                        if (onj[j]) st16(pj[j] + b * 64, v[j]);
+                    if (active) {
+                        const u4v a0 = ws[0], a1 = ws[1], a2 = ws[2], a3 = ws[3];
+                        uint32_t m[16] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w, a2.x, a2.y, a2.z, a2.w, a3.x, a3.y, a3.z, a3.w};
+                        const uint32_t flags = (b == 0 ? b3::CHUNK_START : 0u) |
+                                               (b == 15 ? (b3::CHUNK_END | (single ? b3::ROOT : 0u)) : 0u);
+                        b3::compress(cv, m, k, 0, 64, flags);
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; j++) v[j] = vn[j];
+                }
+            } else if (COPY && stage) {
                 // the copy goes out transposed: every lane leaves its block in its stage slot, then lane l stores
                 // piece l%4 of leaves 16j + l/4 (j = 0..3) — 16 leaves x 64 contiguous bytes per store instruction.
-                // (Staging the LOADS the same way measured slower: the LDS round trip lands in front of every
-                // compression and the scattered loads are cheap to begin with.)
+                // (store-only form, kept for ZN_STAGE_LOADS=0: with aligned sources it is as fast as the two-way form
+                // above; raw blocks inside a frame start at odd addresses and gain 16 % from coalesced loads)
                 const uint64_t has = __ballot(active && dst != nullptr);
                 uint8_t *pj[4];
                 bool onj[4];
