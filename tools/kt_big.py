@@ -1,5 +1,6 @@
 """Diagnostic: per-kernel times of the read step on big rows (C3 shape: N x 8 MiB of periodic text, numpy-built so
-that the script also runs under rocprofv3 --pmc).  Usage: python tools/kt_big.py [rows=64] [kind=text|random]"""
+that the script also runs under rocprofv3 --pmc).  Usage: python tools/kt_big.py [rows=64] [kind=text|random|stored]
+(stored = random bytes on the store path: rows not compressed, hash + copy)"""
 import os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -18,10 +19,12 @@ else:
 d_src = torch.from_numpy(src).cuda()
 lens = np.full(n, sz, np.uint64)
 offs = np.arange(n, dtype=np.uint64) * sz
-rounds = hip.RoundTable(ctx, offs, lens)
+skip = np.ones(n, np.uint8) if kind == "stored" else None
+rounds = hip.RoundTable(ctx, offs, lens, skip)
 d_blob = torch.zeros(rounds.blob_bound() + 64, dtype=torch.uint8, device="cuda")
 enc = rounds.encode_hash(d_src, d_blob)
-rows = hip.RowTable(ctx, enc["blob_offset"], enc["blob_size"], lens, offs, None, enc["checksum"])
+bitmap = np.packbits(enc["compressed"].astype(bool), bitorder="little")
+rows = hip.RowTable(ctx, enc["blob_offset"], enc["blob_size"], lens, offs, bitmap, enc["checksum"])
 d_out = torch.zeros(n * sz + 64, dtype=torch.uint8, device="cuda")
 acc = {}
 for i in range(8):

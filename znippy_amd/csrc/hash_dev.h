@@ -131,9 +131,12 @@ constexpr uint32_t STAGE_SLOT = 80;  // 64 + 16: consecutive lanes' slots start 
 constexpr uint32_t STAGE_BYTES = 64 * STAGE_SLOT;
 typedef __attribute__((address_space(3))) u4v lds_u4a;  // 16-byte aligned LDS vector
 
-template <bool COPY, bool LDSRC = false>
+constexpr uint32_t STAGE_FULL_SLOT = 144;  // 128 + 16: whole cache lines per leaf (big-slice tiles of the store path)
+constexpr uint32_t STAGE_FULL_BYTES = 64 * STAGE_FULL_SLOT;
+
 // `raw_src` (big-slice tiles, fused block kernel): the tile's bytes are copied from raw_src + leaf offset instead of
 // the unit's own source column (a raw block of a compressed frame: blob -> output while hashing).
+template <bool COPY, bool LDSRC = false, bool STAGE_FULL = false>
 __device__ __forceinline__ void hash_tile_leaves(const HashArgs &a, const Tile &t, const LdsSrc *ls, LeafOut &out,
                                                  uint8_t *stage = nullptr, const uint8_t *raw_src = nullptr) {
     const uint32_t lane = threadIdx.x & 63;
@@ -282,7 +285,53 @@ __device__ __forceinline__ void hash_tile_leaves(const HashArgs &a, const Tile &
                                        (b == 15 ? (b3::CHUNK_END | (single ? b3::ROOT : 0u)) : 0u);
                 b3::compress(cv, m, k, 0, 64, flags);
             };
-            if (COPY && stage && !LDSRC && ZN_STAGE_LOADS) {
+            if (COPY && STAGE_FULL && stage && !LDSRC && t.n_units == 0 && __ballot(active && dst == nullptr) == 0ull) {
+                // Big-slice tile of the store path, whole cache lines: a leaf's bytes move 128 at a time (two blocks), 8
+                // lanes per leaf, 8 leaves per instruction — the 64-byte form fetched every line from HBM twice (PMC:
+                // 1.8x the bytes), once for each half, a compression apart.  The tile's 64 leaves are contiguous, so
+                // the transposed addresses are one base + 8 KiB steps.
+                // lane 0 is the tile's first leaf (always active): its pointers are the tile's base
+                const uint64_t sb = ((uint64_t)__shfl((uint32_t)((uint64_t)(uintptr_t)src >> 32), 0) << 32) | __shfl((uint32_t)(uintptr_t)src, 0);
+                const uint64_t db = ((uint64_t)__shfl((uint32_t)((uint64_t)(uintptr_t)dst >> 32), 0) << 32) | __shfl((uint32_t)(uintptr_t)dst, 0);
+                const uint8_t *const s0 = reinterpret_cast<const uint8_t *>((uintptr_t)sb) + ((uint64_t)(lane >> 3) << 10) + 16 * (lane & 7);
+                uint8_t *const d0 = reinterpret_cast<uint8_t *>((uintptr_t)db) + ((uint64_t)(lane >> 3) << 10) + 16 * (lane & 7);
+                const uint64_t act = __ballot(active);
+                bool actj[8];
+#pragma unroll
+                for (int j = 0; j < 8; j++) actj[j] = (act >> (8 * j + (lane >> 3))) & 1;
+                lds_u4a *const r0 = (lds_u4a *)(stage + (lane >> 3) * STAGE_FULL_SLOT + 16 * (lane & 7));
+                const lds_u4a *const ws = (const lds_u4a *)(stage + lane * STAGE_FULL_SLOT);
+                uint4 v[8], vn[8];
+#pragma unroll
+                for (int j = 0; j < 8; j++) { v[j] = make_uint4(0, 0, 0, 0); vn[j] = v[j]; if (actj[j]) v[j] = ld16(s0 + j * 8192); }
+#pragma unroll 1
+                for (uint32_t bb = 0; bb < 8; bb++) {
+#pragma unroll
+                    for (int j = 0; j < 8; j++)
+                        if (actj[j]) r0[j * (8 * STAGE_FULL_SLOT / 16)] = u4v{v[j].x, v[j].y, v[j].z, v[j].w};
+                    if (bb < 7) {
+#pragma unroll
+                        for (int j = 0; j < 8; j++)
+                            if (actj[j]) vn[j] = ld16(s0 + j * 8192 + (bb + 1) * 128);
+                    }
+#pragma unroll
+                    for (int j = 0; j < 8; j++)
+                        if (actj[j]) st16(d0 + j * 8192 + bb * 128, v[j]);
+#pragma unroll
+                    for (int h = 0; h < 2; h++) {
+                        if (active) {
+                            const u4v a0 = ws[4 * h], a1 = ws[4 * h + 1], a2 = ws[4 * h + 2], a3 = ws[4 * h + 3];
+                            uint32_t m[16] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w, a2.x, a2.y, a2.z, a2.w, a3.x, a3.y, a3.z, a3.w};
+                            const uint32_t b = 2 * bb + h;
+                            const uint32_t flags = (b == 0 ? b3::CHUNK_START : 0u) |
+                                                   (b == 15 ? (b3::CHUNK_END | (single ? b3::ROOT : 0u)) : 0u);
+                            b3::compress(cv, m, k, 0, 64, flags);
+                        }
+                    }
+#pragma unroll
+                    for (int j = 0; j < 8; j++) v[j] = vn[j];
+                }
+            } else if (COPY && stage && !LDSRC && ZN_STAGE_LOADS) {
                 // both directions through the stage: lane l moves piece l%4 of leaves 16j + l/4 (j = 0..3), so a load
                 // or a store instruction covers 16 leaves x 64 contiguous bytes.  A block's registers are written to
                 // the stage (every lane then reads its own leaf's block back) and stored to the output as they are.

@@ -14,7 +14,7 @@ namespace zn {
 template <bool COPY, int FOLD_G>
 __global__ __launch_bounds__(256) void k_hash_tiles(HashArgs a) {
     __shared__ __attribute__((aligned(16))) uint32_t s_nodes[FOLD_G > 1 ? 4 : 1][FOLD_G > 1 ? FOLD_G * 64 * 8 : 4];
-    __shared__ __attribute__((aligned(16))) uint8_t s_stage[COPY ? 4 : 1][COPY ? STAGE_BYTES : 16];
+    __shared__ __attribute__((aligned(16))) uint8_t s_stage[COPY ? 4 : 1][COPY ? STAGE_FULL_BYTES : 16];
     const uint32_t w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const uint32_t first = (blockIdx.x * 4 + w) * FOLD_G;
     if (first >= a.n_tiles) return;
@@ -37,7 +37,7 @@ __global__ __launch_bounds__(256) void k_hash_tiles(HashArgs a) {
             if (__ballot(mine) == 0ull) continue;
         }
         LeafOut lo;
-        hash_tile_leaves<COPY, false>(a, t, nullptr, lo, COPY ? s_stage[w] : nullptr);
+        hash_tile_leaves<COPY, false, COPY>(a, t, nullptr, lo, COPY ? s_stage[w] : nullptr);
         if (FOLD_G > 1 && FoldQueue<FOLD_G>::fits(t)) fq.add(nodes, g, t, lo);
         else fold_tile_now(a, t, lo);
     }
@@ -61,8 +61,8 @@ void launch_hash_tiles(const HashArgs &a, hipStream_t s) {
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
     }
     const uint64_t resident = (uint64_t)cus * 20;  // 5 waves per SIMD at this kernel's register count
-    // store path: the copy stage takes 5 KiB of LDS per wave, so at most two tiles' nodes beside it (4 blocks per CU)
-    const int cap = a.fold_tiles_max > 0 ? a.fold_tiles_max : (a.copy_to_B ? 2 : 4);
+    // store path: the copy stage takes 9 KiB of LDS per wave (whole lines for big-slice tiles): no node array beside it
+    const int cap = a.fold_tiles_max > 0 ? a.fold_tiles_max : (a.copy_to_B ? 1 : 4);
     if (cap >= 4 && a.n_tiles >= 6 * resident) launch_hash_tiles_g<4>(a, s);
     else if (cap >= 2 && a.n_tiles >= 3 * resident) launch_hash_tiles_g<2>(a, s);
     else launch_hash_tiles_g<1>(a, s);
