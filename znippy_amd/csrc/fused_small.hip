@@ -1053,11 +1053,15 @@ __global__ __launch_bounds__(256, 5) void k_fused_small(FusedArgs a) {
 // this way is skipped by the block decoder and its two tiles by the second hash pass, so the row's bytes are
 // written once and never read back.  Anything else about the block (another shape, a short last block, a frame the
 // scan gave up on) leaves it to those kernels, untouched.
-__global__ __launch_bounds__(256, 5) void k_fused_blocks(FusedBlocksArgs a) {
-    __shared__ __attribute__((aligned(16))) uint32_t s_nodes[4 * 64 * 8];
+__global__ __launch_bounds__(256, 4) void k_fused_blocks(FusedBlocksArgs a) {
+    // one 9 KiB area per wave: the copy stage of a raw block's leaf loop (whole lines), and afterwards — the first
+    // 2 KiB of it — the wave's 64 leaf CVs for the workgroup's fold (node index = byte offset / 32)
+    __shared__ __attribute__((aligned(16))) uint8_t s_area[4][STAGE_FULL_BYTES];
+    uint32_t *const s_nodes = reinterpret_cast<uint32_t *>(&s_area[0][0]);
+    constexpr uint32_t AREA_NODES = STAGE_FULL_BYTES / 32;  // nodes between two waves' areas
+    static_assert(STAGE_FULL_BYTES % 32 == 0, "area must be a whole number of nodes");
     __shared__ uint32_t s_tab[3][4 * FOLD_UNITS];
     __shared__ __attribute__((aligned(16))) uint8_t s_Wb[4][WSTRIDE];
-    __shared__ __attribute__((aligned(16))) uint8_t s_stage[4][STAGE_BYTES];
     __shared__ uint16_t s_d[4][3];
     const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     if (lane < FOLD_UNITS) s_tab[0][w * FOLD_UNITS + lane] = 0;
@@ -1097,13 +1101,13 @@ __global__ __launch_bounds__(256, 5) void k_fused_blocks(FusedBlocksArgs a) {
             if (avail >= 3 && ((bh >> 1) & 3) == 0 && (bh >> 3) == 128 * 1024 && src_pos + 3 + 128 * 1024ull <= n) {
                 // raw block: its bytes sit in the frame — hash them while they are copied out (store-path loop)
                 LeafOut lo;
-                hash_tile_leaves<true, false>(a.h, t, nullptr, lo, s_stage[w], src + 3 - origin);
-                uint4 *d = reinterpret_cast<uint4 *>(s_nodes + (size_t)(w * 64 + lane) * 8);
+                hash_tile_leaves<true, false, true>(a.h, t, nullptr, lo, s_area[w], src + 3 - origin);
+                uint4 *d = reinterpret_cast<uint4 *>(s_nodes + (size_t)(w * AREA_NODES + lane) * 8);
                 d[0] = make_uint4(lo.cv[0], lo.cv[1], lo.cv[2], lo.cv[3]);
                 d[1] = make_uint4(lo.cv[4], lo.cv[5], lo.cv[6], lo.cv[7]);
                 if (lane == 0) {
                     s_tab[0][w * FOLD_UNITS] = 64;
-                    s_tab[1][w * FOLD_UNITS] = w * 64;
+                    s_tab[1][w * FOLD_UNITS] = w * AREA_NODES;
                     s_tab[2][w * FOLD_UNITS] = t.cv_index;
                     a.tile_done[ti] = 1;
                     a.item_done[item] = 1;
@@ -1118,12 +1122,12 @@ __global__ __launch_bounds__(256, 5) void k_fused_blocks(FusedBlocksArgs a) {
                 LdsSrc ls{WL, &s_d[w][0], &s_d[w][1], &s_d[w][2], 1, nullptr, 0, 0, 0, 0, (a.dbg & 16) ? 0u : 1u, origin};
                 LeafOut lo;
                 hash_tile_leaves<true, true>(a.h, t, &ls, lo);
-                uint4 *d = reinterpret_cast<uint4 *>(s_nodes + (size_t)(w * 64 + lane) * 8);
+                uint4 *d = reinterpret_cast<uint4 *>(s_nodes + (size_t)(w * AREA_NODES + lane) * 8);
                 d[0] = make_uint4(lo.cv[0], lo.cv[1], lo.cv[2], lo.cv[3]);
                 d[1] = make_uint4(lo.cv[4], lo.cv[5], lo.cv[6], lo.cv[7]);
                 if (lane == 0) {
                     s_tab[0][w * FOLD_UNITS] = 64;
-                    s_tab[1][w * FOLD_UNITS] = w * 64;
+                    s_tab[1][w * FOLD_UNITS] = w * AREA_NODES;
                     s_tab[2][w * FOLD_UNITS] = t.cv_index;
                     a.tile_done[ti] = 1;
                     a.item_done[item] = 1;  // the block's other tile comes to the same verdict (same block, same test)
