@@ -1121,7 +1121,7 @@ __global__ __launch_bounds__(256, 4) void k_fused_blocks(FusedBlocksArgs a) {
                 if (lane == 0) { s_d[w][0] = (uint16_t)lit_at; s_d[w][1] = (uint16_t)(L0 - off); s_d[w][2] = (uint16_t)off; }
                 LdsSrc ls{WL, &s_d[w][0], &s_d[w][1], &s_d[w][2], 1, nullptr, 0, 0, 0, 0, (a.dbg & 16) ? 0u : 1u, origin};
                 LeafOut lo;
-                hash_tile_leaves<true, true>(a.h, t, &ls, lo);
+                hash_tile_leaves<true, true, true>(a.h, t, &ls, lo, s_area[w]);  // row stores leave as whole lines through the stage
                 uint4 *d = reinterpret_cast<uint4 *>(s_nodes + (size_t)(w * AREA_NODES + lane) * 8);
                 d[0] = make_uint4(lo.cv[0], lo.cv[1], lo.cv[2], lo.cv[3]);
                 d[1] = make_uint4(lo.cv[4], lo.cv[5], lo.cv[6], lo.cv[7]);

@@ -285,7 +285,45 @@ __device__ __forceinline__ void hash_tile_leaves(const HashArgs &a, const Tile &
                                        (b == 15 ? (b3::CHUNK_END | (single ? b3::ROOT : 0u)) : 0u);
                 b3::compress(cv, m, k, 0, 64, flags);
             };
-            if (COPY && STAGE_FULL && stage && !LDSRC && t.n_units == 0 && __ballot(active && dst == nullptr) == 0ull) {
+            if (COPY && STAGE_FULL && stage && ALL_LDS && t.n_units == 0 && __ballot(active && dst == nullptr) == 0ull) {
+                // Big-slice tile hashed from a window (fused block kernel): the row stores leave as whole lines too —
+                // every lane drops its blocks in its slot, and every second compression the pair goes out transposed,
+                // 8 lanes x 16 bytes per leaf, 8 leaves per store instruction.
+                const uint64_t db = ((uint64_t)__shfl((uint32_t)((uint64_t)(uintptr_t)dst >> 32), 0) << 32) | __shfl((uint32_t)(uintptr_t)dst, 0);
+                uint8_t *const d0 = reinterpret_cast<uint8_t *>((uintptr_t)db) + ((uint64_t)(lane >> 3) << 10) + 16 * (lane & 7);
+                const uint64_t act = __ballot(active);
+                bool actj[8];
+#pragma unroll
+                for (int j = 0; j < 8; j++) actj[j] = (act >> (8 * j + (lane >> 3))) & 1;
+                const lds_u4a *const r0 = (const lds_u4a *)(stage + (lane >> 3) * STAGE_FULL_SLOT + 16 * (lane & 7));
+                lds_u4a *const ws = (lds_u4a *)(stage + lane * STAGE_FULL_SLOT);
+                if (active) fetch(0);
+#pragma unroll 1
+                for (uint32_t b = 0; b < 16; b++) {
+                    uint32_t m[16];
+                    if (active) {
+                        m[0] = n0.x; m[1] = n0.y; m[2] = n0.z; m[3] = n0.w; m[4] = n1.x; m[5] = n1.y; m[6] = n1.z; m[7] = n1.w;
+                        m[8] = n2.x; m[9] = n2.y; m[10] = n2.z; m[11] = n2.w; m[12] = n3.x; m[13] = n3.y; m[14] = n3.z; m[15] = n3.w;
+                        if (b < 15) fetch(b + 1);
+                        lds_u4a *const wh = ws + 4 * (b & 1);
+                        wh[0] = u4v{m[0], m[1], m[2], m[3]}; wh[1] = u4v{m[4], m[5], m[6], m[7]};
+                        wh[2] = u4v{m[8], m[9], m[10], m[11]}; wh[3] = u4v{m[12], m[13], m[14], m[15]};
+                    }
+                    if (b & 1) {
+#pragma unroll
+                        for (int j = 0; j < 8; j++)
+                            if (actj[j]) {
+                                const u4v v = r0[j * (8 * STAGE_FULL_SLOT / 16)];
+                                st16(d0 + j * 8192 + (b >> 1) * 128, make_uint4(v.x, v.y, v.z, v.w));
+                            }
+                    }
+                    if (active) {
+                        const uint32_t flags = (b == 0 ? b3::CHUNK_START : 0u) |
+                                               (b == 15 ? (b3::CHUNK_END | (single ? b3::ROOT : 0u)) : 0u);
+                        b3::compress(cv, m, k, 0, 64, flags);
+                    }
+                }
+            } else if (COPY && STAGE_FULL && stage && !LDSRC && t.n_units == 0 && __ballot(active && dst == nullptr) == 0ull) {
                 // Big-slice tile of the store path, whole cache lines: a leaf's bytes move 128 at a time (two blocks), 8
                 // lanes per leaf, 8 leaves per instruction — the 64-byte form fetched every line from HBM twice (PMC:
                 // 1.8x the bytes), once for each half, a compression apart.  The tile's 64 leaves are contiguous, so
