@@ -220,3 +220,28 @@ def test_small_real_rounds_are_handed_to_the_wide_variant(gpu_ctx, oracle):
     sizes = enc["blob_size"]
     assert sizes[:40].sum() < 0.62 * lens[:40].sum()            # the n/40 budget alone leaves ~0.9 here
     assert (sizes[40:48] < 200).all()
+
+
+@pytest.mark.parametrize("sizes", [[5 << 20], [1 << 20, 3 << 20, 160, 70000 * 16, (2 << 20) + 7],
+                                   [1 << 20, (1 << 20) + 3, 1 << 20], [100, 1 << 20]])
+def test_store_path_tables_blob_is_the_input(gpu_ctx, oracle, sizes):
+    """Tables of skip rounds only (the one-big-jar case): with every blob offset a multiple of 16 the hash kernel
+    copies the rounds while it hashes them (no gather pass over the stored bytes); with an odd length in the middle
+    the two-pass form runs.  Either way the blob region is the input, packed without gaps, and the digests are right."""
+    import torch
+    from znippy_amd import hip
+    data = [gen.incompressible(i + 1, n) for i, n in enumerate(sizes)]
+    src = np.frombuffer(b"".join(data), dtype=np.uint8)
+    lens = np.array(sizes, dtype=np.uint64)
+    offs = np.concatenate([[0], np.cumsum(lens)[:-1]]).astype(np.uint64)
+    d_src = torch.from_numpy(src.copy()).cuda()
+    rounds = hip.RoundTable(gpu_ctx, offs, lens, np.ones(len(sizes), np.uint8))
+    d_blob = torch.zeros(rounds.blob_bound() + 64, dtype=torch.uint8, device="cuda")
+    for _ in range(2):
+        d_blob.zero_()
+        enc = rounds.encode_hash(d_src, d_blob)
+        assert list(enc["blob_offset"]) == list(offs) and list(enc["blob_size"]) == sizes
+        assert not enc["compressed"].any() and enc["blob_bytes"] == len(src)
+        assert np.array_equal(d_blob.cpu().numpy()[:len(src)], src)
+        for i, d in enumerate(data):
+            assert bytes(enc["checksum"][i]) == oracle.blake3(d)

@@ -259,6 +259,7 @@ struct znippy_rounds {
     std::vector<uint64_t> h_len, h_off;
     std::vector<uint8_t> h_skip;
     uint64_t in_bytes = 0, enc_bytes = 0;  // all rounds / rounds that go through the encoder
+    bool all_stored_aligned = false;       // every round is a skip round and every blob offset will be a multiple of 16
     uint64_t blob_bound = 0;
     DevPlan plan;
     // encoder plan: one item per output piece
@@ -799,11 +800,14 @@ int znippy_rounds_create(znippy_ctx *ctx, const uint64_t *src_offset, const uint
     r->h_off.assign(src_offset, src_offset + n);
     r->h_skip.assign(n, 0);
     if (skip) r->h_skip.assign(skip, skip + n);
+    bool odd_len = false;
     for (uint64_t i = 0; i < n; i++) {
         r->blob_bound += r->h_skip[i] ? len[i] : znippy_compress_bound(len[i]);
         r->in_bytes += len[i];
         if (!r->h_skip[i]) r->enc_bytes += len[i];
+        if (i + 1 < n && (len[i] & 15)) odd_len = true;
     }
+    r->all_stored_aligned = n > 0 && r->enc_bytes == 0 && !odd_len;
     int rc;
     if ((rc = dev_upload(ctx, &r->src_off, src_offset, n)) || (rc = dev_upload(ctx, &r->len, len, n)) ||
         (rc = dev_upload(ctx, &r->skip, r->h_skip.data(), n))) {
@@ -892,13 +896,20 @@ int znippy_rounds_create(znippy_ctx *ctx, const uint64_t *src_offset, const uint
 
 uint64_t znippy_rounds_blob_bound(const znippy_rounds *r) { return r ? r->blob_bound : 0; }
 
-static int hash_rounds_async(znippy_ctx *ctx, znippy_rounds *r, const void *d_src, hipStream_t on = nullptr) {
+// d_copy_out != nullptr: the stored (skip) rounds are copied to d_copy_out + blob_offset[round] while they are hashed
+// (store-heavy tables; blob_offset must have been computed on the stream before)
+static int hash_rounds_async(znippy_ctx *ctx, znippy_rounds *r, const void *d_src, hipStream_t on = nullptr,
+                             void *d_copy_out = nullptr, uint64_t copy_cap = 0) {
     hipStream_t s = on ? on : ctx->stream;
     HashArgs h{};
     h.tiles = r->plan.tiles; h.n_tiles = r->plan.n_tiles;
     h.len = r->len;
     h.srcA = (const uint8_t *)d_src; h.offA = r->src_off; h.baseA = 0;
     h.digests = r->digests; h.tile_cv = r->plan.tile_cv;
+    if (d_copy_out) {
+        h.srcB = (uint8_t *)d_copy_out; h.offB = r->blob_offset; h.copy_to_B = 1;
+        h.copy_mask = r->skip; h.copy_cap = copy_cap;
+    }
     // next to a busy encoder (auxiliary stream) the hash keeps out of LDS: the encoder's residency depends on it
     if (on && r->enc_bytes * 4 >= r->in_bytes) h.fold_tiles_max = 1;
     ktime_begin(ctx, "blake3_tiles", s);
@@ -1043,10 +1054,22 @@ extern "C" int znippy_encode_hash_rounds_async(znippy_ctx *ctx, znippy_rounds *r
     ktime_end(ctx);
     // checksum over the ORIGINAL bytes (stream_packer.rs:L219): VALU-bound, submitted to the
     // auxiliary stream right after the persistent (latency-bound) encoder so both share the CUs
-    HIPCHK(ctx, hipStreamWaitEvent(ctx->aux, ctx->ev_fork, 0));
-    int rc = getenv("ZNIPPY_NOHASH") ? ZNIPPY_OK : hash_rounds_async(ctx, r, d_src, ctx->aux);  // diagnostic switch
-    if (rc) return rc;
-    HIPCHK(ctx, hipEventRecord(ctx->ev_join, ctx->aux));
+    // Store-heavy table (most bytes are skip rounds): hashing and copying the stored bytes are one pass over them once
+    // their blob offsets are known — scan and gather run first (the gather leaves the stored pieces alone), then the
+    // hash kernel copies what it hashes.  Otherwise the hash runs beside the encoder on the auxiliary stream.
+    // (Only when every destination is 16-byte aligned — all rounds stored, lengths multiples of 16: the one-big-jar
+    // case.  Blobs are packed without gaps, so behind a compressed round the offsets are odd, and the hash kernel's
+    // 16-byte stores at odd addresses cost more than the second pass they save: C5 4.45 ms against 4.39 + gather
+    // overlapped.)
+    const bool fuse_store = r->all_stored_aligned && !r->store_incompressible && ((uintptr_t)d_blob_out & 15) == 0 &&
+                            !getenv("ZNIPPY_NO_FUSED_STORE") && !getenv("ZNIPPY_NOHASH");
+    int rc = ZNIPPY_OK;
+    if (!fuse_store) {
+        HIPCHK(ctx, hipStreamWaitEvent(ctx->aux, ctx->ev_fork, 0));
+        rc = getenv("ZNIPPY_NOHASH") ? ZNIPPY_OK : hash_rounds_async(ctx, r, d_src, ctx->aux);  // diagnostic switch
+        if (rc) return rc;
+        HIPCHK(ctx, hipEventRecord(ctx->ev_join, ctx->aux));
+    }
     if (r->store_incompressible) {
         ktime_begin(ctx, "store_decide");
         launch_store_decide(r->first_item, r->items, r->len, r->skip, r->n, r->piece_len, r->stored, s);
@@ -1062,10 +1085,16 @@ extern "C" int znippy_encode_hash_rounds_async(znippy_ctx *ctx, znippy_rounds *r
     g.blob_out = (uint8_t *)d_blob_out; g.blob_cap = blob_cap;
     g.blob_offset = r->blob_offset; g.blob_size = r->blob_size; g.total = r->total; g.overflow = r->overflow;
     g.stored = r->store_incompressible ? r->stored : nullptr;
+    g.skip_stored_copy = fuse_store ? 1 : 0;
     ktime_begin(ctx, "gather");
     launch_gather(g, s);
     ktime_end(ctx);
-    HIPCHK(ctx, hipStreamWaitEvent(s, ctx->ev_join, 0));  // digests are complete once the main stream drains
+    if (fuse_store) {
+        rc = hash_rounds_async(ctx, r, d_src, nullptr, d_blob_out, blob_cap);
+        if (rc) return rc;
+    } else {
+        HIPCHK(ctx, hipStreamWaitEvent(s, ctx->ev_join, 0));  // digests are complete once the main stream drains
+    }
     HIPCHK(ctx, hipGetLastError());
     return ZNIPPY_OK;
 }

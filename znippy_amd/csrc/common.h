@@ -51,6 +51,9 @@ struct HashArgs {
     uint32_t *tile_cv;  // 8 words per big-unit tile
     int fold_tiles_max;  // 0 = pick from the tile count; 1 = no deferred folding (no LDS: the launch shares the CUs with the encoder)
     const uint8_t *tile_done;  // optional, PASS_SECOND: tiles already hashed by the fused block kernel
+    // optional (write side, store-heavy tables): copy only units with copy_mask != 0, and only if they end inside copy_cap
+    const uint8_t *copy_mask;
+    uint64_t copy_cap;
 };
 
 // Row status values on the read side: 0 = done (stored row, or decoded+hashed by the fused

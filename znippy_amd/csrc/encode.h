@@ -69,6 +69,7 @@ struct GatherArgs {
     uint64_t *blob_offset, *blob_size, *total;
     uint32_t *overflow;
     const uint8_t *stored;  // optional: rounds the store-if-incompressible pass turned into raw payloads
+    int skip_stored_copy;   // store-heavy tables: the hash kernel copies the stored rounds while it hashes them
 };
 
 void launch_encode(const EncodeArgs &a, int grid, bool small_blocks, hipStream_t s);

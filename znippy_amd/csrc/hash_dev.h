@@ -203,6 +203,7 @@ __device__ __forceinline__ void hash_tile_leaves(const HashArgs &a, const Tile &
         from_b = a.sel && a.sel[unit];
         src = from_b ? a.srcB + a.offB[unit] : a.srcA + (a.offA[unit] - a.baseA);
         dst = (COPY && !from_b && a.srcB) ? a.srcB + a.offB[unit] : nullptr;
+        if (COPY && dst && a.copy_mask && (!a.copy_mask[unit] || a.offB[unit] + ulen > a.copy_cap)) dst = nullptr;
     }
     if (!LDSRC && COPY && raw_src) {
         src = raw_src;

@@ -889,8 +889,9 @@ __global__ __launch_bounds__(256) void k_gather(GatherArgs g) {
     const uint8_t *s = (it.flags & ITEM_SKIP) ? g.src + g.src_off[it.round] + it.prov : g.prov + g.piece_start[piece];
     if (g.stored && g.stored[it.round]) s = g.src + g.src_off[it.round] + (uint64_t)it.block * BLOCK_BYTES;  // raw bytes of this block
     uint8_t *d = g.blob_out + off;
-    if (off + len <= g.blob_cap) wave_copy(d, s, len, lane);
-    else if (lane == 0) atomicOr(g.overflow, 1u);
+    if (off + len <= g.blob_cap) {
+        if (!(g.skip_stored_copy && (it.flags & ITEM_SKIP))) wave_copy(d, s, len, lane);
+    } else if (lane == 0) atomicOr(g.overflow, 1u);
     if (lane == 0) {
         if (it.flags & ITEM_FIRST) g.blob_offset[it.round] = off;
         atomicAdd(reinterpret_cast<unsigned long long *>(&g.blob_size[it.round]), (unsigned long long)len);
