@@ -231,6 +231,7 @@ struct znippy_rows {
     uint32_t *digests = nullptr;
     uint64_t *counters = nullptr;  // 8 x u64 (+ pending_count behind them)
     uint64_t *h_counters = nullptr;  // pinned mirror, filled by the run's own D2H copy
+    bool odd_out = false;  // some stored row's output offset is not a multiple of 16 (store-path kernel variant)
     uint64_t *corrupt = nullptr;
     uint32_t corrupt_cap = 0;
     uint32_t *list_a = nullptr;   // compressed rows with > 64 leaves: general decoder
@@ -471,6 +472,7 @@ int znippy_rows_create(znippy_ctx *ctx, const uint64_t *blob_offset, const uint6
         uint64_t row = row_begin + i;
         comp[i] = compressed_bitmap ? (compressed_bitmap[row >> 3] >> (row & 7)) & 1 : 1;
         r->n_compressed += comp[i];
+        if (!comp[i] && (out_offset[row] & 15)) r->odd_out = true;
     }
     int rc = ZNIPPY_OK;
     if ((rc = dev_upload(ctx, &r->blob_off, blob_offset + row_begin, n)) ||
@@ -598,6 +600,7 @@ int znippy_decode_verify_rows_async(znippy_ctx *ctx, znippy_rows *r, const void 
     h.srcB = (uint8_t *)d_out; h.offB = r->out_off;
     h.sel = r->compressed; h.status = r->status; h.pending_count = r->pending_count;
     h.copy_to_B = 1;
+    h.misaligned_dst = r->odd_out || ((uintptr_t)d_out & 15) != 0;
     h.digests = r->digests; h.tile_cv = r->plan.tile_cv;
     {
         FusedArgs f{};
@@ -909,6 +912,7 @@ static int hash_rounds_async(znippy_ctx *ctx, znippy_rounds *r, const void *d_sr
     if (d_copy_out) {
         h.srcB = (uint8_t *)d_copy_out; h.offB = r->blob_offset; h.copy_to_B = 1;
         h.copy_mask = r->skip; h.copy_cap = copy_cap;
+        h.misaligned_dst = !(r->all_stored_aligned && ((uintptr_t)d_copy_out & 15) == 0);
     }
     // next to a busy encoder (auxiliary stream) the hash keeps out of LDS: the encoder's residency depends on it
     if (on && r->enc_bytes * 4 >= r->in_bytes) h.fold_tiles_max = 1;
@@ -1057,11 +1061,11 @@ extern "C" int znippy_encode_hash_rounds_async(znippy_ctx *ctx, znippy_rounds *r
     // Store-heavy table (most bytes are skip rounds): hashing and copying the stored bytes are one pass over them once
     // their blob offsets are known — scan and gather run first (the gather leaves the stored pieces alone), then the
     // hash kernel copies what it hashes.  Otherwise the hash runs beside the encoder on the auxiliary stream.
-    // (Only when every destination is 16-byte aligned — all rounds stored, lengths multiples of 16: the one-big-jar
-    // case.  Blobs are packed without gaps, so behind a compressed round the offsets are odd, and the hash kernel's
-    // 16-byte stores at odd addresses cost more than the second pass they save: C5 4.45 ms against 4.39 + gather
-    // overlapped.)
-    const bool fuse_store = r->all_stored_aligned && !r->store_incompressible && ((uintptr_t)d_blob_out & 15) == 0 &&
+    // (Blobs are packed without gaps, so behind a compressed round the offsets are odd: unless every round is stored
+    // and every length a multiple of 16, the launch uses the kernel variant that re-cuts the bytes to 16-byte
+    // boundaries on their way out — plain 16-byte stores at odd addresses cost more than the pass they save.)
+    const bool heavy = r->in_bytes && (r->in_bytes - r->enc_bytes) * 2 >= r->in_bytes;
+    const bool fuse_store = heavy && !r->store_incompressible &&
                             !getenv("ZNIPPY_NO_FUSED_STORE") && !getenv("ZNIPPY_NOHASH");
     int rc = ZNIPPY_OK;
     if (!fuse_store) {

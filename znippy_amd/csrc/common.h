@@ -54,6 +54,7 @@ struct HashArgs {
     // optional (write side, store-heavy tables): copy only units with copy_mask != 0, and only if they end inside copy_cap
     const uint8_t *copy_mask;
     uint64_t copy_cap;
+    int misaligned_dst;  // store path: some copy destination is not 16-byte aligned (host knowledge; picks the kernel variant)
 };
 
 // Row status values on the read side: 0 = done (stored row, or decoded+hashed by the fused

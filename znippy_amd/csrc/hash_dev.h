@@ -136,7 +136,10 @@ constexpr uint32_t STAGE_FULL_BYTES = 64 * STAGE_FULL_SLOT;
 
 // `raw_src` (big-slice tiles, fused block kernel): the tile's bytes are copied from raw_src + leaf offset instead of
 // the unit's own source column (a raw block of a compressed frame: blob -> output while hashing).
-template <bool COPY, bool LDSRC = false, bool STAGE_FULL = false>
+constexpr uint32_t STAGE_SHIFT_SLOT = 160;  // 16 (tail of the previous 128 bytes) + 128 + 16
+constexpr uint32_t STAGE_SHIFT_BYTES = 64 * STAGE_SHIFT_SLOT;
+
+template <bool COPY, bool LDSRC = false, bool STAGE_FULL = false, bool STAGE_SHIFT = false>
 __device__ __forceinline__ void hash_tile_leaves(const HashArgs &a, const Tile &t, const LdsSrc *ls, LeafOut &out,
                                                  uint8_t *stage = nullptr, const uint8_t *raw_src = nullptr) {
     const uint32_t lane = threadIdx.x & 63;
@@ -323,6 +326,74 @@ __device__ __forceinline__ void hash_tile_leaves(const HashArgs &a, const Tile &
                                                (b == 15 ? (b3::CHUNK_END | (single ? b3::ROOT : 0u)) : 0u);
                         b3::compress(cv, m, k, 0, 64, flags);
                     }
+                }
+            } else if (COPY && STAGE_SHIFT && stage && !LDSRC && t.n_units == 0 && __ballot(active && dst == nullptr) == 0ull &&
+                       (__shfl((uint32_t)(uintptr_t)dst, 0) & 15) != 0) {
+                // The same for a destination that is not 16-byte aligned (a stored round behind a compressed one in the
+                // packed blob region): 16-byte stores at odd addresses cost the kernel half its speed, so the bytes are
+                // re-cut on their way out of the stage.  A slot keeps the last 16 bytes of the previous 128 in front of
+                // the current 128; output piece q is read from the slot `dl` bytes early (LDS reads may be unaligned) and
+                // stored at the 16-byte boundary below its place.  What that leaves over — the first 16 - dl bytes of a
+                // leaf and its last dl — goes out as one odd store each at the leaf's first and last step, with bytes of
+                // that leaf only, so no store ever writes bytes another wave is responsible for.
+                const uint64_t sb = ((uint64_t)__shfl((uint32_t)((uint64_t)(uintptr_t)src >> 32), 0) << 32) | __shfl((uint32_t)(uintptr_t)src, 0);
+                const uint64_t db = ((uint64_t)__shfl((uint32_t)((uint64_t)(uintptr_t)dst >> 32), 0) << 32) | __shfl((uint32_t)(uintptr_t)dst, 0);
+                const uint32_t dl = (uint32_t)db & 15, q = lane & 7;
+                const uint8_t *const s0 = reinterpret_cast<const uint8_t *>((uintptr_t)sb) + ((uint64_t)(lane >> 3) << 10) + 16 * q;
+                uint8_t *const d0 = reinterpret_cast<uint8_t *>((uintptr_t)db) + ((uint64_t)(lane >> 3) << 10) + 16 * q;  // my piece's own place
+                const uint64_t act = __ballot(active);
+                bool actj[8];
+#pragma unroll
+                for (int j = 0; j < 8; j++) actj[j] = (act >> (8 * j + (lane >> 3))) & 1;
+                uint8_t *const slot = stage + (lane >> 3) * STAGE_SHIFT_SLOT;  // leaf lane/8 (+ 8j: j * 8 slots further)
+                constexpr uint32_t JS = 8 * STAGE_SHIFT_SLOT;
+                const lds_u4a *const own = (const lds_u4a *)(stage + lane * STAGE_SHIFT_SLOT + 16);
+                uint4 v[8], vn[8];
+#pragma unroll
+                for (int j = 0; j < 8; j++) { v[j] = make_uint4(0, 0, 0, 0); vn[j] = v[j]; if (actj[j]) v[j] = ld16(s0 + j * 8192); }
+#pragma unroll 1
+                for (uint32_t bb = 0; bb < 8; bb++) {
+                    if (bb && q == 7) {  // the previous 128 bytes' tail moves in front before they are overwritten
+#pragma unroll
+                        for (int j = 0; j < 8; j++)
+                            if (actj[j]) *(lds_u4a *)(slot + j * JS) = *(const lds_u4a *)(slot + j * JS + 128);
+                    }
+#pragma unroll
+                    for (int j = 0; j < 8; j++)
+                        if (actj[j]) *(lds_u4a *)(slot + j * JS + 16 + 16 * q) = u4v{v[j].x, v[j].y, v[j].z, v[j].w};
+                    if (bb < 7) {
+#pragma unroll
+                        for (int j = 0; j < 8; j++)
+                            if (actj[j]) vn[j] = ld16(s0 + j * 8192 + (bb + 1) * 128);
+                    }
+                    // piece q, re-cut: bytes [16q - dl, 16q - dl + 16) of the slot's chunk to the boundary below; the
+                    // leaf's very first piece has nothing in front of it: it goes out as it is, to its own odd place
+                    const bool first = bb == 0 && q == 0;
+                    const uint32_t sh = first ? 0u : dl;
+#pragma unroll
+                    for (int j = 0; j < 8; j++)
+                        if (actj[j]) {
+                            const u4v o = *(const lds_u4 *)(slot + j * JS + 16 + 16 * q - sh);
+                            st16(d0 + j * 8192 + bb * 128 - sh, make_uint4(o.x, o.y, o.z, o.w));
+                        }
+                    if (bb == 7 && q == 7) {  // the leaf's last dl bytes: its last 16, to their own odd place
+#pragma unroll
+                        for (int j = 0; j < 8; j++)
+                            if (actj[j]) st16(d0 + j * 8192 + bb * 128, v[j]);
+                    }
+#pragma unroll
+                    for (int h = 0; h < 2; h++) {
+                        if (active) {
+                            const u4v a0 = own[4 * h], a1 = own[4 * h + 1], a2 = own[4 * h + 2], a3 = own[4 * h + 3];
+                            uint32_t m[16] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w, a2.x, a2.y, a2.z, a2.w, a3.x, a3.y, a3.z, a3.w};
+                            const uint32_t b = 2 * bb + h;
+                            const uint32_t flags = (b == 0 ? b3::CHUNK_START : 0u) |
+                                                   (b == 15 ? (b3::CHUNK_END | (single ? b3::ROOT : 0u)) : 0u);
+                            b3::compress(cv, m, k, 0, 64, flags);
+                        }
+                    }
+#pragma unroll
+                    for (int j = 0; j < 8; j++) v[j] = vn[j];
                 }
             } else if (COPY && STAGE_FULL && stage && !LDSRC && t.n_units == 0 && __ballot(active && dst == nullptr) == 0ull) {
                 // Big-slice tile of the store path, whole cache lines: a leaf's bytes move 128 at a time (two blocks), 8

@@ -11,10 +11,12 @@ namespace zn {
 // FOLD_G = tiles per wave whose parent levels are folded together (hash_dev.h, FoldQueue).  More tiles per wave
 // means fewer fold passes but coarser work items; the launcher picks it from the tile count so that a
 // small batch still spreads over every SIMD a few times.
-template <bool COPY, int FOLD_G>
-__global__ __launch_bounds__(256) void k_hash_tiles(HashArgs a) {
+// SHIFT (store path only): the variant that can re-cut the bytes for destinations that are not 16-byte aligned; it
+// needs more registers and LDS than the plain one, so it is launched only when the host knows of such a destination.
+template <bool COPY, int FOLD_G, bool SHIFT = false>
+__global__ __launch_bounds__(256, SHIFT ? 4 : 1) void k_hash_tiles(HashArgs a) {  // SHIFT: 40 KB of stage per block, held at 128 registers
     __shared__ __attribute__((aligned(16))) uint32_t s_nodes[FOLD_G > 1 ? 4 : 1][FOLD_G > 1 ? FOLD_G * 64 * 8 : 4];
-    __shared__ __attribute__((aligned(16))) uint8_t s_stage[COPY ? 4 : 1][COPY ? STAGE_FULL_BYTES : 16];
+    __shared__ __attribute__((aligned(16))) uint8_t s_stage[COPY ? 4 : 1][COPY ? (SHIFT ? STAGE_SHIFT_BYTES : STAGE_FULL_BYTES) : 16];
     const uint32_t w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const uint32_t first = (blockIdx.x * 4 + w) * FOLD_G;
     if (first >= a.n_tiles) return;
@@ -37,7 +39,7 @@ __global__ __launch_bounds__(256) void k_hash_tiles(HashArgs a) {
             if (__ballot(mine) == 0ull) continue;
         }
         LeafOut lo;
-        hash_tile_leaves<COPY, false, COPY>(a, t, nullptr, lo, COPY ? s_stage[w] : nullptr);
+        hash_tile_leaves<COPY, false, COPY, SHIFT>(a, t, nullptr, lo, COPY ? s_stage[w] : nullptr);
         if (FOLD_G > 1 && FoldQueue<FOLD_G>::fits(t)) fq.add(nodes, g, t, lo);
         else fold_tile_now(a, t, lo);
     }
@@ -48,8 +50,14 @@ template <int G>
 static void launch_hash_tiles_g(const HashArgs &a, hipStream_t s) {
     const uint32_t waves = (a.n_tiles + G - 1) / G;
     dim3 grid((waves + 3) / 4), block(256);
-    if (a.copy_to_B) hipLaunchKernelGGL((k_hash_tiles<true, G>), grid, block, 0, s, a);
-    else hipLaunchKernelGGL((k_hash_tiles<false, G>), grid, block, 0, s, a);
+    if constexpr (G == 1) {  // the store path runs one tile per wave: its stage leaves no LDS for a node array
+        if (a.copy_to_B) {
+            if (a.misaligned_dst) hipLaunchKernelGGL((k_hash_tiles<true, 1, true>), grid, block, 0, s, a);
+            else hipLaunchKernelGGL((k_hash_tiles<true, 1, false>), grid, block, 0, s, a);
+            return;
+        }
+    }
+    hipLaunchKernelGGL((k_hash_tiles<false, G>), grid, block, 0, s, a);
 }
 
 void launch_hash_tiles(const HashArgs &a, hipStream_t s) {
