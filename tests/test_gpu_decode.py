@@ -335,3 +335,36 @@ def test_big_rows_block_items_fused(gpu_ctx, oracle):
     assert np.array_equal(rows.digests(), enc["checksum"])
     names = [k for k, _ in gpu_ctx.kernel_times()]
     assert "decode_verify_fused_blocks" in names
+
+
+def test_stored_big_rows_every_output_alignment(gpu_ctx, oracle):
+    """Store path, big rows: the hash+copy kernel re-cuts the bytes when an output offset is not a multiple of 16
+    (16-byte stores land on boundaries; a leaf's first and last 16 bytes go out as they are).  Every alignment 0..15,
+    sizes that are whole leaves and ragged ones, guard bytes between the rows must survive."""
+    import torch
+    from znippy_amd import hip
+    rng = np.random.default_rng(21)
+    sizes = [(3 << 16) + (i % 3) * 1024 + (0 if i % 2 else int(rng.integers(1, 1023))) for i in range(16)] + [1 << 20, (1 << 20) + 5]
+    rows = [gen.incompressible(50 + i, n) for i, n in enumerate(sizes)]
+    GAP = 48
+    out_off, pos = [], 0
+    for i, n in enumerate(sizes):
+        pos = (pos + 15) // 16 * 16 + (i % 16)          # alignment i mod 16
+        out_off.append(pos)
+        pos += n + GAP
+    total = pos + 64
+    blobs = np.frombuffer(b"".join(rows) + bytes(64), dtype=np.uint8)
+    bs = np.array(sizes, dtype=np.uint64)
+    bo = np.concatenate([[0], np.cumsum(bs)[:-1]]).astype(np.uint64)
+    ck = np.stack([np.frombuffer(oracle.blake3(d), dtype=np.uint8) for d in rows])
+    d_blobs = torch.from_numpy(blobs.copy()).cuda()
+    d_out = torch.full((total,), 0xA5, dtype=torch.uint8, device="cuda")
+    bitmap = np.zeros((len(sizes) + 7) // 8, np.uint8)   # nothing compressed
+    rt = hip.RowTable(gpu_ctx, bo, bs, bs, np.array(out_off, dtype=np.uint64), bitmap, ck)
+    counters, corrupt, status = rt.decode_verify(d_blobs, d_out)
+    assert (status == 0).all() and len(corrupt) == 0 and counters["verified_bytes"] == sum(sizes)
+    out = d_out.cpu().numpy()
+    want = np.full(total, 0xA5, np.uint8)
+    for o, d in zip(out_off, rows):
+        want[o:o + len(d)] = np.frombuffer(d, dtype=np.uint8)
+    assert np.array_equal(out, want)
