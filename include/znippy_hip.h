@@ -90,6 +90,13 @@ int znippy_rows_create(znippy_ctx *ctx, const uint64_t *blob_offset, const uint6
                        const uint64_t *out_offset, const uint8_t *checksum, uint64_t row_begin,
                        uint64_t row_end, znippy_rows **out);
 void znippy_rows_destroy(znippy_rows *rows);
+/* Declare the size in bytes of the blob region the table will be run against (d_blobs of the calls below).  Every
+ * run validates each row on the host, once per distinct (blob_base, blob_cap, out_cap): a row whose blob does not
+ * lie inside [blob_base, blob_base + blob_cap), or whose bytes would not fit inside out_cap, is NOT touched by any
+ * kernel and reports ZNIPPY_E_CORRUPT / ZNIPPY_E_DST_SMALL in row_status (counted as a decode error) — a crafted
+ * or damaged index is an error code, never a device fault.  Without this call only the output side is checked.
+ * A stored row (compressed = 0) is its blob: its length is blob_size, as in the reference (decompress.rs:L143-166). */
+int znippy_rows_set_blob_cap(znippy_rows *rows, uint64_t blob_cap);
 
 /* Decode-or-passthrough + BLAKE3 + compare for every row of the table.
  *   d_blobs   : DEVICE pointer to the blob region; row r's blob is d_blobs[blob_offset[r]-blob_base ..]
@@ -109,6 +116,10 @@ int znippy_decode_verify_rows_async(znippy_ctx *ctx, znippy_rows *rows, const vo
                                     uint64_t blob_base, void *d_out, uint64_t out_cap);
 int znippy_rows_results(znippy_ctx *ctx, znippy_rows *rows, znippy_verify_counters *counters,
                         uint64_t *corrupt_rows, uint64_t corrupt_cap, int32_t *row_status);
+/* Counters of the run `lag` (0 or 1) runs before the latest one queued on this table: waits for THAT run only,
+ * so a caller that keeps two runs in flight reads run k's counters while run k+1 executes — the read loop
+ * reports after the loop, not per row (decompress.rs:L195-221).  ZNIPPY_E_INVAL if no such run exists. */
+int znippy_rows_results_lagged(znippy_ctx *ctx, znippy_rows *rows, unsigned lag, znippy_verify_counters *counters);
 /* Computed digests of the last run (HOST, 32 bytes per row of the table). */
 int znippy_rows_digests(znippy_ctx *ctx, znippy_rows *rows, uint8_t *digests);
 
@@ -148,6 +159,12 @@ int znippy_rounds_results(znippy_ctx *ctx, znippy_rounds *rounds, uint64_t *blob
  * encode call on the same table. */
 int znippy_rounds_results_view(znippy_ctx *ctx, znippy_rounds *rounds, const uint64_t **blob_offset,
                                const uint64_t **blob_size, const uint8_t **checksum, uint64_t *blob_bytes);
+
+/* The same for the run `lag` (0 or 1) runs before the latest one; waits for that run's result copy only (every
+ * run's results leave on a copy stream into their own pinned mirror).  Pointers stay valid until two more encode
+ * calls have been queued on the table. */
+int znippy_rounds_results_lagged(znippy_ctx *ctx, znippy_rounds *rounds, unsigned lag, const uint64_t **blob_offset,
+                                 const uint64_t **blob_size, const uint8_t **checksum, uint64_t *blob_bytes);
 
 /* Hash only (store path / verify-only): digests[i] = BLAKE3(d_src[off_i .. off_i+len_i]).
  * digests: HOST, 32 bytes per round. */

@@ -78,6 +78,10 @@ uint64_t znippy_archive_file_count(const znippy_archive *a);
 int64_t znippy_archive_file_size(const znippy_archive *a, const char *relative_path); /* -1: not found */
 int znippy_archive_extract_file(znippy_archive *a, const char *relative_path, void *dst, size_t cap,
                                 size_t *written);
+/* The same with every chunk's BLAKE3 checked against the index's checksum column (the reference's extract_file has
+ * no verification, archive.rs:L144-168; SURVEY §8f rank 1 asks for it): ZNIPPY_E_CHECKSUM on a mismatch. */
+int znippy_archive_extract_file_verified(znippy_archive *a, const char *relative_path, void *dst, size_t cap,
+                                         size_t *written);
 void znippy_archive_close(znippy_archive *a);
 
 /* ---- index / container ---- */

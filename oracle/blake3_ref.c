@@ -9,7 +9,7 @@
  * 1 KiB chunks, 64-B blocks, 7 rounds, binary tree, ROOT flag on the last compression).
  *
  * Pinned by: the public known-answer vectors for "" / "abc" / the official
- * `i % 251` input pattern (tests/golden/blake3_kat.json, checked in tests/test_oracle_blake3.py).
+ * `i % 251` input pattern (tests/golden/blake3_kat.json, checked in tests/test_oracle.py).
  */
 #include <stdint.h>
 #include <stddef.h>

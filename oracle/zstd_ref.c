@@ -15,7 +15,7 @@
  *
  * PARITY UNPINNED against OpenZL bytes: the reference ships no golden blobs
  * (SURVEY.md §8c).  Pinned against the container's libzstd 1.4.8 (an independent
- * implementation of the same RFC) in tests/test_oracle_zstd.py and by committed frames in
+ * implementation of the same RFC) in tests/test_oracle.py and by committed frames in
  * tests/golden/.
  */
 #include <stdint.h>

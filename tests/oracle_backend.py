@@ -28,6 +28,15 @@ class OracleBackend:
         ck = np.ascontiguousarray(checksum, dtype=np.uint8) if have_ck else np.zeros((n, 32), np.uint8)
         rel = np.asarray(blob_offset, dtype=np.uint64) - np.uint64(blob_base)
         bl = np.concatenate([np.asarray(blobs, dtype=np.uint8), np.zeros(16, np.uint8)])
+        # rows pointing outside the blob region: the device layer reports them (ZNIPPY_E_CORRUPT) without reading
+        # anything; here they are fed to the loop as empty frames, which fail to decode the same way
+        blob_size = np.asarray(blob_size, dtype=np.uint64).copy()
+        compressed = np.asarray(compressed, dtype=bool).copy()
+        oob = (rel > len(blobs)) | (blob_size > np.uint64(len(blobs)) - np.minimum(rel, np.uint64(len(blobs))))
+        rel = np.where(oob, np.uint64(0), rel)
+        blob_size[oob] = 0
+        compressed[oob] = True
+        bitmap = np.packbits(compressed, bitorder="little")
         st, corrupt = O.decompress_rows(bl, rel, blob_size, usize, out_offset, bitmap, ck, 0, n, out=out,
                                         n_threads=self.n_threads, use_libzstd=False, corrupt_cap=max(n, 1))
         status = np.zeros(n, dtype=np.int32)

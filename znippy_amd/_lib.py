@@ -43,7 +43,7 @@ EXPORTS = [
     "znippy_decode_verify_rows_async", "znippy_rows_results", "znippy_rows_digests",
     "znippy_rounds_create", "znippy_rounds_destroy", "znippy_rounds_blob_bound",
     "znippy_encode_hash_rounds", "znippy_encode_hash_rounds_async", "znippy_rounds_results",
-    "znippy_rounds_results_view", "znippy_rounds_set_store_incompressible", "znippy_hash_rounds", "znippy_last_kernel_times",
+    "znippy_rounds_results_view", "znippy_rows_results_lagged", "znippy_rows_set_blob_cap", "znippy_rounds_results_lagged", "znippy_rounds_set_store_incompressible", "znippy_hash_rounds", "znippy_last_kernel_times",
 ]
 
 
@@ -86,6 +86,10 @@ def lib():
                                             vp, C.c_uint64, vp]
     L.znippy_decode_verify_rows_async.argtypes = [vp, vp, vp, C.c_uint64, vp, C.c_uint64]
     L.znippy_rows_results.argtypes = [vp, vp, C.POINTER(VerifyCounters), vp, C.c_uint64, vp]
+    L.znippy_rows_results_lagged.argtypes = [vp, vp, C.c_uint, C.POINTER(VerifyCounters)]
+    L.znippy_rounds_results_lagged.argtypes = [vp, vp, C.c_uint, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp),
+                                               C.POINTER(C.c_uint64)]
+    L.znippy_rows_set_blob_cap.argtypes = [vp, C.c_uint64]
     L.znippy_rows_digests.argtypes = [vp, vp, vp]
     L.znippy_rounds_create.argtypes = [vp, vp, vp, vp, C.c_uint64, C.POINTER(vp)]
     L.znippy_rounds_destroy.argtypes = [vp]

@@ -2,11 +2,14 @@
 
 open() loads only the index; extract_file(path) preads that file's blobs, decodes compressed
 chunks on the GPU and concatenates them in fdata_offset order.  Like the reference, no checksum
-verification happens on this path (archive.rs:L144-168)."""
+verification happens on this path by default (archive.rs:L144-168); `verify=True` adds the check the
+reference lacks: every chunk's BLAKE3 against the index's checksum column."""
+import os
+
 import numpy as np
 
 from . import index as ix
-from .decompress import _columns
+from .decompress import _columns, read_spans, row_lengths
 
 
 class ZnippyArchive:
@@ -16,6 +19,7 @@ class ZnippyArchive:
         _, batches = ix.read_znippy_index(self.path)
         c = _columns(batches)
         self._c = c
+        self._rlen = row_lengths(c)
         self.file_index = {}
         for row, p in enumerate(c["paths"]):
             self.file_index.setdefault(p, []).append(row)
@@ -39,14 +43,15 @@ class ZnippyArchive:
         rows = self.file_index.get(relative_path)
         return None if rows is None else int(sum(int(self._c["usize"][r]) for r in rows))
 
-    def extract_file(self, relative_path) -> bytes:
-        out = self.extract_files([relative_path])[0]
+    def extract_file(self, relative_path, verify=False) -> bytes:
+        out = self.extract_files([relative_path], verify=verify)[0]
         if isinstance(out, Exception):
             raise out
         return out
 
-    def extract_files(self, paths):
-        """Batch extract: all requested files' chunks go to the GPU as one row set."""
+    def extract_files(self, paths, verify=False):
+        """Batch extract: all requested files' chunks go to the GPU as one row set.  Only the requested rows' blobs
+        are read (rows that sit next to each other in the archive in one read), not the span between them."""
         from .backend import default_backend
         c = self._c
         rows, spans, results = [], [], []
@@ -59,15 +64,14 @@ class ZnippyArchive:
             rows.extend(r)
         if rows:
             rows_np = np.asarray(rows)
-            bo, bs, usz = c["blob_offset"][rows_np], c["blob_size"][rows_np], c["usize"][rows_np]
-            lo, hi = int(bo.min()), int((bo + bs).max())
+            bs, usz = c["blob_size"][rows_np], self._rlen[rows_np]
             with open(self.path, "rb") as f:
-                f.seek(lo)
-                blobs = np.frombuffer(f.read(hi - lo), dtype=np.uint8)
+                blobs, bo = read_spans(f, os.path.getsize(self.path), c["blob_offset"][rows_np], bs)
             out_off = np.concatenate([[0], np.cumsum(usz)[:-1]]).astype(np.uint64)
             backend = self._backend or default_backend()
-            _, _, status, out = backend.decode_verify(blobs, lo, bo, bs, usz, out_off, c["compressed"][rows_np], None,
-                                                      int(usz.sum()))
+            _, corrupt, status, out = backend.decode_verify(blobs, 0, bo, bs, usz, out_off, c["compressed"][rows_np],
+                                                            c["checksum"][rows_np] if verify else None, int(usz.sum()))
+            corrupt = set(int(x) for x in corrupt)
         for p, sp in zip(paths, spans):
             if sp is None:
                 results.append(KeyError(f"file not found in archive: {p}"))
@@ -75,6 +79,9 @@ class ZnippyArchive:
             a, b = sp
             if (status[a:b] < 0).any():
                 results.append(ValueError(f"decompress failed for {p}: status {int(status[a:b].min())}"))
+                continue
+            if verify and any(k in corrupt for k in range(a, b)):
+                results.append(ValueError(f"checksum mismatch in {p}"))
                 continue
             start = int(out_off[a])
             end = int(out_off[b - 1] + usz[b - 1])

@@ -44,7 +44,8 @@ class HipBackend:
         d_out = self.torch.empty(out_total + 64, dtype=self.torch.uint8, device=f"cuda:{self.device}")
         bitmap = np.packbits(np.asarray(compressed, dtype=bool), bitorder="little")
         rt = self.hip.RowTable(self.ctx, blob_offset, blob_size, usize, out_offset, bitmap, checksum)
-        counters, corrupt, status = rt.decode_verify(d_blobs, d_out, blob_base=blob_base, out_cap=out_total)
+        counters, corrupt, status = rt.decode_verify(d_blobs, d_out, blob_base=blob_base, out_cap=out_total,
+                                                     blob_cap=len(blobs))
         out = d_out[:out_total].cpu().numpy()
         rt.close()
         return counters, corrupt, status, out

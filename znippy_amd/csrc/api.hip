@@ -55,6 +55,7 @@ struct znippy_ctx {
     EncTables *enc_tabs = nullptr;
     // auxiliary stream: the write side hashes on it while the main stream encodes
     hipStream_t aux = nullptr;
+    hipStream_t copy = nullptr;  // result read-back of the write side (D2H beside the next run's kernels)
     uint8_t *lit_scratch_b = nullptr;  // literal scratch of the block-item launch (runs next to the general decoder)
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     // kernel timing
@@ -67,7 +68,28 @@ struct znippy_ctx {
     std::vector<std::pair<size_t, void *>> dev_pool;  // device buffers handed back by destroyed tables
     std::unordered_map<void *, size_t> dev_sizes;     // capacity of every pooled-kind buffer that is in use
     size_t dev_pool_bytes = 0;
+    // diagnostic switches (ZNIPPY_* environment), read ONCE when the context is created: nothing on the hot path
+    // calls getenv
+    struct {
+        int dbg = 0;             // ZNIPPY_DBG bit set (FusedArgs::dbg)
+        unsigned lds_pad = 0;    // ZNIPPY_LDS_PAD
+        bool no_block_items = false, no_fused_blocks = false, ddbg = false, edbg = false, no_fused_store = false,
+             nohash = false, no_roles = false;
+    } sw;
 };
+
+static void read_switches(znippy_ctx *ctx) {
+    auto on = [](const char *n) { const char *v = getenv(n); return v && *v && *v != '0'; };
+    if (const char *e = getenv("ZNIPPY_DBG")) ctx->sw.dbg = atoi(e);
+    if (const char *e = getenv("ZNIPPY_LDS_PAD")) ctx->sw.lds_pad = (unsigned)atoi(e);
+    ctx->sw.no_block_items = on("ZNIPPY_NO_BLOCK_ITEMS");
+    ctx->sw.no_fused_blocks = on("ZNIPPY_NO_FUSED_BLOCKS");
+    ctx->sw.ddbg = on("ZNIPPY_DDBG");
+    ctx->sw.edbg = on("ZNIPPY_EDBG");
+    ctx->sw.no_fused_store = on("ZNIPPY_NO_FUSED_STORE");
+    ctx->sw.nohash = on("ZNIPPY_NOHASH");
+    ctx->sw.no_roles = on("ZNIPPY_NO_ROLES");
+}
 
 static void *pinned_take(znippy_ctx *ctx, size_t bytes, size_t *cap) {
     size_t best = ctx->pinned_pool.size();
@@ -230,7 +252,20 @@ struct znippy_rows {
     int32_t *status = nullptr;
     uint32_t *digests = nullptr;
     uint64_t *counters = nullptr;  // 8 x u64 (+ pending_count behind them)
-    uint64_t *h_counters = nullptr;  // pinned mirror, filled by the run's own D2H copy
+    // pinned mirror of the counters, filled by the run's own D2H copy.  Two slots + one event each: run k uses slot
+    // k & 1, so the counters of run k can be read while run k + 1 is already executing (znippy_rows_results_lagged)
+    uint64_t *h_counters = nullptr;
+    hipEvent_t ev_done[2] = {nullptr, nullptr};
+    uint64_t run_seq = 0;  // async runs queued so far
+    // Host copies of the columns a run is validated against (one pass per distinct (blob_base, blob_cap, out_cap)):
+    // a row whose blob lies outside the blob region, or whose bytes would land outside the output region, gets its
+    // status from the host (status_init) and no kernel touches it — a crafted index is an error code, not a fault.
+    std::vector<uint64_t> h_blob_off, h_blob_size, h_len, h_out_off;
+    uint64_t blob_cap = ~0ull;  // size of the caller's blob region (znippy_rows_set_blob_cap); ~0 = not declared
+    uint64_t val_base = 0, val_bcap = 0, val_ocap = 0;
+    bool val_done = false;
+    uint32_t n_bad = 0;
+    int32_t *status_init = nullptr;
     bool odd_out = false;  // some stored row's output offset is not a multiple of 16 (store-path kernel variant)
     uint64_t *corrupt = nullptr;
     uint32_t corrupt_cap = 0;
@@ -276,10 +311,14 @@ struct znippy_rounds {
     uint32_t *piece_len = nullptr, *piece_len_init = nullptr;
     uint64_t *piece_start = nullptr, *local_excl = nullptr, *block_tot = nullptr;
     // results live in ONE device slab (one D2H per call): [total u64][overflow u64][blob_offset n][blob_size n][digests 32n]
-    uint8_t *res = nullptr, *h_res = nullptr;  // device slab + pinned host mirror
-    size_t h_res_cap = 0, h_stored_cap = 0;
+    // Two slabs + two mirrors + one event each: run k uses slot k & 1 and its D2H copy rides the context's copy
+    // stream, so run k + 1 encodes while run k's results travel (and are read: znippy_rounds_results_lagged).
+    uint8_t *res = nullptr, *h_res = nullptr;  // device slab + pinned host mirror of the CURRENT run's slot
+    uint8_t *res_m[2] = {nullptr, nullptr}, *h_res_m[2] = {nullptr, nullptr};
+    size_t h_res_cap_m[2] = {0, 0}, h_stored_cap = 0;
+    hipEvent_t ev_enc[2] = {nullptr, nullptr}, ev_res[2] = {nullptr, nullptr};
+    uint64_t run_seq = 0;
     size_t res_bytes = 0;
-    bool h_valid = false;
     bool store_incompressible = false;  // opt-in (znippy_rounds_set_store_incompressible)
     uint32_t *first_item = nullptr;     // first piece of every round
     uint8_t *stored = nullptr, *h_stored = nullptr;  // per round: turned into a raw payload by the opt-in pass
@@ -336,6 +375,7 @@ int znippy_ctx_create(int device, void *hip_stream, znippy_ctx **out) {
     if (!out) return ZNIPPY_E_INVAL;
     znippy_ctx *ctx = new znippy_ctx();
     ctx->device = device;
+    read_switches(ctx);
     if (hipSetDevice(device) != hipSuccess) { delete ctx; return ZNIPPY_E_HIP; }
     if (hip_stream) ctx->stream = (hipStream_t)hip_stream;
     else {
@@ -344,6 +384,7 @@ int znippy_ctx_create(int device, void *hip_stream, znippy_ctx **out) {
     }
     init_fused_tables();
     if (hipStreamCreateWithFlags(&ctx->aux, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&ctx->copy, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming) != hipSuccess) {
         znippy_ctx_destroy(ctx);
@@ -378,6 +419,7 @@ void znippy_ctx_destroy(znippy_ctx *ctx) {
     if (ctx->enc_seq) (void)hipFree(ctx->enc_seq);
     if (ctx->enc_tabs) (void)hipFree(ctx->enc_tabs);
     if (ctx->aux) { (void)hipStreamSynchronize(ctx->aux); (void)hipStreamDestroy(ctx->aux); }
+    if (ctx->copy) { (void)hipStreamSynchronize(ctx->copy); (void)hipStreamDestroy(ctx->copy); }
     for (auto &e : ctx->pinned_pool) (void)hipHostFree(e.second);
     for (auto &e : ctx->dev_pool) (void)hipFree(e.second);
     if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
@@ -391,6 +433,7 @@ const char *znippy_last_error(const znippy_ctx *ctx) { return ctx ? ctx->err.c_s
 int znippy_ctx_sync(znippy_ctx *ctx) {
     if (!ctx) return ZNIPPY_E_INVAL;
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->copy) HIPCHK(ctx, hipStreamSynchronize(ctx->copy));
     return ZNIPPY_OK;
 }
 
@@ -406,19 +449,29 @@ int znippy_last_kernel_times(znippy_ctx *ctx, const char **names, float *ms, int
 }
 
 // ---- frame header (host) ------------------------------------------------------------------------
+// Leading skippable frames (RFC 8878 3.1.2) carry no content: the single-chunk shims step over them — the size
+// query and the decoder both start at the first Zstandard frame.  -1: a skippable frame runs past the input.
+static ptrdiff_t skippable_prefix(const uint8_t *p, size_t n) {
+    size_t at = 0;
+    while (n - at >= 8) {
+        uint32_t magic, sz;
+        memcpy(&magic, p + at, 4);
+        if ((magic & 0xFFFFFFF0u) != 0x184D2A50u) break;
+        memcpy(&sz, p + at + 4, 4);
+        if ((uint64_t)8 + sz > n - at) return -1;
+        at += 8 + (size_t)sz;
+    }
+    return (ptrdiff_t)at;
+}
+
 int znippy_get_decompressed_size(const void *frame, size_t n, uint64_t *out_size) {
     const uint8_t *p = (const uint8_t *)frame;
     if (!p || !out_size) return ZNIPPY_E_INVAL;
-    // skippable frames
-    while (n >= 8) {
-        uint32_t magic;
-        memcpy(&magic, p, 4);
-        if ((magic & 0xFFFFFFF0u) != 0x184D2A50u) break;
-        uint32_t sz;
-        memcpy(&sz, p + 4, 4);
-        if ((size_t)8 + sz > n) return ZNIPPY_E_CORRUPT;
-        p += 8 + sz;
-        n -= 8 + sz;
+    {
+        const ptrdiff_t skip = skippable_prefix(p, n);
+        if (skip < 0) return ZNIPPY_E_CORRUPT;
+        p += skip;
+        n -= (size_t)skip;
     }
     if (n < 5) return ZNIPPY_E_CORRUPT;
     uint32_t magic;
@@ -446,10 +499,12 @@ void znippy_rows_destroy(znippy_rows *r) {
     void *ptrs[] = {r->blob_off, r->blob_size, r->usize, r->out_off, r->compressed, r->checksum,
                     r->status, r->digests, r->counters, r->corrupt, r->list_a, r->pending,
                     r->cand_row, r->cand_base, r->cand_nblocks, r->item_row, r->item_k, r->item_src, r->row_flag, r->pending2,
-                    r->bt_tile, r->bt_item, r->tile_done, r->item_done, r->todo};
+                    r->bt_tile, r->bt_item, r->tile_done, r->item_done, r->todo, r->status_init};
     for (void *p : ptrs)
         tfree(r->ctx, p);
     if (r->h_counters) (void)hipHostFree(r->h_counters);
+    for (hipEvent_t e : r->ev_done)
+        if (e) (void)hipEventDestroy(e);
     free_plan(r->ctx, r->plan);
     delete r;
 }
@@ -468,12 +523,20 @@ int znippy_rows_create(znippy_ctx *ctx, const uint64_t *blob_offset, const uint6
     r->n = (uint32_t)(row_end - row_begin);
     const uint32_t n = r->n;
     std::vector<uint8_t> comp(n);
+    r->h_blob_off.assign(blob_offset + row_begin, blob_offset + row_end);
+    r->h_blob_size.assign(blob_size + row_begin, blob_size + row_end);
+    r->h_out_off.assign(out_offset + row_begin, out_offset + row_end);
+    r->h_len.assign(uncompressed_size + row_begin, uncompressed_size + row_end);
     for (uint32_t i = 0; i < n; i++) {
         uint64_t row = row_begin + i;
         comp[i] = compressed_bitmap ? (compressed_bitmap[row >> 3] >> (row & 7)) & 1 : 1;
         r->n_compressed += comp[i];
         if (!comp[i] && (out_offset[row] & 15)) r->odd_out = true;
+        // a stored row IS its blob: the reference hashes and writes the blob bytes and never looks at the index's
+        // uncompressed_size for it (decompress.rs:L143-166: `&read_buf`), so neither does this table
+        if (!comp[i]) r->h_len[i] = r->h_blob_size[i];
     }
+    uncompressed_size = r->h_len.data() - row_begin;  // from here on: the effective lengths
     int rc = ZNIPPY_OK;
     if ((rc = dev_upload(ctx, &r->blob_off, blob_offset + row_begin, n)) ||
         (rc = dev_upload(ctx, &r->blob_size, blob_size + row_begin, n)) ||
@@ -491,7 +554,9 @@ int znippy_rows_create(znippy_ctx *ctx, const uint64_t *blob_offset, const uint6
     if (tmalloc(ctx, &r->status, std::max<size_t>(4 * (size_t)n, 16)) != hipSuccess ||
         tmalloc(ctx, &r->digests, std::max<size_t>(32 * (size_t)n, 32)) != hipSuccess ||
         tmalloc(ctx, &r->counters, 128) != hipSuccess ||  // [counters 8 x u64][pending_count] : one memset per run
-        hipHostMalloc(&r->h_counters, 64) != hipSuccess ||
+        hipHostMalloc(&r->h_counters, 128) != hipSuccess ||
+        hipEventCreateWithFlags(&r->ev_done[0], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&r->ev_done[1], hipEventDisableTiming) != hipSuccess ||
         tmalloc(ctx, &r->corrupt, 8 * (size_t)r->corrupt_cap) != hipSuccess) {
         znippy_rows_destroy(r);
         return ZNIPPY_E_NOMEM;
@@ -514,7 +579,7 @@ int znippy_rows_create(znippy_ctx *ctx, const uint64_t *blob_offset, const uint6
         big_blob += blob_size[row_begin + i];
         n_big++;
         const uint64_t nb = (us + BLK - 1) / BLK;
-        if (nb >= 2 && us < 0xFFFFFFFFull && item_row.size() + nb < 0x7FFFFFFFull && !getenv("ZNIPPY_NO_BLOCK_ITEMS")) {
+        if (nb >= 2 && us < 0xFFFFFFFFull && item_row.size() + nb < 0x7FFFFFFFull && !ctx->sw.no_block_items) {
             cand_row.push_back(i);
             cand_base.push_back((uint32_t)item_row.size());
             cand_nb.push_back((uint32_t)nb);
@@ -543,7 +608,7 @@ int znippy_rows_create(znippy_ctx *ctx, const uint64_t *blob_offset, const uint6
             return ZNIPPY_E_NOMEM;
         }
     }
-    if (r->n_cand && !getenv("ZNIPPY_NO_FUSED_BLOCKS")) {
+    if (r->n_cand && !ctx->sw.no_fused_blocks) {
         std::vector<uint32_t> row_base(n, 0xFFFFFFFFu), bt_tile, bt_item;
         for (size_t c = 0; c < cand_row.size(); c++) row_base[cand_row[c]] = cand_base[c];
         for (uint32_t ti = 0; ti < (uint32_t)p.tiles.size(); ti++) {
@@ -580,6 +645,41 @@ int znippy_rows_create(znippy_ctx *ctx, const uint64_t *blob_offset, const uint6
     return ZNIPPY_OK;
 }
 
+int znippy_rows_set_blob_cap(znippy_rows *r, uint64_t blob_cap) {
+    if (!r) return ZNIPPY_E_INVAL;
+    r->blob_cap = blob_cap;
+    return ZNIPPY_OK;
+}
+
+// Every row's source range against the declared blob region and its output range against out_cap, overflow-safe,
+// once per distinct triple.  Bad rows (normally none) get their status from the host.
+static int rows_validate(znippy_ctx *ctx, znippy_rows *r, uint64_t blob_base, uint64_t out_cap) {
+    if (r->val_done && r->val_base == blob_base && r->val_bcap == r->blob_cap && r->val_ocap == out_cap) return ZNIPPY_OK;
+    std::vector<int32_t> init;
+    uint32_t bad = 0;
+    const uint64_t bcap = r->blob_cap;
+    for (uint32_t i = 0; i < r->n; i++) {
+        const uint64_t bo = r->h_blob_off[i], bs = r->h_blob_size[i], len = r->h_len[i], oo = r->h_out_off[i];
+        int code = 0;
+        if (bo < blob_base) code = ZNIPPY_E_CORRUPT;
+        else if (bcap != ~0ull && (bs > bcap || bo - blob_base > bcap - bs)) code = ZNIPPY_E_CORRUPT;
+        else if (len > out_cap || oo > out_cap - len) code = ZNIPPY_E_DST_SMALL;
+        if (code) {
+            if (init.empty()) init.assign(r->n, 0);
+            init[i] = code;
+            bad++;
+        }
+    }
+    if (bad) {
+        if (!r->status_init && tmalloc(ctx, &r->status_init, 4 * (size_t)r->n) != hipSuccess) return ZNIPPY_E_NOMEM;
+        HIPCHK(ctx, hipMemcpy(r->status_init, init.data(), 4 * (size_t)r->n, hipMemcpyHostToDevice));
+    }
+    r->n_bad = bad;
+    r->val_base = blob_base; r->val_bcap = r->blob_cap; r->val_ocap = out_cap;
+    r->val_done = true;
+    return ZNIPPY_OK;
+}
+
 int znippy_decode_verify_rows_async(znippy_ctx *ctx, znippy_rows *r, const void *d_blobs,
                                     uint64_t blob_base, void *d_out, uint64_t out_cap) {
     if (!ctx || !r || r->ctx != ctx) return ZNIPPY_E_INVAL;
@@ -588,10 +688,14 @@ int znippy_decode_verify_rows_async(znippy_ctx *ctx, znippy_rows *r, const void 
     hipStream_t s = ctx->stream;
     ctx->n_ktimes = 0;
     { const int rc0 = ensure_decoder(ctx); if (rc0) return rc0; }
+    { const int rc0 = rows_validate(ctx, r, blob_base, out_cap); if (rc0) return rc0; }
+    const int preset = r->n_bad ? 1 : 0;
+    if (preset) HIPCHK(ctx, hipMemcpyAsync(r->status, r->status_init, 4 * (size_t)r->n, hipMemcpyDeviceToDevice, s));
+    else
     HIPCHK(ctx, hipMemsetAsync(r->status, 0, std::max<size_t>(4 * (size_t)r->n, 16), s));
     HIPCHK(ctx, hipMemsetAsync(r->counters, 0, 128, s));  // counters + pending_count
     HIPCHK(ctx, hipMemsetAsync(ctx->cursor, 0, 64, s));
-    if (!r->n) return ZNIPPY_OK;
+    if (!r->n) { r->run_seq++; return ZNIPPY_OK; }
     // 1) fused small-row kernel: decode simple frames + hash (+ copy stored rows), one wave per tile
     HashArgs h{};
     h.tiles = r->plan.tiles; h.n_tiles = r->plan.n_tiles;
@@ -607,8 +711,9 @@ int znippy_decode_verify_rows_async(znippy_ctx *ctx, znippy_rows *r, const void 
         f.h = h;
         f.h.pass = 1;  // PASS_FUSED
         f.blob_size = r->blob_size; f.out_cap = out_cap; f.status = r->status;
+        f.preset = preset;
         f.pending = r->pending; f.pending_count = r->pending_count;
-        { const char *e = getenv("ZNIPPY_DBG"); f.dbg = e ? atoi(e) : 0; }
+        f.dbg = ctx->sw.dbg;
         if (f.dbg & 8) {  // diagnostic: print the previous launch's phase stamps, then reset them
             static unsigned long long *dbg = nullptr;
             if (!dbg) { (void)hipMalloc(&dbg, 64); (void)hipMemset(dbg, 0, 64); }
@@ -622,7 +727,7 @@ int znippy_decode_verify_rows_async(znippy_ctx *ctx, znippy_rows *r, const void 
             f.dbg_buf = dbg;
         }
         if (f.dbg & (16 | 32 | 64)) set_fused_abl(f.dbg);
-        { const char *e = getenv("ZNIPPY_LDS_PAD"); f.lds_pad = e ? (uint32_t)atoi(e) : 0; }
+        f.lds_pad = ctx->sw.lds_pad;
         ktime_begin(ctx, "decode_verify_fused");
         launch_fused_small(f, s);
         ktime_end(ctx);
@@ -638,6 +743,7 @@ int znippy_decode_verify_rows_async(znippy_ctx *ctx, znippy_rows *r, const void 
         b.blobs = (const uint8_t *)d_blobs; b.blob_base = blob_base;
         b.blob_off = r->blob_off; b.blob_size = r->blob_size; b.usize = r->usize; b.out_off = r->out_off; b.out_cap = out_cap;
         b.item_src = r->item_src; b.row_flag = r->row_flag; b.status = r->status;
+        b.preset = preset;
         b.pending = r->pending2; b.pending_count = r->pending_count + 1;  // its own hand-over list (count: second word of the control block)
         HIPCHK(ctx, hipEventRecord(ctx->ev_fork, s));
         HIPCHK(ctx, hipStreamWaitEvent(ctx->aux, ctx->ev_fork, 0));
@@ -654,13 +760,14 @@ int znippy_decode_verify_rows_async(znippy_ctx *ctx, znippy_rows *r, const void 
             fb.bt_tile = r->bt_tile; fb.bt_item = r->bt_item; fb.n_bt = r->n_bt;
             fb.item_src = r->item_src; fb.row_flag = r->row_flag;
             fb.tile_done = r->tile_done; fb.item_done = r->item_done;
-            { const char *e = getenv("ZNIPPY_DBG"); fb.dbg = e ? atoi(e) : 0; }
+            fb.dbg = ctx->sw.dbg;
             ktime_begin(ctx, "decode_verify_fused_blocks", ctx->aux);
             launch_fused_blocks(fb, ctx->aux);
             ktime_end(ctx, ctx->aux);
             launch_compact_items(r->item_done, r->n_items, r->todo, r->pending_count + 2, ctx->aux);
         }
         DecodeArgs a{};
+        a.preset = preset;
         a.block_mode = 1;
         a.item_row = r->item_row; a.item_k = r->item_k; a.item_src = r->item_src; a.n_items = r->n_items; a.row_flag = r->row_flag;
         a.item_done = r->n_bt ? r->item_done : nullptr;
@@ -673,7 +780,7 @@ int znippy_decode_verify_rows_async(znippy_ctx *ctx, znippy_rows *r, const void 
         a.out = (uint8_t *)d_out; a.out_cap = out_cap;
         a.status = r->status; a.n_rows = r->n; a.cursor = ctx->cursor + 4;
         a.lit_scratch = ctx->lit_scratch_b;
-        if (getenv("ZNIPPY_DDBG")) {  // diagnostic: phase shares of the previous block-item launch
+        if (ctx->sw.ddbg) {  // diagnostic: phase shares of the previous block-item launch
             static unsigned long long *dbg = nullptr;
             if (!dbg) { (void)hipMalloc(&dbg, 64); (void)hipMemset(dbg, 0, 64); }
             unsigned long long h[8];
@@ -692,6 +799,7 @@ int znippy_decode_verify_rows_async(znippy_ctx *ctx, znippy_rows *r, const void 
     }
     if (r->n_compressed) {
         DecodeArgs a{};
+        a.preset = preset;
         a.list_a = r->list_a; a.n_list_a = r->n_list_a;
         a.pending = r->pending; a.pending_count = r->pending_count;
         a.blobs = (const uint8_t *)d_blobs;
@@ -730,8 +838,29 @@ int znippy_decode_verify_rows_async(znippy_ctx *ctx, znippy_rows *r, const void 
     launch_verify(r->digests, r->checksum, r->usize, r->status, r->n, r->row_begin, r->counters, r->corrupt,
                   r->corrupt_cap, s);
     ktime_end(ctx);
-    HIPCHK(ctx, hipMemcpyAsync(r->h_counters, r->counters, 64, hipMemcpyDeviceToHost, s));
+    {
+        const unsigned slot = (unsigned)(r->run_seq & 1);
+        HIPCHK(ctx, hipMemcpyAsync(r->h_counters + 8 * slot, r->counters, 64, hipMemcpyDeviceToHost, s));
+        HIPCHK(ctx, hipEventRecord(r->ev_done[slot], s));
+        r->run_seq++;
+    }
     HIPCHK(ctx, hipGetLastError());
+    return ZNIPPY_OK;
+}
+
+// Counters of the run `lag` runs before the latest one (lag 0 or 1): waits for THAT run only, so a caller that
+// keeps two runs in flight reads run k's counters while run k + 1 executes (the read loop reports after the loop,
+// not per row: decompress.rs:L195-221).
+int znippy_rows_results_lagged(znippy_ctx *ctx, znippy_rows *r, unsigned lag, znippy_verify_counters *counters) {
+    if (!ctx || !r || r->ctx != ctx || !counters || lag > 1 || r->run_seq <= lag) return ZNIPPY_E_INVAL;
+    uint64_t c[8] = {0};
+    if (r->n) {
+        const unsigned slot = (unsigned)((r->run_seq - 1 - lag) & 1);
+        HIPCHK(ctx, hipEventSynchronize(r->ev_done[slot]));
+        memcpy(c, r->h_counters + 8 * slot, 64);
+    }
+    counters->total_chunks = c[0]; counters->total_written_bytes = c[1]; counters->verified_bytes = c[2];
+    counters->corrupt_bytes = c[3]; counters->corrupt_rows = c[4]; counters->decode_errors = c[5];
     return ZNIPPY_OK;
 }
 
@@ -741,7 +870,7 @@ int znippy_rows_results(znippy_ctx *ctx, znippy_rows *r, znippy_verify_counters 
     HIPCHK(ctx, hipSetDevice(ctx->device));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     uint64_t c[8] = {0};
-    if (r->n) memcpy(c, r->h_counters, 64);  // copied by the run itself (pinned): no extra round trip here
+    if (r->n && r->run_seq) memcpy(c, r->h_counters + 8 * ((r->run_seq - 1) & 1), 64);  // copied by the run itself (pinned)
     if (counters) {
         counters->total_chunks = c[0]; counters->total_written_bytes = c[1]; counters->verified_bytes = c[2];
         counters->corrupt_bytes = c[3]; counters->corrupt_rows = c[4]; counters->decode_errors = c[5];
@@ -779,12 +908,28 @@ int znippy_rows_digests(znippy_ctx *ctx, znippy_rows *r, uint8_t *digests) {
 }
 
 // ---- rounds -------------------------------------------------------------------------------------
+static void rounds_select(znippy_rounds *r, unsigned slot) {  // the result slab the next run writes
+    const size_t n = r->n;
+    r->res = r->res_m[slot];
+    r->h_res = r->h_res_m[slot];
+    r->total = reinterpret_cast<uint64_t *>(r->res);
+    r->overflow = reinterpret_cast<uint32_t *>(r->res + 8);
+    r->blob_offset = reinterpret_cast<uint64_t *>(r->res + 16);
+    r->blob_size = r->blob_offset + n;
+    r->digests = reinterpret_cast<uint32_t *>(r->res + 16 + n * 16);
+}
+
 void znippy_rounds_destroy(znippy_rounds *r) {
     if (!r) return;
     (void)hipSetDevice(r->ctx->device);
-    void *ptrs[] = {r->src_off, r->len, r->skip, r->res, r->items, r->piece_len, r->piece_len_init,
+    if (r->ctx->copy) (void)hipStreamSynchronize(r->ctx->copy);  // a result copy may still be reading a slab
+    for (int k = 0; k < 2; k++) {
+        pinned_give(r->ctx, r->h_res_m[k], r->h_res_cap_m[k]);
+        if (r->ev_enc[k]) (void)hipEventDestroy(r->ev_enc[k]);
+        if (r->ev_res[k]) (void)hipEventDestroy(r->ev_res[k]);
+    }
+    void *ptrs[] = {r->src_off, r->len, r->skip, r->res_m[0], r->res_m[1], r->items, r->piece_len, r->piece_len_init,
                     r->piece_start, r->local_excl, r->block_tot, r->first_item, r->stored, r->order_small, r->order_wide, r->retry_list, r->retry_count};
-    pinned_give(r->ctx, r->h_res, r->h_res_cap);
     pinned_give(r->ctx, r->h_stored, r->h_stored_cap);
     for (void *p : ptrs)
         tfree(r->ctx, p);
@@ -818,16 +963,15 @@ int znippy_rounds_create(znippy_ctx *ctx, const uint64_t *src_offset, const uint
         return rc;
     }
     r->res_bytes = 16 + (size_t)n * (8 + 8 + 32);
-    if (tmalloc(ctx, &r->res, r->res_bytes) != hipSuccess ||
-        !(r->h_res = (uint8_t *)pinned_take(ctx, r->res_bytes, &r->h_res_cap))) {
-        znippy_rounds_destroy(r);
-        return ZNIPPY_E_NOMEM;
-    }
-    r->total = reinterpret_cast<uint64_t *>(r->res);
-    r->overflow = reinterpret_cast<uint32_t *>(r->res + 8);
-    r->blob_offset = reinterpret_cast<uint64_t *>(r->res + 16);
-    r->blob_size = r->blob_offset + n;
-    r->digests = reinterpret_cast<uint32_t *>(r->res + 16 + (size_t)n * 16);
+    for (int k = 0; k < 2; k++)
+        if (tmalloc(ctx, &r->res_m[k], r->res_bytes) != hipSuccess ||
+            !(r->h_res_m[k] = (uint8_t *)pinned_take(ctx, r->res_bytes, &r->h_res_cap_m[k])) ||
+            hipEventCreateWithFlags(&r->ev_enc[k], hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&r->ev_res[k], hipEventDisableTiming) != hipSuccess) {
+            znippy_rounds_destroy(r);
+            return ZNIPPY_E_NOMEM;
+        }
+    rounds_select(r, 0);
     PlanBuf p;
     build_plan(len, (uint32_t)n, p);
     if ((rc = upload_plan(ctx, p, r->plan))) {
@@ -978,6 +1122,11 @@ int znippy_decompress(znippy_ctx *ctx, const void *frame, size_t n, void *dst, s
     uint64_t usize = 0;
     int rc = znippy_get_decompressed_size(frame, n, &usize);
     if (rc) return rc;
+    {  // the kernels want the Zstandard magic at byte 0: leading skippable frames stay on the host
+        const ptrdiff_t skip = skippable_prefix((const uint8_t *)frame, n);
+        frame = (const uint8_t *)frame + skip;
+        n -= (size_t)skip;
+    }
     if (usize > cap) return ZNIPPY_E_DST_SMALL;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     rc = shim_reserve(ctx, n, usize);
@@ -1016,9 +1165,11 @@ extern "C" int znippy_encode_hash_rounds_async(znippy_ctx *ctx, znippy_rounds *r
         HIPCHK(ctx, hipMalloc(&ctx->enc_prov, r->prov_bytes + 64));
         ctx->enc_prov_cap = r->prov_bytes + 64;
     }
+    const unsigned slot = (unsigned)(r->run_seq & 1);
+    rounds_select(r, slot);
+    if (r->run_seq >= 2) HIPCHK(ctx, hipStreamWaitEvent(s, r->ev_res[slot], 0));  // the slab's previous results have left
     HIPCHK(ctx, hipEventRecord(ctx->ev_fork, s));
     HIPCHK(ctx, hipMemsetAsync(r->res, 0, 16 + 16 * (size_t)r->n, s));  // total, overflow, blob_offset, blob_size
-    r->h_valid = false;
     HIPCHK(ctx, hipMemsetAsync(ctx->cursor, 0, 64, s));
     HIPCHK(ctx, hipMemsetAsync(r->retry_count, 0, 4, s));
     EncodeArgs a{};
@@ -1026,7 +1177,7 @@ extern "C" int znippy_encode_hash_rounds_async(znippy_ctx *ctx, znippy_rounds *r
     a.src = (const uint8_t *)d_src; a.src_off = r->src_off; a.len = r->len;
     a.prov = ctx->enc_prov; a.seq_scratch = ctx->enc_seq;
     a.piece_len = r->piece_len; a.piece_start = r->piece_start; a.tabs = ctx->enc_tabs;
-    if (getenv("ZNIPPY_EDBG")) {  // diagnostic: phase shares of the previous run's wide-variant blocks
+    if (ctx->sw.edbg) {  // diagnostic: phase shares of the previous run's wide-variant blocks
         static unsigned long long *dbg = nullptr;
         if (!dbg) { (void)hipMalloc(&dbg, 64); (void)hipMemset(dbg, 0, 64); }
         unsigned long long h[8];
@@ -1066,11 +1217,11 @@ extern "C" int znippy_encode_hash_rounds_async(znippy_ctx *ctx, znippy_rounds *r
     // boundaries on their way out — plain 16-byte stores at odd addresses cost more than the pass they save.)
     const bool heavy = r->in_bytes && (r->in_bytes - r->enc_bytes) * 2 >= r->in_bytes;
     const bool fuse_store = heavy && !r->store_incompressible &&
-                            !getenv("ZNIPPY_NO_FUSED_STORE") && !getenv("ZNIPPY_NOHASH");
+                            !ctx->sw.no_fused_store && !ctx->sw.nohash;
     int rc = ZNIPPY_OK;
     if (!fuse_store) {
         HIPCHK(ctx, hipStreamWaitEvent(ctx->aux, ctx->ev_fork, 0));
-        rc = getenv("ZNIPPY_NOHASH") ? ZNIPPY_OK : hash_rounds_async(ctx, r, d_src, ctx->aux);  // diagnostic switch
+        rc = ctx->sw.nohash ? ZNIPPY_OK : hash_rounds_async(ctx, r, d_src, ctx->aux);  // diagnostic switch
         if (rc) return rc;
         HIPCHK(ctx, hipEventRecord(ctx->ev_join, ctx->aux));
     }
@@ -1099,7 +1250,36 @@ extern "C" int znippy_encode_hash_rounds_async(znippy_ctx *ctx, znippy_rounds *r
     } else {
         HIPCHK(ctx, hipStreamWaitEvent(s, ctx->ev_join, 0));  // digests are complete once the main stream drains
     }
+    // the results leave on the copy stream (one DMA into the slot's pinned mirror) while the main stream is free for
+    // the next run
+    HIPCHK(ctx, hipEventRecord(r->ev_enc[slot], s));
+    HIPCHK(ctx, hipStreamWaitEvent(ctx->copy, r->ev_enc[slot], 0));
+    HIPCHK(ctx, hipMemcpyAsync(r->h_res, r->res, r->res_bytes, hipMemcpyDeviceToHost, ctx->copy));
+    HIPCHK(ctx, hipEventRecord(r->ev_res[slot], ctx->copy));
+    r->run_seq++;
     HIPCHK(ctx, hipGetLastError());
+    return ZNIPPY_OK;
+}
+
+// Results of the run `lag` runs before the latest one (0 or 1) as pointers into that run's pinned mirror; waits for
+// that run's copy only.  Valid until two more encode calls have been queued on the table.
+extern "C" int znippy_rounds_results_lagged(znippy_ctx *ctx, znippy_rounds *r, unsigned lag, const uint64_t **blob_offset,
+                                            const uint64_t **blob_size, const uint8_t **checksum, uint64_t *blob_bytes) {
+    if (!ctx || !r || r->ctx != ctx || lag > 1 || r->run_seq <= lag) return ZNIPPY_E_INVAL;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const unsigned slot = (unsigned)((r->run_seq - 1 - lag) & 1);
+    HIPCHK(ctx, hipEventSynchronize(r->ev_res[slot]));
+    const uint8_t *h = r->h_res_m[slot];
+    uint64_t total;
+    uint32_t ovf;
+    memcpy(&total, h, 8);
+    memcpy(&ovf, h + 8, 4);
+    if (ovf) return ZNIPPY_E_DST_SMALL;
+    const size_t n = r->n;
+    if (blob_offset) *blob_offset = reinterpret_cast<const uint64_t *>(h + 16);
+    if (blob_size) *blob_size = reinterpret_cast<const uint64_t *>(h + 16 + 8 * n);
+    if (checksum) *checksum = h + 16 + 16 * n;
+    if (blob_bytes) *blob_bytes = total;
     return ZNIPPY_OK;
 }
 
@@ -1107,13 +1287,13 @@ extern "C" int znippy_rounds_results(znippy_ctx *ctx, znippy_rounds *r, uint64_t
                                      uint8_t *checksum, uint8_t *compressed, uint64_t *blob_bytes) {
     if (!ctx || !r || r->ctx != ctx) return ZNIPPY_E_INVAL;
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     if (blob_bytes) *blob_bytes = 0;
     if (!r->n) return ZNIPPY_OK;
-    if (!r->h_valid) {
-        HIPCHK(ctx, hipMemcpy(r->h_res, r->res, r->res_bytes, hipMemcpyDeviceToHost));  // pinned: one DMA
-        if (r->store_incompressible) HIPCHK(ctx, hipMemcpy(r->h_stored, r->stored, r->n, hipMemcpyDeviceToHost));
-        r->h_valid = true;
+    if (!r->run_seq) return ZNIPPY_E_INVAL;  // nothing has been encoded on this table yet
+    HIPCHK(ctx, hipEventSynchronize(r->ev_res[(r->run_seq - 1) & 1]));  // the latest run's results have arrived
+    if (r->store_incompressible) {
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        HIPCHK(ctx, hipMemcpy(r->h_stored, r->stored, r->n, hipMemcpyDeviceToHost));
     }
     uint64_t total;
     uint32_t ovf;

@@ -88,6 +88,7 @@ struct DecodeArgs {
     const uint8_t *item_done;           // optional: items already written (and hashed) by the fused block kernel
     const uint32_t *todo, *n_todo;      // optional: the items that are left (k_compact_items); n_work = *n_todo
     uint32_t *seq_scratch;
+    int preset;  // != 0: status[] was initialised with the host's verdicts — a row with status < 0 is left alone
 };
 
 struct FusedArgs {
@@ -103,6 +104,7 @@ struct FusedArgs {
     int dbg;
     unsigned long long *dbg_buf;  // diagnostic stamps (ZNIPPY_DBG & 8)
     uint32_t lds_pad;  // extra dynamic LDS per block: caps blocks/CU (in-flight footprint vs Infinity Cache)
+    int preset;        // != 0: status[] was initialised with the host's verdicts — a row with status < 0 is left alone
 };
 
 // Block items of the common shape (fused_small.hip, k_fused_blocks): the big-slice tiles of block-candidate rows.
@@ -140,6 +142,7 @@ struct BlockScanArgs {
     uint32_t *row_flag;
     int32_t *status;
     uint32_t *pending, *pending_count;
+    int preset;  // != 0: rows with status < 0 (host verdict) are not candidates
 };
 void launch_scan_blocks(const BlockScanArgs &a, hipStream_t s);
 void launch_compact_items(const uint8_t *item_done, uint32_t n_items, uint32_t *todo, uint32_t *n_todo, hipStream_t s);

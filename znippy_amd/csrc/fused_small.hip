@@ -818,8 +818,10 @@ __device__ __forceinline__ void fused_tile(const FusedArgs &a, const uint32_t wa
     // WIN bytes of up to WROWS frames staged into LDS with all loads in flight at once ----
     uint32_t c_sel = 0, c_bs = 0;
     uint64_t c_len = 0, c_src = 0, c_oo = 0;
+    int32_t c_st = 0;  // host verdict on the row (bad source / output range): < 0 = leave it alone
     if (lane < t.n_units) {
         const uint32_t row = t.first_unit + lane;
+        if (a.preset) c_st = a.status[row];
         c_sel = a.h.sel[row];
         c_len = a.h.len[row];
         c_src = a.h.offA[row] - a.h.baseA;
@@ -832,7 +834,7 @@ __device__ __forceinline__ void fused_tile(const FusedArgs &a, const uint32_t wa
     __shared__ int32_t s_st[4][64];  // per wave: status of each row of the tile (0 = hash it)
     int32_t *const l_st = s_st[threadIdx.x >> 6];
     if (lane < WROWS) d_y[lane] = 0xFFFF;
-    l_st[lane] = 0;
+    l_st[lane] = c_st;
     uint32_t need_reread = 0;  // some compressed row of the tile must be hashed from its global output
 
     // A tile of many small rows has windows for WROWS of them at a time: rows WROWS.. are taken group by group
@@ -857,7 +859,7 @@ __device__ __forceinline__ void fused_tile(const FusedArgs &a, const uint32_t wa
                 const uint32_t n = __shfl(c_bs, g0 + u), o = 8 * lane;
                 const uint8_t *p = a.h.srcA + so + o;
                 uint64_t v = 0;
-                if (__shfl(c_sel, g0 + u)) {
+                if (__shfl(c_sel, g0 + u) && __shfl(c_st, g0 + u) == 0) {
                     if (o + 8 <= n) __builtin_memcpy(&v, p, 8);
                     else
                         for (uint32_t k = 0; k < 8; k++)
@@ -870,7 +872,7 @@ __device__ __forceinline__ void fused_tile(const FusedArgs &a, const uint32_t wa
             const uint32_t g_sel = __shfl(c_sel, gl), g_bs = __shfl(c_bs, gl);
             const uint64_t g_len = ((uint64_t)__shfl((uint32_t)(c_len >> 32), gl) << 32) | __shfl((uint32_t)c_len, gl);
             const uint64_t g_oo = ((uint64_t)__shfl((uint32_t)(c_oo >> 32), gl) << 32) | __shfl((uint32_t)c_oo, gl);
-            const bool want = lane < WROWS && g0 + lane < t.n_units && g_sel && g_oo + g_len <= a.out_cap;
+            const bool want = lane < WROWS && g0 + lane < t.n_units && g_sel && g_oo + g_len <= a.out_cap && __shfl(c_st, gl) == 0;
             const FastRow f = parse_fast(WL + (lane < WROWS ? lane : 0) * WSTRIDE, g_bs, g_len, want, T);
             const uint32_t m = (uint32_t)__ballot(f.ok != 0);
             if (m) {
@@ -895,7 +897,7 @@ __device__ __forceinline__ void fused_tile(const FusedArgs &a, const uint32_t wa
                 const uint64_t so = __shfl(c_src, u);
                 const uint32_t n = __shfl(c_bs, u), o = 8 * lane;
                 const uint8_t *p = a.h.srcA + so + o;
-                if (__shfl(c_sel, u)) {
+                if (__shfl(c_sel, u) && __shfl(c_st, u) == 0) {
                     if (o + 8 <= n) __builtin_memcpy(&wv[u], p, 8);
                     else {
                         uint64_t v = 0;
@@ -927,7 +929,7 @@ __device__ __forceinline__ void fused_tile(const FusedArgs &a, const uint32_t wa
             T.lls = lane < 36 ? c_llb[lane] | (uint32_t)c_lla[lane] << 24 : 0u;
             T.mls = lane < 53 ? c_mlb[lane] | (uint32_t)c_mla[lane] << 24 : 0u;
         }
-        const bool want = lane < t.n_units && lane < WROWS && c_sel && c_oo + c_len <= a.out_cap;
+        const bool want = lane < t.n_units && lane < WROWS && c_sel && c_oo + c_len <= a.out_cap && c_st == 0;
         fr = parse_fast(WL + (lane < WROWS ? lane : 0) * WSTRIDE, c_bs, c_len, want, T);
     }
     const uint32_t fmask = (uint32_t)__ballot(fr.ok != 0);
@@ -952,6 +954,7 @@ __device__ __forceinline__ void fused_tile(const FusedArgs &a, const uint32_t wa
     for (uint32_t u = 0; u < t.n_units && !(a.dbg & 2); u++) {
         const uint32_t row = t.first_unit + u;
         if (!uni(__shfl(c_sel, u))) continue;  // stored row: copied while it is hashed below
+        if ((int32_t)uni((uint32_t)__shfl(c_st, u)) < 0) continue;  // host verdict stands
         const uint64_t usize = ((uint64_t)uni((uint32_t)(__shfl(c_len, u) >> 32)) << 32) | uni((uint32_t)__shfl(c_len, u));
         const uint64_t ooff = ((uint64_t)uni((uint32_t)(__shfl(c_oo, u) >> 32)) << 32) | uni((uint32_t)__shfl(c_oo, u));
         const uint64_t soff = ((uint64_t)uni((uint32_t)(__shfl(c_src, u) >> 32)) << 32) | uni((uint32_t)__shfl(c_src, u));

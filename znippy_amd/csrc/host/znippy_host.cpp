@@ -252,15 +252,17 @@ struct znippy_index {
     size_t n() const { return rows.rows(); }
 };
 
-static int load_index(const char *path, znippy_index *ix) {
+// A file is untrusted input: every length is checked against the file before anything is allocated or indexed,
+// every read is checked, the manifest's columns are checked against the schema before they are indexed.
+static int load_index_impl(const char *path, znippy_index *ix) {
     int fd = open(path, O_RDONLY);
     if (fd < 0) return fail(ZNIPPY_E_INVAL, std::string("cannot open ") + path);
     struct stat st;
-    fstat(fd, &st);
+    if (fstat(fd, &st) != 0) { close(fd); return fail(ZNIPPY_E_INVAL, std::string("cannot stat ") + path); }
     ix->file_size = (uint64_t)st.st_size;
     if (ix->file_size < 16) { close(fd); return fail(ZNIPPY_E_CORRUPT, "file too small to be a v0.7 znippy archive"); }
     uint8_t tail[16];
-    pread_all(fd, tail, 16, ix->file_size - 16);
+    if (!pread_all(fd, tail, 16, ix->file_size - 16)) { close(fd); return fail(ZNIPPY_E_CORRUPT, "cannot read the footer"); }
     uint64_t moff;
     if (!znippy_interpret_footer(tail, 16, &moff)) {
         close(fd);
@@ -269,12 +271,21 @@ static int load_index(const char *path, znippy_index *ix) {
     const uint64_t mend = ix->file_size - 16;
     if (moff > mend) { close(fd); return fail(ZNIPPY_E_CORRUPT, "corrupt v0.7 manifest_offset"); }
     std::vector<uint8_t> mb(mend - moff);
-    pread_all(fd, mb.data(), mb.size(), moff);
+    if (!mb.empty() && !pread_all(fd, mb.data(), mb.size(), moff)) { close(fd); return fail(ZNIPPY_E_CORRUPT, "cannot read the manifest"); }
     aipc::Batch m;
     std::string err;
     if (!aipc::read_stream(mb.data(), mb.size(), &m, nullptr, &err) || m.cols.size() != 6) {
         close(fd);
         return fail(ZNIPPY_E_CORRUPT, "manifest: " + err);
+    }
+    {  // the six manifest columns, by kind and with equal row counts (index.rs:L279-288)
+        const aipc::Batch want = manifest_schema();
+        const size_t nr = m.cols[0].rows();
+        for (size_t c = 0; c < 6; c++)
+            if (m.cols[c].kind != want.cols[c].kind || m.cols[c].rows() != nr) {
+                close(fd);
+                return fail(ZNIPPY_E_CORRUPT, "manifest: column " + want.cols[c].name + " has the wrong type or length");
+            }
     }
     ix->blob_end = moff;
     for (size_t i = 0; i < m.rows(); i++) {
@@ -286,9 +297,9 @@ static int load_index(const char *path, znippy_index *ix) {
     ix->rows.cols.clear();
     bool first = true;
     for (const auto &e : ix->manifest) {
-        if (e.index_offset + e.index_len > ix->file_size) { close(fd); return fail(ZNIPPY_E_CORRUPT, "sub-index out of range"); }
+        if (e.index_offset > ix->file_size || e.index_len > ix->file_size - e.index_offset) { close(fd); return fail(ZNIPPY_E_CORRUPT, "sub-index out of range"); }
         std::vector<uint8_t> sb(e.index_len);
-        pread_all(fd, sb.data(), sb.size(), e.index_offset);
+        if (!sb.empty() && !pread_all(fd, sb.data(), sb.size(), e.index_offset)) { close(fd); return fail(ZNIPPY_E_CORRUPT, "cannot read a sub-index"); }
         if (!aipc::read_stream(sb.data(), sb.size(), &ix->rows, first ? &ix->metadata : nullptr, &err)) {
             close(fd);
             return fail(ZNIPPY_E_CORRUPT, "sub-index: " + err);
@@ -307,7 +318,28 @@ static int load_index(const char *path, znippy_index *ix) {
         if (!found) return fail(ZNIPPY_E_CORRUPT, "index is missing column " + wc.name);
     }
     ix->rows = std::move(ordered);
+    const size_t nr = ix->rows.cols[0].rows();
+    for (const auto &c : ix->rows.cols)
+        if (c.rows() != nr) return fail(ZNIPPY_E_CORRUPT, "index column " + c.name + " has the wrong length");
     return ZNIPPY_OK;
+}
+
+// No C++ exception crosses the C ABI: allocation failures and anything a parser throws become status codes.
+template <class F>
+static int guarded(F &&f) {
+    try {
+        return f();
+    } catch (const std::bad_alloc &) {
+        return fail(ZNIPPY_E_NOMEM, "out of host memory");
+    } catch (const std::exception &e) {
+        return fail(ZNIPPY_E_CORRUPT, std::string("malformed input: ") + e.what());
+    } catch (...) {
+        return fail(ZNIPPY_E_CORRUPT, "malformed input");
+    }
+}
+
+static int load_index(const char *path, znippy_index *ix) {
+    return guarded([&] { return load_index_impl(path, ix); });
 }
 
 namespace {
@@ -576,7 +608,7 @@ size_t znippy_write_manifest_bytes(const znippy_manifest_entry *entries, size_t 
 }
 
 // ---- write side: compress_stream --------------------------------------------------------------
-int znippy_compress_stream(const char *output, int no_skip, int device, znippy_stream **out) {
+static int znippy_compress_stream_impl(const char *output, int no_skip, int device, znippy_stream **out) {
     if (!output || !out) return fail(ZNIPPY_E_INVAL, "null argument");
     std::unique_ptr<znippy_stream> s(new znippy_stream());
     s->t_open = now_s();
@@ -593,7 +625,7 @@ int znippy_compress_stream(const char *output, int no_skip, int device, znippy_s
 
 // The reader's chunking (stream_packer.rs:L146-206) runs on the caller's thread: each entry is cut into
 // Rounds and copied once, straight into page-locked staging.
-int znippy_stream_send(znippy_stream *s, const char *relative_path, const void *data, size_t len, int pkg_type,
+static int znippy_stream_send_impl(znippy_stream *s, const char *relative_path, const void *data, size_t len, int pkg_type,
                        const char *repo) {
     if (!s || !relative_path || (len && !data)) return fail(ZNIPPY_E_INVAL, "null argument");
     const double t0 = now_s();
@@ -620,7 +652,7 @@ int znippy_stream_send(znippy_stream *s, const char *relative_path, const void *
     return ZNIPPY_OK;
 }
 
-int znippy_stream_finish(znippy_stream *sp, znippy_compression_report *report) {
+static int znippy_stream_finish_impl(znippy_stream *sp, znippy_compression_report *report) {
     if (!sp) return fail(ZNIPPY_E_INVAL, "null stream");
     std::unique_ptr<znippy_stream> s(sp);
     const double t0 = now_s();
@@ -775,7 +807,7 @@ private:
 
 extern "C" {
 
-int znippy_compress_dir(const char *input_dir, const char *output, int no_skip, const char *repo, int device,
+static int znippy_compress_dir_impl(const char *input_dir, const char *output, int no_skip, const char *repo, int device,
                         znippy_compression_report *report) {
     if (!input_dir || !output) return fail(ZNIPPY_E_INVAL, "null argument");
     const double t_begin = now_s();
@@ -861,6 +893,7 @@ namespace {
 
 struct DecodedRange {
     std::vector<uint64_t> out_off;  // position of each row's bytes in the decoded region
+    std::vector<uint64_t> len;      // bytes of each row: uncompressed_size, or blob_size for a stored row (decompress.rs:L160-166)
     uint64_t total = 0;
     std::vector<int32_t> status;
     znippy_verify_counters cnt{};
@@ -880,13 +913,17 @@ int decode_range(znippy_ctx *ctx, int arc_fd, const znippy_index &ix, const uint
     std::vector<uint64_t> bo(n), bs(n), us(n);
     std::vector<uint8_t> bitmap((n + 7) / 8, 0), ck(verify ? 32 * n : 0);
     dr->out_off.assign(n, 0);
+    dr->len.assign(n, 0);
     dr->status.assign(n, 0);
     dr->total = 0;
     dr->cnt = znippy_verify_counters{};
     uint64_t lo = UINT64_MAX, hi = 0, sum = 0;
     for (size_t k = 0; k < n; k++) {
         const uint64_t r = row_ids[k];
-        bo[k] = ix.rows.cols[5].u64[r]; bs[k] = ix.rows.cols[6].u64[r]; us[k] = ix.rows.cols[4].u64[r];
+        bo[k] = ix.rows.cols[5].u64[r]; bs[k] = ix.rows.cols[6].u64[r];
+        us[k] = ix.rows.cols[3].u8[r] ? ix.rows.cols[4].u64[r] : bs[k];  // a stored row is its blob
+        dr->len[k] = us[k];
+        if (dr->total + us[k] < dr->total) return fail(ZNIPPY_E_CORRUPT, "row sizes overflow");
         if (ix.rows.cols[3].u8[r]) bitmap[k >> 3] |= (uint8_t)(1u << (k & 7));
         if (verify) std::memcpy(&ck[32 * k], &ix.rows.cols[7].u8[32 * r], 32);
         dr->out_off[k] = dr->total;
@@ -920,6 +957,7 @@ int decode_range(znippy_ctx *ctx, int arc_fd, const znippy_index &ix, const uint
     znippy_rows *rt = nullptr;
     int rc = znippy_rows_create(ctx, bo.data(), bs.data(), bitmap.data(), us.data(), dr->out_off.data(), verify ? ck.data() : nullptr, 0, n, &rt);
     if (rc) return fail(rc, "znippy_rows_create failed");
+    znippy_rows_set_blob_cap(rt, nblob);  // a row pointing outside what was read is an error code, not a device fault
     std::vector<uint64_t> cr(n);
     rc = znippy_decode_verify_rows(ctx, rt, bufs.d_blobs.p, base, bufs.d_out.p, dr->total, &dr->cnt, cr.data(), n, dr->status.data());
     znippy_rows_destroy(rt);
@@ -936,7 +974,8 @@ struct RowWriter {
     const znippy_index *ix;
     const char *out_dir;
     const std::vector<uint8_t> *first_touch;
-    bool truncate;
+    bool truncate;  // this process owns the whole archive: O_TRUNC on first touch, like the reference (L74-101)
+    const std::unordered_map<std::string, uint64_t> *final_size;  // several ranks share the files: first touch sets the final size
     std::atomic<int> *err;
     void operator()(const uint8_t *bytes, const DecodedRange *dr, uint64_t row0, uint64_t k0, uint64_t k1) const {
         std::string cur_dir;
@@ -960,8 +999,15 @@ struct RowWriter {
                 fd = open(full.c_str(), O_CREAT | O_WRONLY | ((first && truncate) ? O_TRUNC : 0), 0644);
                 cur_path = &p;
                 if (fd < 0) { err->store(1); g_open_failed(p); return; }
+                // Ranks write disjoint parts of a file in any order, so none of them may O_TRUNC; instead every rank
+                // sets the file to its final length when it first touches it (idempotent: every row lies inside
+                // that length) — a longer file left from an earlier run loses its stale tail.
+                if (first && !truncate && final_size) {
+                    auto it = final_size->find(p);
+                    if (it != final_size->end() && ftruncate(fd, (off_t)it->second) != 0) err->store(2);
+                }
             }
-            if (!pwrite_all(fd, bytes + dr->out_off[k], ix->rows.cols[4].u64[r], ix->rows.cols[2].u64[r])) err->store(2);
+            if (!pwrite_all(fd, bytes + dr->out_off[k], dr->len[k], ix->rows.cols[2].u64[r])) err->store(2);
         }
         if (fd >= 0) close(fd);
     }
@@ -972,7 +1018,7 @@ struct RowWriter {
 
 extern "C" {
 
-int znippy_decompress_archive(const char *index_path, int save_data, const char *out_dir, int device, uint32_t rank,
+static int znippy_decompress_archive_impl(const char *index_path, int save_data, const char *out_dir, int device, uint32_t rank,
                               uint32_t world, znippy_verify_report *report, uint64_t *corrupt_rows, uint64_t corrupt_cap,
                               uint64_t *n_corrupt) {
     if (!index_path || !report || (save_data && !out_dir) || world == 0 || rank >= world) return fail(ZNIPPY_E_INVAL, "bad argument");
@@ -999,6 +1045,22 @@ int znippy_decompress_archive(const char *index_path, int save_data, const char 
         n_unique = uniq.size();
     }
     const auto range = split_rows(ix.rows.cols[4].u64, rank, world);
+    std::unordered_map<std::string, uint64_t> final_size;
+    if (world > 1 && save_data) {
+        // first touch is per rank (the first row of a path inside MY range), and comes with the file's final length
+        std::fill(first_touch.begin(), first_touch.end(), 0);
+        std::unordered_set<std::string> seen;
+        for (uint64_t r = range.first; r < range.second; r++) {
+            if (r > range.first && paths[r] == paths[r - 1]) continue;
+            if (seen.insert(paths[r]).second) first_touch[r] = 1;
+        }
+        final_size.reserve(n_unique * 2);
+        for (uint64_t r = 0; r < n_rows; r++) {
+            const uint64_t len = ix.rows.cols[3].u8[r] ? ix.rows.cols[4].u64[r] : ix.rows.cols[6].u64[r];
+            uint64_t &fs = final_size[paths[r]];
+            fs = std::max(fs, ix.rows.cols[2].u64[r] + len);
+        }
+    }
     if (save_data) mkdirs(out_dir);
     int arc = open(index_path, O_RDONLY);
     if (arc < 0) return fail(ZNIPPY_E_INVAL, "cannot open archive");
@@ -1023,7 +1085,7 @@ int znippy_decompress_archive(const char *index_path, int save_data, const char 
         void join() { for (auto &t : writers) t.join(); writers.clear(); }
     } slabs[2];
     std::atomic<int> werr{0};
-    const RowWriter writer{&ix, out_dir, &first_touch, world == 1, &werr};
+    const RowWriter writer{&ix, out_dir, &first_touch, world == 1, world > 1 ? &final_size : nullptr, &werr};
     const unsigned n_writers = adjacent ? writer_threads() : 1;
     const uint64_t batch_bytes = range_bytes(save_data != 0);
     double t_d2h = 0, t_wjoin = 0;
@@ -1118,7 +1180,7 @@ struct znippy_archive {
 
 extern "C" {
 
-int znippy_archive_open(const char *path, int device, znippy_archive **out) {
+static int znippy_archive_open_impl(const char *path, int device, znippy_archive **out) {
     if (!path || !out) return fail(ZNIPPY_E_INVAL, "null argument");
     std::unique_ptr<znippy_archive> a(new znippy_archive());
     a->path = path;
@@ -1147,7 +1209,7 @@ int64_t znippy_archive_file_size(const znippy_archive *a, const char *rel) {
     return (int64_t)s;
 }
 
-int znippy_archive_extract_file(znippy_archive *a, const char *rel, void *dst, size_t cap, size_t *written) {
+static int znippy_archive_extract_file_impl(znippy_archive *a, const char *rel, void *dst, size_t cap, size_t *written, int verify = 0) {
     if (!a || !rel || !written) return fail(ZNIPPY_E_INVAL, "null argument");
     auto it = a->files.find(rel);
     if (it == a->files.end()) return fail(ZNIPPY_E_INVAL, std::string("file not found in archive: ") + rel);
@@ -1157,10 +1219,13 @@ int znippy_archive_extract_file(znippy_archive *a, const char *rel, void *dst, s
         if (rc) return fail(rc, "no usable GPU: the codec/hash path has no CPU fallback");
     }
     DecodedRange dr;
-    int rc = decode_range(a->ctx, a->fd, a->ix, it->second.data(), it->second.size(), false, a->bufs, &dr);
+    int rc = decode_range(a->ctx, a->fd, a->ix, it->second.data(), it->second.size(), verify != 0, a->bufs, &dr);
     if (rc) return rc;
     for (int32_t st : dr.status)
         if (st < 0) return fail(st, "OpenZL-equivalent decompress failed");  // propagates (archive.rs:L160)
+    // optional verify (the reference's extract_file has none, archive.rs:L144-168; SURVEY §8f rank 1 adds it): every
+    // chunk's BLAKE3 against the index's checksum column, computed by the same kernels as the bulk path
+    if (verify && dr.cnt.corrupt_rows) return fail(ZNIPPY_E_CHECKSUM, std::string("checksum mismatch in ") + rel);
     if (dr.total > cap) return fail(ZNIPPY_E_DST_SMALL, "destination too small");
     if (dr.total && hipMemcpy(dst, a->bufs.d_out.p, dr.total, hipMemcpyDeviceToHost) != hipSuccess) return fail(ZNIPPY_E_HIP, "D2H failed");
     *written = dr.total;
@@ -1175,7 +1240,7 @@ void znippy_archive_close(znippy_archive *a) {
 }
 
 // ---- index ------------------------------------------------------------------------------------
-int znippy_index_open(const char *path, znippy_index **out) {
+static int znippy_index_open_impl(const char *path, znippy_index **out) {
     if (!path || !out) return fail(ZNIPPY_E_INVAL, "null argument");
     std::unique_ptr<znippy_index> ix(new znippy_index());
     int rc = load_index(path, ix.get());
@@ -1212,5 +1277,46 @@ const char *znippy_index_metadata(const znippy_index *ix, const char *key) {
     return it == ix->metadata.end() ? nullptr : it->second.c_str();
 }
 void znippy_index_close(znippy_index *ix) { delete ix; }
+
+}  // extern "C"
+
+// ---- the entry points above, behind the exception guard ----
+extern "C" {
+
+int znippy_archive_extract_file_verified(znippy_archive *a, const char *relative_path, void *dst, size_t cap, size_t *written) {
+    return guarded([&] { return znippy_archive_extract_file_impl(a, relative_path, dst, cap, written, 1); });
+}
+
+int znippy_compress_stream(const char *output, int no_skip, int device, znippy_stream **out) {
+    return guarded([&] { return znippy_compress_stream_impl(output, no_skip, device, out); });
+}
+
+int znippy_stream_send(znippy_stream *s, const char *relative_path, const void *data, size_t len, int pkg_type, const char *repo) {
+    return guarded([&] { return znippy_stream_send_impl(s, relative_path, data, len, pkg_type, repo); });
+}
+
+int znippy_stream_finish(znippy_stream *sp, znippy_compression_report *report) {
+    return guarded([&] { return znippy_stream_finish_impl(sp, report); });
+}
+
+int znippy_compress_dir(const char *input_dir, const char *output, int no_skip, const char *repo, int device, znippy_compression_report *report) {
+    return guarded([&] { return znippy_compress_dir_impl(input_dir, output, no_skip, repo, device, report); });
+}
+
+int znippy_decompress_archive(const char *index_path, int save_data, const char *out_dir, int device, uint32_t rank, uint32_t world, znippy_verify_report *report, uint64_t *corrupt_rows, uint64_t corrupt_cap, uint64_t *n_corrupt) {
+    return guarded([&] { return znippy_decompress_archive_impl(index_path, save_data, out_dir, device, rank, world, report, corrupt_rows, corrupt_cap, n_corrupt); });
+}
+
+int znippy_archive_open(const char *path, int device, znippy_archive **out) {
+    return guarded([&] { return znippy_archive_open_impl(path, device, out); });
+}
+
+int znippy_archive_extract_file(znippy_archive *a, const char *rel, void *dst, size_t cap, size_t *written) {
+    return guarded([&] { return znippy_archive_extract_file_impl(a, rel, dst, cap, written, 0); });
+}
+
+int znippy_index_open(const char *path, znippy_index **out) {
+    return guarded([&] { return znippy_index_open_impl(path, out); });
+}
 
 }  // extern "C"

@@ -660,13 +660,15 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES == 4 ? 4 : 1) void k_zstd_decod
             const uint32_t it = S.row;
             S.skip = a.block_mode && w < n_work && (a.item_src[it] == 0xFFFFFFFFu || a.row_flag[a.item_row[it]] != 0 ||
                                                     (a.item_done && a.item_done[it]));
+            if (!a.block_mode && a.preset && w < n_work)  // the host already ruled on this row (bad source / output range)
+                S.skip = a.status[w < a.n_list_a ? a.list_a[w] : a.pending[w - a.n_list_a]] < 0;
         }
         __syncthreads();
         const uint32_t widx = S.row;
         if (S.claim >= n_work) break;
         uint32_t row, item_k = 0, item_src = 0;
+        if (S.skip) { __syncthreads(); continue; }  // block item not eligible / frame already given up / host verdict
         if (a.block_mode) {
-            if (S.skip) { __syncthreads(); continue; }  // not eligible / the frame was already given up
             row = a.item_row[widx]; item_k = a.item_k[widx]; item_src = a.item_src[widx];
         } else row = widx < a.n_list_a ? a.list_a[widx] : a.pending[widx - a.n_list_a];
 
@@ -1324,7 +1326,7 @@ __global__ __launch_bounds__(64) void k_scan_blocks(BlockScanArgs a) {
     if (c >= a.n_cand) return;
     const uint32_t row = a.cand_row[c], base = a.cand_base[c], nb = a.cand_nblocks[c];
     const uint8_t *src = a.blobs + (a.blob_off[row] - a.blob_base);
-    const uint64_t n = a.blob_size[row], fcs_want = a.usize[row];
+    const uint64_t n = (a.preset && a.status[row] < 0) ? 0 : a.blob_size[row], fcs_want = a.usize[row];  // host verdict: not a candidate
     bool ok = n >= 6 && (src[0] | (src[1] << 8) | (src[2] << 16) | ((uint32_t)src[3] << 24)) == 0xFD2FB528u;
     uint64_t pos = 5;
     if (ok) {
@@ -1414,6 +1416,7 @@ __global__ __launch_bounds__(64) void k_finish_blocks(BlockScanArgs a) {
     const uint32_t c = blockIdx.x * 64 + threadIdx.x;
     if (c >= a.n_cand) return;
     const uint32_t row = a.cand_row[c];
+    if (a.status[row] < 0) return;  // host verdict stands
     if (a.row_flag[row]) {
         a.status[row] = 1;  // handed to the general decoder, like a row the fused kernel gave up on
         a.pending[atomicAdd(a.pending_count, 1u)] = row;

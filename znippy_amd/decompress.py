@@ -39,6 +39,55 @@ def _columns(batches):
                 checksum=ck_np)
 
 
+def row_lengths(c):
+    """Bytes each row produces: uncompressed_size, or blob_size for a stored row — the reference hashes and writes
+    the blob itself there and never looks at uncompressed_size (decompress.rs:L143-166, `&read_buf`)."""
+    return np.where(c["compressed"], c["usize"], c["blob_size"]).astype(np.uint64)
+
+
+def read_spans(f, file_size, bo, bs, gap=64 << 10):
+    """Blobs of the given rows as ONE packed buffer: rows are grouped into spans (neighbours closer than `gap` are
+    read together), each span is one positioned read, and every row's offset is rebased into the buffer.  Rows
+    that do not lie inside the file keep an offset PAST the buffer, so the device layer reports them
+    (ZNIPPY_E_CORRUPT) instead of reading anything.  -> (buffer, rebased blob_offset)"""
+    n = len(bo)
+    new_bo = np.zeros(n, np.uint64)
+    if n == 0:
+        return np.zeros(0, np.uint8), new_bo
+    ok = (bo <= file_size) & (bs <= file_size - np.minimum(bo, file_size))
+    order = np.argsort(bo, kind="stable")
+    parts, pos, bad = [], 0, []
+    i = 0
+    while i < n:
+        k = int(order[i])
+        if not ok[k]:
+            bad.append(k)
+            i += 1
+            continue
+        lo, hi = int(bo[k]), int(bo[k] + bs[k])
+        members = [k]
+        j = i + 1
+        while j < n and ok[int(order[j])] and int(bo[int(order[j])]) <= hi + gap:
+            m = int(order[j])
+            hi = max(hi, int(bo[m] + bs[m]))
+            members.append(m)
+            j += 1
+        f.seek(lo)
+        data = f.read(hi - lo)
+        if len(data) != hi - lo:  # truncated underneath us: the rows of this span become out-of-range rows
+            bad.extend(members)
+        else:
+            parts.append(np.frombuffer(data, dtype=np.uint8))
+            for m in members:
+                new_bo[m] = pos + int(bo[m]) - lo
+            pos += hi - lo
+        i = j
+    buf = np.concatenate(parts) if parts else np.zeros(0, np.uint8)
+    for k in bad:
+        new_bo[k] = len(buf) + 1
+    return buf, new_bo
+
+
 def decompress_archive(index_path, save_data: bool, out_dir, backend=None, group=None) -> ix.VerifyReport:
     from .backend import default_backend
     index_path, out_dir = str(index_path), str(out_dir)
@@ -54,7 +103,16 @@ def decompress_archive(index_path, save_data: bool, out_dir, backend=None, group
             rank, world = dist.get_rank(group), dist.get_world_size(group)
     except ImportError:
         pass
+    rlen = row_lengths(c)
     r0, r1 = split_rows(c["usize"], world)[rank]
+    file_size = os.path.getsize(index_path)
+    final_size = {}
+    if world > 1 and save_data:  # several ranks write one file: whoever touches it first sets its final length
+        ends = c["fdata_offset"] + rlen
+        for p, e in zip(c["paths"], ends):
+            e = int(e)
+            if final_size.get(p, -1) < e:
+                final_size[p] = e
 
     # output files (L74-101): created/truncated on first touch, one cached descriptor (rows of a file are
     # adjacent) instead of the reference's table of open files
@@ -72,6 +130,10 @@ def decompress_archive(index_path, save_data: bool, out_dir, backend=None, group
             os.makedirs(os.path.dirname(full) or ".", exist_ok=True)
         flags = os.O_CREAT | os.O_WRONLY | (os.O_TRUNC if (first and world == 1) else 0)
         cur[0], cur[1] = p, os.open(full, flags, 0o644)
+        if first and world > 1:
+            # no rank may O_TRUNC (the others write their parts in any order); instead each sets the file to its final
+            # length at first touch — idempotent, and a longer file left by an earlier run loses its stale tail
+            os.ftruncate(cur[1], final_size[p])
         return cur[1]
 
     backend = backend or (default_backend() if r1 > r0 else None)
@@ -82,17 +144,14 @@ def decompress_archive(index_path, save_data: bool, out_dir, backend=None, group
         i = r0
         while i < r1:
             j, nbytes = i, 0
-            while j < r1 and (j == i or nbytes + int(c["usize"][j]) <= RANGE_BYTES):
-                nbytes += int(c["usize"][j])
+            while j < r1 and (j == i or nbytes + int(rlen[j]) <= RANGE_BYTES):
+                nbytes += int(rlen[j])
                 j += 1
-            bo, bs = c["blob_offset"][i:j], c["blob_size"][i:j]
-            lo = int(bo.min()) if j > i else 0
-            hi = int((bo + bs).max()) if j > i else 0
-            arc.seek(lo)
-            blobs = np.frombuffer(arc.read(hi - lo), dtype=np.uint8)  # the preads of L148-153, coalesced
-            usz = c["usize"][i:j]
+            bs = c["blob_size"][i:j]
+            blobs, bo = read_spans(arc, file_size, c["blob_offset"][i:j], bs)  # the preads of L148-153, coalesced
+            usz = rlen[i:j]
             out_off = np.concatenate([[0], np.cumsum(usz)[:-1]]).astype(np.uint64)
-            cnt, corrupt, status, out = backend.decode_verify(blobs, lo, bo, bs, usz, out_off, c["compressed"][i:j],
+            cnt, corrupt, status, out = backend.decode_verify(blobs, 0, bo, bs, usz, out_off, c["compressed"][i:j],
                                                               c["checksum"][i:j], int(usz.sum()))
             for k in counters:
                 counters[k] += int(cnt[k])

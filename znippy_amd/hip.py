@@ -135,8 +135,12 @@ class RowTable:
 
     __del__ = close
 
-    def decode_verify_async(self, d_blobs, d_out, blob_base=0, out_cap=None):
+    def decode_verify_async(self, d_blobs, d_out, blob_base=0, out_cap=None, blob_cap=None):
         out_cap = d_out.numel() if out_cap is None else out_cap
+        if blob_cap is None and not isinstance(d_blobs, int):
+            blob_cap = d_blobs.numel()
+        if blob_cap is not None:  # the blob region's size is known: rows pointing outside it become error codes
+            self.ctx._chk(self.ctx.L.znippy_rows_set_blob_cap(self.h, int(blob_cap)), "znippy_rows_set_blob_cap")
         self.ctx._chk(self.ctx.L.znippy_decode_verify_rows_async(self.ctx.h, self.h, _dptr(d_blobs), blob_base,
                                                                  _dptr(d_out), out_cap),
                       "znippy_decode_verify_rows_async")
@@ -148,8 +152,15 @@ class RowTable:
                                                      np_ptr(status) if want_status else None), "znippy_rows_results")
         return c.as_dict(), corrupt[:min(c.corrupt_rows, corrupt.size)].copy(), status[:self.n]
 
-    def decode_verify(self, d_blobs, d_out, blob_base=0, out_cap=None):
-        self.decode_verify_async(d_blobs, d_out, blob_base, out_cap)
+    def results_lagged(self, lag=1):
+        """Counters of the run `lag` runs before the latest queued one (waits for that run only)."""
+        c = VerifyCounters()
+        self.ctx._chk(self.ctx.L.znippy_rows_results_lagged(self.ctx.h, self.h, lag, C.byref(c)),
+                      "znippy_rows_results_lagged")
+        return c.as_dict()
+
+    def decode_verify(self, d_blobs, d_out, blob_base=0, out_cap=None, blob_cap=None):
+        self.decode_verify_async(d_blobs, d_out, blob_base, out_cap, blob_cap)
         return self.results()
 
     def digests(self):
@@ -217,6 +228,18 @@ class RoundTable:
                           "znippy_rounds_results")
         return dict(blob_offset=mk(bo, 8 * k, np.uint64), blob_size=mk(bs, 8 * k, np.uint64),
                     checksum=mk(ck, 32 * k, np.uint8).reshape(k, 32), compressed=comp, blob_bytes=int(total.value))
+
+    def results_lagged(self, lag=1):
+        """Views of the results of the run `lag` runs before the latest queued one (compressed[] as known to the host)."""
+        bo, bs, ck = vp(), vp(), vp()
+        total = C.c_uint64()
+        self.ctx._chk(self.ctx.L.znippy_rounds_results_lagged(self.ctx.h, self.h, lag, C.byref(bo), C.byref(bs),
+                                                              C.byref(ck), C.byref(total)), "znippy_rounds_results_lagged")
+        k = self.n
+        mk = lambda p, nbytes, dt: np.frombuffer((C.c_uint8 * nbytes).from_address(p.value), dtype=dt)
+        return dict(blob_offset=mk(bo, 8 * k, np.uint64), blob_size=mk(bs, 8 * k, np.uint64),
+                    checksum=mk(ck, 32 * k, np.uint8).reshape(k, 32), compressed=self._compressed,
+                    blob_bytes=int(total.value))
 
     def encode_hash(self, d_src, d_blob_out, blob_cap=None):
         self.encode_hash_async(d_src, d_blob_out, blob_cap)

@@ -29,7 +29,7 @@ class _ME(C.Structure):
 HOST_EXPORTS = [
     "znippy_host_last_error", "znippy_compress_stream", "znippy_stream_send", "znippy_stream_finish",
     "znippy_compress_dir", "znippy_decompress_archive", "znippy_archive_open", "znippy_archive_file_count", "znippy_archive_file_size",
-    "znippy_archive_extract_file", "znippy_archive_close", "znippy_index_open", "znippy_index_rows",
+    "znippy_archive_extract_file", "znippy_archive_extract_file_verified", "znippy_archive_close", "znippy_index_open", "znippy_index_rows",
     "znippy_index_manifest_len", "znippy_index_manifest_entry", "znippy_index_row", "znippy_index_metadata",
     "znippy_index_close", "znippy_interpret_footer", "znippy_write_manifest_bytes",
 ]
@@ -54,6 +54,7 @@ def lib():
         L.znippy_archive_file_size.argtypes = [vp, C.c_char_p]
         L.znippy_archive_file_size.restype = C.c_int64
         L.znippy_archive_extract_file.argtypes = [vp, C.c_char_p, vp, C.c_size_t, C.POINTER(C.c_size_t)]
+        L.znippy_archive_extract_file_verified.argtypes = [vp, C.c_char_p, vp, C.c_size_t, C.POINTER(C.c_size_t)]
         L.znippy_archive_close.argtypes = [vp]
         L.znippy_archive_close.restype = None
         L.znippy_index_open.argtypes = [C.c_char_p, C.POINTER(vp)]
@@ -157,13 +158,15 @@ class ZnippyArchive:
         s = lib().znippy_archive_file_size(self.h, rel.encode())
         return None if s < 0 else int(s)
 
-    def extract_file(self, rel) -> bytes:
+    def extract_file(self, rel, verify=False) -> bytes:
+        """verify=True: every chunk's BLAKE3 is checked against the index (the reference has no such option)."""
         size = self.file_size(rel)
         if size is None:
             raise KeyError(f"file not found in archive: {rel}")
         buf = np.empty(max(size, 1), dtype=np.uint8)
         w = C.c_size_t()
-        _chk(lib().znippy_archive_extract_file(self.h, rel.encode(), buf.ctypes.data_as(vp), size, C.byref(w)), "extract_file")
+        f = lib().znippy_archive_extract_file_verified if verify else lib().znippy_archive_extract_file
+        _chk(f(self.h, rel.encode(), buf.ctypes.data_as(vp), size, C.byref(w)), "extract_file")
         return buf[:w.value].tobytes()
 
     def close(self):
