@@ -173,6 +173,9 @@ int znippy_hash_rounds(znippy_ctx *ctx, znippy_rounds *rounds, const void *d_src
 /* ---- measurement hooks (bench.py): device time of the last async call's kernels, by HIP
  * events on the context's stream.  names/ms: up to cap entries; returns the count. */
 int znippy_last_kernel_times(znippy_ctx *ctx, const char **names, float *ms, int cap);
+/* The hash's VALU floor, measured: nanoseconds one 64-lane BLAKE3 compress pass costs a SIMD when nothing else runs
+ * (a kernel of compressions only, 4 waves per SIMD on every CU).  bench.py prices the read step's passes with it. */
+int znippy_measure_blake3_pass_ns(znippy_ctx *ctx, float *ns_per_pass_per_simd);
 
 #ifdef __cplusplus
 }

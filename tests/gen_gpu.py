@@ -17,7 +17,12 @@ def binary(size, device="cuda"):
 
 
 def _lcg(v0, size, inc, device="cuda"):
-    """val_{k+1} = val_k * a + inc (mod 2^64), byte = val >> 33; int64 arithmetic wraps like u64."""
+    """val_{k+1} = val_k * a + inc (mod 2^64), byte = val >> 33; int64 arithmetic wraps like u64.
+
+    Built by doubling: the first k values and the coefficients of a k-step jump give the next k values in one
+    multiply-add, so B values take log2(B) launches; the stream is then extended B at a time.  (The first version
+    made 4 launches per 64 KiB — 32,000 for C4's 500 MiB — and crashed under rocprofv3 --pmc, inside the profiler's
+    interception of a torch launch; see profiles/README.md.)"""
     a = 6364136223846793005
     mask = (1 << 64) - 1
 
@@ -25,27 +30,27 @@ def _lcg(v0, size, inc, device="cuda"):
         x &= mask
         return x - (1 << 64) if x >= (1 << 63) else x
 
-    B = 1 << 16
-    # first B values sequentially on the host (python ints), then jump-ahead by B on the device
-    vals = np.empty(B, dtype=np.int64)
-    v = v0
-    for i in range(B):
-        v = (v * a + inc) & mask
-        vals[i] = s64(v)
-    A, Cc = 1, 0
-    for _ in range(B):
-        A = (A * a) & mask
-        Cc = (Cc * a + inc) & mask
-    cur = torch.from_numpy(vals).to(device)
-    A_t = torch.tensor(s64(A), dtype=torch.int64, device=device)
-    C_t = torch.tensor(s64(Cc), dtype=torch.int64, device=device)
+    def t64(x):
+        return torch.tensor(s64(x), dtype=torch.int64, device=device)
+
+    if size == 0:
+        return torch.empty(0, dtype=torch.uint8, device=device)
+    B = 1 << 24
+    cur = torch.tensor([s64((v0 * a + inc) & mask)], dtype=torch.int64, device=device)  # val_1
+    A, Cc = a, inc                                   # coefficients of a jump by len(cur) = 1 step
+    while cur.numel() < min(B, size):
+        cur = torch.cat([cur, cur * t64(A) + t64(Cc)])
+        A, Cc = (A * A) & mask, (Cc * A + Cc) & mask  # jump by twice as many steps
     out = torch.empty(size, dtype=torch.uint8, device=device)
+    n0 = cur.numel()
+    A_t, C_t = t64(A), t64(Cc)                       # jump by n0 steps
     pos = 0
     while pos < size:
-        n = min(B, size - pos)
+        n = min(n0, size - pos)
         out[pos:pos + n] = ((cur[:n] >> 33) & 0xFF).to(torch.uint8)
-        cur = cur * A_t + C_t
         pos += n
+        if pos < size:
+            cur = cur * A_t + C_t
     return out
 
 

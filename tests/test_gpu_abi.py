@@ -66,3 +66,136 @@ def test_bound_covers_every_input(gpu_ctx):
     for n in (0, 1, 7, 1000, 131072, 131073, 1 << 20):
         for data in (gen.random_lcg(n), bytes(n)):
             assert len(gpu_ctx.compress(data)) <= gpu_ctx.compress_bound(n)
+
+
+def _table(gpu_ctx, oracle, entries, comp, level=3):
+    """Rows over a packed blob region: entries[i] compressed with libzstd when comp[i] else stored."""
+    frames = [oracle.libzstd_compress(e, level) if c else e for e, c in zip(entries, comp)]
+    bs = np.array([len(f) for f in frames], dtype=np.uint64)
+    bo = np.concatenate([[0], np.cumsum(bs)[:-1]]).astype(np.uint64)
+    us = np.array([len(e) for e in entries], dtype=np.uint64)
+    oo = np.concatenate([[0], np.cumsum(us)[:-1]]).astype(np.uint64)
+    ck = np.stack([np.frombuffer(oracle.blake3(e), dtype=np.uint8) for e in entries])
+    return b"".join(frames), bo, bs, us, oo, np.packbits(np.asarray(comp, dtype=bool), bitorder="little"), ck
+
+
+def test_stored_row_is_its_blob_whatever_the_index_says(gpu_ctx, oracle):
+    """a stored row (compressed = 0) is hashed, copied and counted with blob_size bytes — what the
+    reference does (`&read_buf`, decompress.rs:L143-166) — so an index row whose uncompressed_size disagrees can
+    not make the store-path kernels read past the blob."""
+    import torch
+    from znippy_amd import hip
+    entries = [gen.incompressible(3, 5000), gen.text(10240), gen.incompressible(4, 200000)]
+    blob, bo, bs, us, oo, bitmap, ck = _table(gpu_ctx, oracle, entries, [0, 1, 0])
+    lied = us.copy()
+    lied[0] = 50_000            # small stored row claims 10x its blob
+    lied[2] = 900_000           # big stored row (slices) claims 4.5x its blob
+    d_blobs = torch.from_numpy(np.frombuffer(blob, dtype=np.uint8).copy()).cuda()      # NO padding behind the blobs
+    d_out = torch.zeros(int(us.sum()) + 64, dtype=torch.uint8, device="cuda")
+    rt = hip.RowTable(gpu_ctx, bo, bs, lied, oo, bitmap, ck)
+    counters, corrupt, status = rt.decode_verify(d_blobs, d_out)
+    assert (status == 0).all() and len(corrupt) == 0
+    assert counters["total_written_bytes"] == int(us.sum()) == counters["verified_bytes"]
+    assert d_out[:int(us.sum())].cpu().numpy().tobytes() == b"".join(entries)
+
+
+def test_rows_outside_the_blob_or_output_region_are_error_codes(gpu_ctx, oracle):
+    """Bad source ranges (crafted / truncated index) and short destinations, for stored and compressed rows, small
+    and big: ZNIPPY_E_CORRUPT / ZNIPPY_E_DST_SMALL per row, counted as decode errors, nothing written for them,
+    nothing written past out_cap (guard bytes), the good rows unaffected."""
+    import torch
+    from znippy_amd import _lib, hip
+    entries = [gen.text(10240), gen.incompressible(1, 3000), gen.binary(300000), gen.incompressible(2, 150000),
+               gen.pseudo_text(20000, 3), gen.incompressible(5, 777)]
+    comp = [1, 0, 1, 0, 1, 0]
+    blob, bo, bs, us, oo, bitmap, ck = _table(gpu_ctx, oracle, entries, comp)
+    total = int(us.sum())
+    d_blobs = torch.from_numpy(np.frombuffer(blob, dtype=np.uint8).copy()).cuda()
+    # (1) sources outside the region: offsets past the end, a size that runs over the end, offset + size wrapping
+    bad_bo, bad_bs = bo.copy(), bs.copy()
+    bad_bo[1] = len(blob) + 10                    # small stored row: starts behind the region
+    bad_bs[3] = np.uint64(len(blob))              # big stored row: runs over the end
+    bad_bo[4] = np.uint64(2**64 - 100)            # compressed row: offset + size wraps
+    d_out = torch.zeros(total + 64, dtype=torch.uint8, device="cuda")
+    rt = hip.RowTable(gpu_ctx, bad_bo, bad_bs, us, oo, bitmap, ck)
+    counters, corrupt, status = rt.decode_verify(d_blobs, d_out, blob_cap=len(blob))
+    assert list(status) == [0, _lib.E_CORRUPT, 0, _lib.E_CORRUPT, _lib.E_CORRUPT, 0]
+    assert counters["decode_errors"] == 3 and counters["total_chunks"] == 6 and counters["corrupt_rows"] == 0
+    good = [0, 2, 5]
+    assert counters["verified_bytes"] == sum(len(entries[i]) for i in good)
+    host = d_out.cpu().numpy()
+    for i in good:
+        assert host[int(oo[i]):int(oo[i] + us[i])].tobytes() == entries[i]
+    for i in (1, 3, 4):
+        assert not host[int(oo[i]):int(oo[i] + us[i])].any()      # untouched
+    rt.close()
+    # (2) destination too short: rows that would end behind out_cap are refused, the guard bytes stay
+    cut = int(oo[3]) + 1000                        # rows 3, 4, 5 do not fit
+    d_out = torch.full((total + 64,), 0xAB, dtype=torch.uint8, device="cuda")
+    rt = hip.RowTable(gpu_ctx, bo, bs, us, oo, bitmap, ck)
+    counters, corrupt, status = rt.decode_verify(d_blobs, d_out, out_cap=cut, blob_cap=len(blob))
+    assert list(status) == [0, 0, 0, _lib.E_DST_SMALL, _lib.E_DST_SMALL, _lib.E_DST_SMALL]
+    host = d_out.cpu().numpy()
+    assert (host[int(oo[3]):] == 0xAB).all()
+    assert host[:int(oo[3])].tobytes() == b"".join(entries[:3])
+    assert counters["decode_errors"] == 3 and counters["verified_bytes"] == int(oo[3])
+    # the same table run against a big enough destination afterwards: the verdicts are per (region, cap), not sticky
+    d_out.zero_()
+    counters, corrupt, status = rt.decode_verify(d_blobs, d_out, blob_cap=len(blob))
+    assert (status == 0).all() and counters["verified_bytes"] == total
+    rt.close()
+
+
+def test_lagged_results_pipeline_two_runs_in_flight(gpu_ctx, oracle):
+    """znippy_rows_results_lagged / znippy_rounds_results_lagged: run k's results while run k+1 executes."""
+    import torch
+    from znippy_amd import _lib, hip
+    from znippy_amd._lib import ZnippyError
+    n, sz = 600, 10240
+    chunk = np.frombuffer(gen.text(sz), dtype=np.uint8)
+    d_src = torch.from_numpy(np.tile(chunk, n)).cuda()
+    lens = np.full(n, sz, np.uint64)
+    offs = np.arange(n, dtype=np.uint64) * sz
+    rounds = hip.RoundTable(gpu_ctx, offs, lens)
+    d_blob = torch.zeros(rounds.blob_bound() + 64, dtype=torch.uint8, device="cuda")
+    with pytest.raises(ZnippyError):
+        rounds.results_lagged(0)                  # nothing queued yet
+    rounds.encode_hash_async(d_src, d_blob)
+    first = {k: (v.copy() if hasattr(v, "copy") else v) for k, v in rounds.results_lagged(0).items()}
+    want_ck = oracle.blake3(chunk)
+    assert all(first["checksum"][i].tobytes() == want_ck for i in (0, n // 2, n - 1))
+    for _ in range(3):                             # k+1 queued, k read
+        rounds.encode_hash_async(d_src, d_blob)
+        prev = rounds.results_lagged(1)
+        assert prev["blob_bytes"] == first["blob_bytes"] and np.array_equal(prev["blob_size"], first["blob_size"])
+        assert np.array_equal(prev["checksum"], first["checksum"])
+    last = rounds.results()
+    assert np.array_equal(last["blob_offset"], first["blob_offset"])
+    rows = hip.RowTable(gpu_ctx, first["blob_offset"], first["blob_size"], lens, offs, None, first["checksum"])
+    d_out = torch.zeros(n * sz + 64, dtype=torch.uint8, device="cuda")
+    with pytest.raises(ZnippyError):
+        rows.results_lagged(0)
+    rows.decode_verify_async(d_blob, d_out)
+    with pytest.raises(ZnippyError):
+        rows.results_lagged(1)                     # only one run so far
+    for _ in range(4):
+        rows.decode_verify_async(d_blob, d_out)
+        c = rows.results_lagged(1)
+        assert c["verified_bytes"] == n * sz and c["corrupt_rows"] == 0 and c["total_chunks"] == n
+    c, corrupt, status = rows.results()
+    assert c["verified_bytes"] == n * sz and (status == 0).all()
+    assert torch.equal(d_out[:n * sz], d_src)
+
+
+def test_skippable_frames_in_front_of_a_frame(gpu_ctx, oracle):
+    """the size query steps over leading skippable frames (RFC 8878 3.1.2) — so does the decoder."""
+    import struct
+    from znippy_amd import hip
+    data = gen.pseudo_text(30000, 9)
+    frame = oracle.libzstd_compress(data, 3)
+    skippable = struct.pack("<II", 0x184D2A53, 11) + b"hello world" + struct.pack("<II", 0x184D2A50, 0)
+    assert hip.get_decompressed_size(skippable + frame) == len(data)
+    assert gpu_ctx.decompress(skippable + frame) == data
+    from znippy_amd._lib import ZnippyError
+    with pytest.raises(ZnippyError):
+        hip.get_decompressed_size(struct.pack("<II", 0x184D2A50, 500) + frame[:20])   # skippable frame runs past the input

@@ -119,3 +119,68 @@ def test_c5_mixed_jar_style_archive(gpu_ctx, oracle):
     parts8 = split_rows(lens, 8)
     loads = [sum(lens[a:b]) for a, b in parts8]
     assert max(loads) < 1.5 * total / 8
+
+
+def test_c3_single_2gib_text_file_200mib_slices(gpu_ctx, oracle):
+    """BASELINE configs[2] as worded there: 'split into 200MB Magazine slices' = 11 rounds of <= 200 MiB (in the
+    reference 200 MiB is the slot size, slot_packer.rs:L30; a round this large is format-legal)."""
+    import workloads
+    import torch
+    wl = workloads.build("c3slot", torch)
+    assert len(wl["lens"]) == 11 and int(wl["lens"].sum()) == 2 << 30 and int(wl["lens"].max()) == 200 << 20
+    enc, ratio = _roundtrip(gpu_ctx, oracle, wl["d_src"], wl["lens"], None, sample_rows=[10])
+    assert ratio > 500
+
+
+def test_c5_full_size_mixed_archive_as_8_row_ranges(gpu_ctx, oracle):
+    """BASELINE configs[4] at its stated size (~6.2 GB, 5,000 files) on ONE card: the archive is
+    decoded once as a whole and once as the 8 contiguous row ranges `split_rows` hands to 8 ranks — each range its
+    own row table over only its own blobs (blob_base = its first blob), as decompress_archive does per rank.  The
+    summed counters equal the single-table run (= what the RCCL all-reduce of the counters yields), both outputs
+    equal the source, sampled digests equal the oracle's."""
+    import torch
+    import workloads
+    from znippy_amd import hip
+    from znippy_amd.sharding import split_rows
+    wl = workloads.build("c5", torch)
+    d_src, lens, skip = wl["d_src"], wl["lens"], wl["skip"]
+    n, total = len(lens), int(lens.sum())
+    assert total > 5 * 10**9 and n > 5000
+    offs = np.concatenate([[0], np.cumsum(lens)[:-1]]).astype(np.uint64)
+    rounds = hip.RoundTable(gpu_ctx, offs, lens, skip)
+    d_blob = torch.empty(rounds.blob_bound() + 64, dtype=torch.uint8, device="cuda")
+    enc = rounds.encode_hash(d_src, d_blob)
+    enc = {k: (v.copy() if hasattr(v, "copy") else v) for k, v in enc.items()}
+    rounds.close()
+    bo, bs, ck = enc["blob_offset"], enc["blob_size"], enc["checksum"]
+    assert int(bo[0]) == 0 and np.array_equal(bo[1:], np.cumsum(bs)[:-1])
+    assert np.array_equal(enc["compressed"], 1 - skip)
+    # checksum of checksums on a sample: small xml rows, jar rows, 8 MiB slices of the big jars, the last row
+    for r in (0, 7, 3499, 3500, 3519, 4899, 4900, 4903, n - 1):
+        src = d_src[int(offs[r]):int(offs[r] + lens[r])].cpu().numpy()
+        assert ck[r].tobytes() == oracle.blake3(src), r
+    bitmap = np.packbits(enc["compressed"].astype(bool), bitorder="little")
+    want = dict(total_chunks=n, total_written_bytes=total, verified_bytes=total, corrupt_bytes=0, corrupt_rows=0,
+                decode_errors=0)
+    d_out = torch.zeros(total + 64, dtype=torch.uint8, device="cuda")
+    whole = hip.RowTable(gpu_ctx, bo, bs, lens, offs, bitmap, ck)
+    counters, corrupt, status = whole.decode_verify(d_blob, d_out)
+    whole.close()
+    assert counters == want and (status == 0).all() and len(corrupt) == 0
+    assert torch.equal(d_out[:total], d_src[:total])
+    # 8 ranges
+    d_out.zero_()
+    parts = split_rows(lens, 8)
+    loads = [int(lens[a:b].sum()) for a, b in parts]
+    assert max(loads) < 1.5 * total / 8 and min(b - a for a, b in parts) > 0
+    summed = {k: 0 for k in want}
+    for a, b in parts:
+        lo, hi = int(bo[a]), int(bo[b - 1] + bs[b - 1])
+        rt = hip.RowTable(gpu_ctx, bo, bs, lens, offs, bitmap, ck, row_begin=a, row_end=b)
+        c, corrupt, status = rt.decode_verify(d_blob[lo:hi + 64], d_out, blob_base=lo, blob_cap=hi - lo)   # this rank's blobs only
+        rt.close()
+        assert (status == 0).all() and len(corrupt) == 0 and c["total_chunks"] == b - a
+        for k in summed:
+            summed[k] += c[k]
+    assert summed == want
+    assert torch.equal(d_out[:total], d_src[:total])

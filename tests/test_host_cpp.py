@@ -72,6 +72,61 @@ def test_cpp_index_reader_reads_pyarrow_written_archive(tmp_path, oracle):
     assert md["znippy_format_version"] == "3" and "compression_level" in md and "checksum_group_0" not in md
 
 
+def test_cpp_index_reader_rejects_malformed_containers_with_status_codes(tmp_path, oracle):
+    """A file is untrusted input: wrong manifest schema, lengths that do not fit the file, truncated streams and
+    absurd sizes all come back as status codes from the C ABI (no fault, no C++ exception across the boundary)."""
+    import pyarrow as pa
+    from oracle_backend import OracleBackend
+    from znippy_amd import host
+    from znippy_amd.stream_packer import ArchiveEntry, compress_stream
+    c = compress_stream(tmp_path / "a.znippy", False, backend=OracleBackend())
+    for i in range(5):
+        c.sender().send(ArchiveEntry(f"f{i}.txt", gen.pseudo_text(4000 + i, seed=i)))
+    c.finish()
+    good = (tmp_path / "a.znippy").read_bytes()
+    rows, manifest, _ = host.read_index(tmp_path / "a.znippy")
+    assert len(rows) == 5
+    moff = struct.unpack("<Q", good[-8:])[0]
+
+    def expect_error(blob, name):
+        f = tmp_path / name
+        f.write_bytes(blob)
+        with pytest.raises(host.HostError):
+            host.read_index(f)
+
+    # (1) manifest whose columns have other types (strings where the offsets should be)
+    sink = pa.BufferOutputStream()
+    bad_schema = pa.schema([pa.field(n, pa.utf8(), nullable=False) for n in
+                            ("pkg_type", "repo", "module_name", "index_offset", "index_len", "row_count")])
+    with pa.ipc.new_stream(sink, bad_schema) as w:
+        w.write_batch(pa.record_batch([pa.array(["x"])] * 6, schema=bad_schema))
+    mb = sink.getvalue().to_pybytes()
+    expect_error(good[:moff] + mb + ix.MULTI_INDEX_MAGIC + struct.pack("<Q", moff), "badschema.znippy")
+    # (2) sub-index length far beyond the file, and offset + length wrapping around 2^64
+    for off, ln in ((manifest[0].index_offset, 1 << 60), ((1 << 64) - 8, 64), (len(good) + 5, 1)):
+        m2 = [ix.ManifestEntry(manifest[0].pkg_type, manifest[0].repo, manifest[0].module_name, off, ln, manifest[0].row_count)]
+        mb = host.write_manifest_bytes(m2)
+        expect_error(good[:moff] + mb + ix.MULTI_INDEX_MAGIC + struct.pack("<Q", moff), f"badlen_{ln}.znippy")
+    # (3) manifest offset beyond the file / garbage where the manifest should be / file cut in the middle
+    expect_error(good[:-8] + struct.pack("<Q", len(good) + 100), "badmoff.znippy")
+    expect_error(good[:moff] + b"\x00" * 64 + ix.MULTI_INDEX_MAGIC + struct.pack("<Q", moff), "garbage.znippy")
+    expect_error(good[:moff + 40] + ix.MULTI_INDEX_MAGIC + struct.pack("<Q", moff), "cut.znippy")
+    expect_error(b"tiny", "tiny.znippy")
+    # (4) sub-index bytes damaged: flatbuffer offsets pointing anywhere
+    sub0 = manifest[0].index_offset
+    rng = np.random.default_rng(5)
+    for _ in range(20):
+        b = bytearray(good)
+        for k in rng.integers(sub0 + 8, sub0 + 300, size=6):
+            b[int(k)] = int(rng.integers(0, 256))
+        f = tmp_path / "fuzz.znippy"
+        f.write_bytes(bytes(b))
+        try:
+            host.read_index(f)       # either it still parses or it is an error code; never a crash
+        except host.HostError:
+            pass
+
+
 gpu = pytest.mark.gpu
 
 

@@ -60,6 +60,12 @@ def test_world2_gloo_matches_single_process(tmp_path, oracle):
     archive.write_bytes(bytes(raw))
 
     single = decompress_archive(archive, True, tmp_path / "single", backend=OracleBackend())
+    # the multi-rank run extracts OVER files left by an earlier, longer extraction: no rank may O_TRUNC (the others
+    # write their parts in any order), so the first rank to touch a file sets its final length — stale tails must go
+    for e in entries:
+        stale = tmp_path / "multi" / e.relative_path
+        stale.parent.mkdir(parents=True, exist_ok=True)
+        stale.write_bytes(b"\xEE" * (len(e.data) + 4321))
     port = _free_port()
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE="2")
     procs = []
@@ -107,19 +113,24 @@ def test_world2_gloo_write_side_equals_single_process(tmp_path, oracle):
 
 
 @pytest.mark.gpu
-def test_bench_n2_path_rehearsed_on_one_gpu():
+@pytest.mark.parametrize("scaling", ["weak", "strong"])
+def test_bench_n2_path_rehearsed_on_one_gpu(scaling):
     """bench.py's N>1 code path (rendezvous, per-step counter all-reduce on its own stream, barrier + MAX-over-ranks
-    timing, rank-0 JSON) with two ranks sharing the one card over gloo; the driver runs the real thing over RCCL."""
+    timing, rank-0 JSON) with two ranks sharing the one card over gloo; the driver runs the real thing over RCCL.
+    weak: every rank owns a copy of the workload; strong: ONE archive, the row cursor split into per-rank ranges."""
     import json
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, ZNIPPY_BENCH_BACKEND="gloo")
     p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-                        "--master-addr", "127.0.0.1", "--master-port", "29533", os.path.join(root, "bench.py"),
-                        "--gpus", "2", "--steps", "3", "--warmup", "1", "--workload", "c2small"],
+                        "--master-addr", "127.0.0.1", "--master-port", "29533" if scaling == "weak" else "29534",
+                        os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                        "--workload", "c2small", "--scaling", scaling],
                        capture_output=True, text=True, timeout=600, env=env, cwd=root)
     assert p.returncode == 0, p.stderr[-2000:]
     line = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
-    assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["value"] > 0
+    assert line["n_gpus"] == 2 and line["scaling"] == scaling and line["value"] > 0
     assert line["config"]["parallelism"].endswith("x2") and line["cpu_baseline"] is None
+    assert line["config"]["rows_per_gpu"] == (2000 if scaling == "weak" else 1000)
+    assert "libzstd level-19" in line["config"]["archive"] and line["read_own_archive"]["MBps"] > 0

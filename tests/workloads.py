@@ -1,0 +1,58 @@
+"""BASELINE.json's configurations as device-resident Round batches, shared by bench.py and the
+full-size -m gpu tests.  Inputs are regenerated from the reference's generators (tests/gen.py, tests/gen_gpu.py),
+never stored."""
+import numpy as np
+
+import gen
+import gen_gpu
+
+SLICE = 8 << 20          # stream_packer.rs:L31
+SLOT = 200 << 20         # slot_packer.rs:L30 (BASELINE configs[2] calls these "Magazine slices")
+
+
+def c5_layout():
+    """Synthetic stand-in for the 5 GB / 5k-file artifact repo: 3,500 .xml text files of 1-8 KiB
+    (compress_dir_bench.rs:L45-68), 1,400 .jar of 100 KiB..2 MiB and 100 .jar of 20..69.5 MiB of incompressible
+    bytes (repro_crate.rs:L8-16; store path), stream chunking (8 MiB slices).  -> (xml sizes, jar sizes)"""
+    xml = [1024 + (i % 8) * 1024 for i in range(3500)]
+    jars = [100 * 1024 + (i % 20) * 100 * 1024 for i in range(1400)] + [(20 << 20) + i * (1 << 19) for i in range(100)]
+    return xml, jars
+
+
+def build(name, torch):
+    """-> dict(d_src, lens, skip, name): the Rounds of one configuration over a resident staging buffer."""
+    if name in ("c2", "c2small"):
+        n = 100_000 if name == "c2" else 2_000
+        chunk = np.frombuffer(gen.text(10 * 1024), dtype=np.uint8)
+        d_src = torch.from_numpy(np.tile(chunk, n)).cuda()
+        label = ("100k x 10KiB text chunks (BASELINE configs[1])" if name == "c2"
+                 else "2k x 10KiB text chunks (reduced; NOT the headline config)")
+        return dict(d_src=d_src, lens=np.full(n, 10240, np.uint64), skip=None, name=label)
+    if name == "c3":
+        size = 2 << 30
+        return dict(d_src=gen_gpu.text(size), lens=np.full(size // SLICE, SLICE, np.uint64), skip=None,
+                    name="single 2 GiB text file, 256 x 8 MiB slices (BASELINE configs[2] at the reference's slice size)")
+    if name == "c3slot":
+        size = 2 << 30
+        lens = np.array([SLOT] * (size // SLOT) + ([size % SLOT] if size % SLOT else []), dtype=np.uint64)
+        return dict(d_src=gen_gpu.text(size), lens=lens, skip=None,
+                    name="single 2 GiB text file, 11 slices of <= 200 MiB (BASELINE configs[2] as worded there)")
+    if name == "c5":
+        xml, jars = c5_layout()
+        lens, skip = list(xml), [0] * len(xml)
+        for j in jars:
+            for o in range(0, j, SLICE):
+                lens.append(min(SLICE, j - o))
+                skip.append(1)
+        # jar bytes are consecutive cuts of one LCG stream
+        d_src = torch.cat([gen_gpu.text(sum(xml)), gen_gpu.incompressible(7, sum(jars))])
+        return dict(d_src=d_src, lens=np.array(lens, np.uint64), skip=np.array(skip, np.uint8),
+                    name="mixed artifact repo stand-in: 3,500 xml (1-8 KiB) + 1,500 jars (100 KiB-69.5 MiB, store path), %.2f GB"
+                         % ((sum(xml) + sum(jars)) / 1e9))
+    if name in ("c4store", "c4codec"):
+        size = 500 << 20
+        lens = np.array([SLICE] * (size // SLICE) + ([size % SLICE] if size % SLICE else []), dtype=np.uint64)
+        skip = np.ones(len(lens), np.uint8) if name == "c4store" else None
+        return dict(d_src=gen_gpu.random_lcg(size), lens=lens, skip=skip,
+                    name="500 MiB LCG blob, 8 MiB slices, " + ("store path (random.jar)" if skip is not None else "codec path (random.bin)"))
+    raise SystemExit(f"unknown workload {name}")

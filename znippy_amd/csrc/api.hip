@@ -14,6 +14,7 @@
 #include <unordered_map>
 
 namespace zn {
+int measure_b3_pass_ns(int cus, hipStream_t s, float *ns_per_pass_per_simd);
 size_t decode_lit_scratch_bytes(int grid);
 void set_fused_dbg(unsigned long long *p);
 void set_fused_abl(int v);
@@ -446,6 +447,13 @@ int znippy_last_kernel_times(znippy_ctx *ctx, const char **names, float *ms, int
         (void)hipEventElapsedTime(&ms[i], ctx->ktimes[i].t0, ctx->ktimes[i].t1);
     }
     return n;
+}
+
+int znippy_measure_blake3_pass_ns(znippy_ctx *ctx, float *ns_per_pass_per_simd) {
+    if (!ctx || !ns_per_pass_per_simd) return ZNIPPY_E_INVAL;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return measure_b3_pass_ns(ctx->encode_grid / 8, ctx->stream, ns_per_pass_per_simd);
 }
 
 // ---- frame header (host) ------------------------------------------------------------------------

@@ -209,4 +209,49 @@ void launch_verify(const uint32_t *digests, const uint8_t *checksum, const uint6
                        n_rows, row_begin, reinterpret_cast<unsigned long long *>(counters), corrupt_rows, corrupt_cap);
 }
 
+// ---- measurement hook: the VALU floor of the hash ------------------------------------------------------------
+// Nothing but BLAKE3 compressions (message in registers, no memory traffic), 4 waves per SIMD on every CU: what
+// one 64-lane compress pass costs a SIMD when the integer VALU is the only thing in use.  bench.py multiplies it
+// by the passes a step needs to report the floor the hash sets whatever the memory system does.
+__global__ __launch_bounds__(256) void k_b3_pass_ubench(uint32_t *out, uint32_t seed, int passes) {
+    uint32_t cv[8], m[16];
+#pragma unroll
+    for (int i = 0; i < 8; i++) cv[i] = threadIdx.x * 7 + i + seed;
+#pragma unroll
+    for (int i = 0; i < 16; i++) m[i] = threadIdx.x * 13 + i * seed;
+#pragma unroll 1
+    for (int p = 0; p < passes; p++) {
+        b3::compress(cv, m, (uint32_t)p, 0, 64, 0);
+        m[p & 15] ^= cv[0];
+    }
+    uint32_t x = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) x ^= cv[i];
+    out[blockIdx.x * 256 + threadIdx.x] = x;
+}
+
+int measure_b3_pass_ns(int cus, hipStream_t s, float *ns_per_pass_per_simd) {
+    const int grid = cus * 4, passes = 200;  // 4 blocks of 4 waves per CU = 4 waves per SIMD
+    uint32_t *d = nullptr;
+    if (hipMalloc(&d, (size_t)grid * 256 * 4) != hipSuccess) return -3;
+    hipEvent_t t0, t1;
+    (void)hipEventCreate(&t0);
+    (void)hipEventCreate(&t1);
+    float best = 0.f;
+    for (int rep = 0; rep < 3; rep++) {
+        (void)hipEventRecord(t0, s);
+        hipLaunchKernelGGL(k_b3_pass_ubench, dim3(grid), dim3(256), 0, s, d, (uint32_t)(rep + 1), passes);
+        (void)hipEventRecord(t1, s);
+        (void)hipEventSynchronize(t1);
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, t0, t1);
+        if (rep && (best == 0.f || ms < best)) best = ms;  // first launch: code upload + clocks ramping
+    }
+    (void)hipEventDestroy(t0);
+    (void)hipEventDestroy(t1);
+    (void)hipFree(d);
+    *ns_per_pass_per_simd = best * 1e6f / (float)(passes * 4);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
 }  // namespace zn

@@ -243,7 +243,7 @@ bool read_stream(const uint8_t *p, size_t n, Batch *out, std::map<std::string, s
         if (htype == HDR_SCHEMA) {
             if (!hdr.ok()) return fail("schema header missing");
             uint32_t nf;
-            hdr.vec(1, &nf);
+            hdr.vec(1, &nf, 4);
             if (!have_schema && out->cols.empty()) {
                 for (uint32_t i = 0; i < nf; i++) {
                     const fb::Table f = hdr.vec_table(1, i);
@@ -264,7 +264,7 @@ bool read_stream(const uint8_t *p, size_t n, Batch *out, std::map<std::string, s
             }
             if (metadata) {
                 uint32_t nk;
-                hdr.vec(2, &nk);
+                hdr.vec(2, &nk, 4);
                 for (uint32_t i = 0; i < nk; i++) {
                     const fb::Table kv = hdr.vec_table(2, i);
                     (*metadata)[kv.str(0)] = kv.str(1);
@@ -275,10 +275,10 @@ bool read_stream(const uint8_t *p, size_t n, Batch *out, std::map<std::string, s
             if (!have_schema || !hdr.ok()) return fail("record batch before schema");
             const int64_t rows = hdr.scalar<int64_t>(0, 0);
             uint32_t nn, nb;
-            const uint8_t *nodes = hdr.vec(1, &nn);
-            const uint8_t *bufs = hdr.vec(2, &nb);
+            const uint8_t *nodes = hdr.vec(1, &nn, 16);
+            const uint8_t *bufs = hdr.vec(2, &nb, 16);
             if (hdr.field_off(3)) return fail("compressed record batches are not supported");
-            if (rows < 0 || nn != out->cols.size()) return fail("bad record batch");
+            if (rows < 0 || rows >= (int64_t)1 << 40 || nn != out->cols.size() || (nn && !nodes)) return fail("bad record batch");
             uint32_t bi = 0;
             auto buf = [&](const uint8_t **ptr, int64_t *len) -> bool {
                 if (bi >= nb) return false;
@@ -286,7 +286,7 @@ bool read_stream(const uint8_t *p, size_t n, Batch *out, std::map<std::string, s
                 std::memcpy(&off, bufs + 16 * bi, 8);
                 std::memcpy(len, bufs + 16 * bi + 8, 8);
                 bi++;
-                if (off < 0 || *len < 0 || off + *len > body_len) return false;
+                if (off < 0 || *len < 0 || off > body_len || *len > body_len - off) return false;
                 *ptr = body + off;
                 return true;
             };
@@ -303,7 +303,7 @@ bool read_stream(const uint8_t *p, size_t n, Batch *out, std::map<std::string, s
                     const uint8_t *op, *dp;
                     int64_t ol, dl;
                     if (!buf(&op, &ol) || !buf(&dp, &dl)) return fail("bad utf8 buffers");
-                    if (rows && ol < (rows + 1) * 4) return fail("short offsets buffer");
+                    if (rows && (rows >= (int64_t)1 << 40 || ol < (rows + 1) * 4)) return fail("short offsets buffer");
                     for (int64_t i = 0; i < rows; i++) {
                         int32_t a, b;
                         std::memcpy(&a, op + 4 * i, 4);

@@ -135,39 +135,50 @@ class Builder {
 };
 
 // ---- reading ----
+// The buffer is untrusted (it comes from a file): every dereference is checked against [begin, end).  A field
+// that cannot be read safely reads as absent (default value / empty string / empty vector / !ok() table).
 struct Table {
-    const uint8_t *base = nullptr;  // table position
-    const uint8_t *end = nullptr;   // end of the flatbuffer (bounds)
+    const uint8_t *base = nullptr;   // table position
+    const uint8_t *begin = nullptr;  // the flatbuffer's bounds
+    const uint8_t *end = nullptr;
     bool ok() const { return base != nullptr; }
+    bool in(const uint8_t *p, uint64_t n) const { return p && p >= begin && p <= end && (uint64_t)(end - p) >= n; }
     uint16_t field_off(int field) const {
+        if (!in(base, 4)) return 0;
         int32_t so;
         std::memcpy(&so, base, 4);
-        const uint8_t *vt = base - so;
+        const int64_t vt_pos = (int64_t)(base - begin) - (int64_t)so;
+        if (vt_pos < 0 || vt_pos + 4 > (int64_t)(end - begin)) return 0;
+        const uint8_t *vt = begin + vt_pos;
         uint16_t vt_size;
         std::memcpy(&vt_size, vt, 2);
-        uint16_t idx = (uint16_t)(4 + 2 * field);
+        if (vt_size < 4 || !in(vt, vt_size)) return 0;
+        const uint32_t idx = 4u + 2u * (uint32_t)field;
         if (idx + 2 > vt_size) return 0;
         uint16_t o;
         std::memcpy(&o, vt + idx, 2);
         return o;
     }
     template <class T> T scalar(int field, T def) const {
-        uint16_t o = field_off(field);
-        if (!o) return def;
+        const uint16_t o = field_off(field);
+        if (!o || !in(base + o, sizeof(T))) return def;
         T v;
         std::memcpy(&v, base + o, sizeof(T));
         return v;
     }
+    // target of an offset field: at least 4 readable bytes there (a length prefix or a table's soffset)
     const uint8_t *indirect(int field) const {
-        uint16_t o = field_off(field);
-        if (!o) return nullptr;
+        const uint16_t o = field_off(field);
+        if (!o || !in(base + o, 4)) return nullptr;
         uint32_t u;
         std::memcpy(&u, base + o, 4);
+        if ((uint64_t)(end - (base + o)) < (uint64_t)u + 4) return nullptr;
         return base + o + u;
     }
     Table table(int field) const {
         Table t;
         t.base = indirect(field);
+        t.begin = begin;
         t.end = end;
         return t;
     }
@@ -176,23 +187,31 @@ struct Table {
         if (!p) return std::string();
         uint32_t n;
         std::memcpy(&n, p, 4);
+        if (!in(p + 4, n)) return std::string();
         return std::string((const char *)p + 4, n);
     }
-    // vector: returns element pointer + count
-    const uint8_t *vec(int field, uint32_t *count) const {
+    // vector of `elem`-byte elements: element pointer + count (0 / nullptr if it does not fit the buffer)
+    const uint8_t *vec(int field, uint32_t *count, uint32_t elem) const {
+        *count = 0;
         const uint8_t *p = indirect(field);
-        if (!p) { *count = 0; return nullptr; }
-        std::memcpy(count, p, 4);
+        if (!p) return nullptr;
+        uint32_t n;
+        std::memcpy(&n, p, 4);
+        if (!in(p + 4, (uint64_t)n * elem)) return nullptr;
+        *count = n;
         return p + 4;
     }
     Table vec_table(int field, uint32_t i) const {
         uint32_t n;
-        const uint8_t *e = vec(field, &n);
+        const uint8_t *e = vec(field, &n, 4);
         Table t;
         if (!e || i >= n) return t;
         uint32_t u;
         std::memcpy(&u, e + 4 * i, 4);
-        t.base = e + 4 * i + u;
+        const uint8_t *at = e + 4 * i;
+        if ((uint64_t)(end - at) < (uint64_t)u + 4) return t;
+        t.base = at + u;
+        t.begin = begin;
         t.end = end;
         return t;
     }
@@ -203,8 +222,9 @@ inline Table root(const uint8_t *buf, size_t n) {
     if (n < 8) return t;
     uint32_t u;
     std::memcpy(&u, buf, 4);
-    if (u >= n) return t;
+    if ((uint64_t)u + 4 > n) return t;
     t.base = buf + u;
+    t.begin = buf;
     t.end = buf + n;
     return t;
 }

@@ -67,6 +67,12 @@ class Context:
         n = self.L.znippy_last_kernel_times(self.h, names, ms, 16)
         return [(names[i].decode(), float(ms[i])) for i in range(n)]
 
+    def blake3_pass_ns(self):
+        """Measured VALU floor: ns per 64-lane compress pass per SIMD (compressions only, nothing else running)."""
+        v = C.c_float()
+        self._chk(self.L.znippy_measure_blake3_pass_ns(self.h, C.byref(v)), "znippy_measure_blake3_pass_ns")
+        return float(v.value)
+
     # ---- single-chunk shims (codec.rs semantics, host buffers) ----
     def compress_bound(self, n):
         return int(self.L.znippy_compress_bound(n))
