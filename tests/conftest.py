@@ -29,3 +29,24 @@ def gpu_ctx():
     ctx = hip.Context(0)
     yield ctx
     ctx.close()
+
+
+@pytest.fixture(scope="session")
+def gpu_ctx_roles():
+    """A context whose tables ALWAYS go through the role-split persistent kernel first (ZNIPPY_ROLES_MIN=1; by default
+    only tables of >= 2048 small tiles do), so small test tables exercise it.  Switches are read at context creation."""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from znippy_amd import hip
+    old = os.environ.get("ZNIPPY_ROLES_MIN")
+    os.environ["ZNIPPY_ROLES_MIN"] = "1"
+    try:
+        ctx = hip.Context(0)
+    finally:
+        if old is None:
+            del os.environ["ZNIPPY_ROLES_MIN"]
+        else:
+            os.environ["ZNIPPY_ROLES_MIN"] = old
+    yield ctx
+    ctx.close()

@@ -1,0 +1,137 @@
+"""The role-split persistent kernel of the small-row read path (csrc/fused_small.hip, k_fused_roles: one loader +
+seven hasher waves per workgroup) against the oracle's restated read loop (decompress.rs:L135-190): bytes, digests,
+counters, corrupt rows, per-row status — for tables it takes entirely (every row a whole-leaf row of the recognised
+periodic shape), tables it hands over entirely, and every mixture, tile by tile."""
+import numpy as np
+import pytest
+
+import gen
+from test_gpu_decode import _build_archive, _run_gpu
+
+pytestmark = pytest.mark.gpu
+
+
+def _period(p, n, seed=0):
+    rng = np.random.default_rng(seed * 1000 + p)
+    pat = rng.integers(0, 256, size=p, dtype=np.uint8).tobytes()
+    return (pat * (n // p + 1))[:n]
+
+
+def _check(oracle, ctx, entries, level=19, skip=None, pad=0, mutate=None):
+    arch = _build_archive(oracle, entries, level=level, skip=skip)
+    if mutate:
+        mutate(arch)
+    counters, corrupt, status, out, rt = _run_gpu(ctx, arch, pad_blobs=pad)
+    n = len(entries)
+    bitmap = np.packbits(arch["compressed"].astype(bool), bitorder="little")
+    want_out = np.zeros(int(arch["usize"].sum()), dtype=np.uint8)
+    want, want_corrupt = oracle.decompress_rows(arch["blobs"], arch["blob_offset"], arch["blob_size"], arch["usize"],
+                                                arch["out_off"], bitmap, arch["checksum"], 0, n, out=want_out)
+    assert counters == want
+    assert list(corrupt) == list(want_corrupt)
+    assert np.array_equal(out, want_out)
+    return arch, status, rt
+
+
+@pytest.mark.parametrize("level", [1, 3, 19])
+def test_c2_shape_table_is_taken_whole(gpu_ctx_roles, oracle, level):
+    """5,000 x 10 KiB text rows (libzstd frames at three levels): all tiles are fast tiles."""
+    entries = [gen.text(10240)] * 5000
+    arch, status, rt = _check(oracle, gpu_ctx_roles, entries, level=level, pad=3)
+    assert (status == 0).all()
+    assert np.array_equal(rt.digests(), arch["checksum"])
+    names = [k for k, _ in gpu_ctx_roles.kernel_times()]
+    assert "decode_verify_roles" in names
+
+
+def test_periods_and_row_lengths(gpu_ctx_roles, oracle):
+    """Whole-leaf rows of every leaf count 1..64 with periods from 1 byte to beyond the 960-byte limit of the
+    recognised shape, packed blobs (arbitrary frame alignment)."""
+    entries = []
+    periods = [1, 2, 3, 7, 15, 16, 17, 45, 64, 100, 251, 255, 256, 400, 511, 700, 959, 960, 961, 1500]
+    for k in range(1, 65):
+        p = periods[k % len(periods)]
+        entries.append(_period(p, k * 1024, seed=k))
+    for p in periods:
+        entries.append(_period(p, 10240, seed=99))
+    arch, status, rt = _check(oracle, gpu_ctx_roles, entries, level=19, pad=1)
+    assert (status == 0).all()
+    assert np.array_equal(rt.digests(), arch["checksum"])
+
+
+def test_mixture_of_fast_tiles_and_everything_else(gpu_ctx_roles, gpu_ctx, oracle):
+    """Fast tiles next to tiles the loader must hand over: ragged rows, stored rows, entropy-coded rows, empty rows,
+    tiles of many tiny rows, big rows (slices), broken frames, wrong checksums — same results as the plain context
+    and the oracle loop."""
+    rng = np.random.default_rng(5)
+    entries, skip = [], []
+    for i in range(900):
+        kind = int(rng.integers(0, 10))
+        if kind <= 3:
+            e = gen.text(10240)                                   # fast
+        elif kind == 4:
+            e = gen.text(int(rng.integers(1, 30000)))            # ragged
+        elif kind == 5:
+            e = gen.incompressible(i, int(rng.integers(0, 20000)))
+        elif kind == 6:
+            e = gen.pseudo_text(int(rng.integers(100, 50000)), seed=i)
+        elif kind == 7:
+            e = b""
+        elif kind == 8:
+            e = _period(int(rng.integers(1, 1200)), 1024 * int(rng.integers(1, 20)), seed=i)   # mostly fast
+        else:
+            e = gen.binary(1024)                                  # tiny whole-leaf rows: many per tile
+        entries.append(e)
+        skip.append(1 if kind == 5 and i % 2 else 0)
+    entries.append(gen.text(3 << 20)); skip.append(0)           # big compressed row: block items
+    entries.append(gen.incompressible(3, 1 << 20)); skip.append(1)
+
+    def mutate(arch):
+        ck = arch["checksum"].copy()
+        for r in (0, 5, 17, 400):
+            ck[r, 7] ^= 0x40                                      # wrong expected digests
+        arch["checksum"] = ck
+        blobs = arch["blobs"].copy()
+        for r in (3, 250, 251):                                   # broken frames (compressed rows only)
+            if arch["compressed"][r] and arch["blob_size"][r] > 8:
+                blobs[int(arch["blob_offset"][r]) + 2] ^= 0xFF
+        arch["blobs"] = blobs
+
+    arch, status_r, rt_r = _check(oracle, gpu_ctx_roles, entries, level=19, skip=skip, pad=7, mutate=mutate)
+    arch2, status_p, rt_p = _check(oracle, gpu_ctx, entries, level=19, skip=skip, pad=7, mutate=mutate)
+    assert np.array_equal(status_r, status_p)
+    ok = status_r == 0
+    assert np.array_equal(rt_r.digests()[ok], rt_p.digests()[ok])
+
+
+def test_roles_kernel_respects_host_verdicts_and_out_cap(gpu_ctx_roles, oracle):
+    """Rows ruled out by the host (source outside the blob region, destination too short) inside otherwise fast
+    tiles: the tile goes to the slow list, the row keeps its error code, the rest decodes."""
+    import torch
+    from znippy_amd import _lib, hip
+    n, sz = 120, 10240
+    entries = [gen.text(sz)] * n
+    arch = _build_archive(oracle, entries, level=19)
+    bo = arch["blob_offset"].copy()
+    bo[10] = np.uint64(len(arch["blobs"]) + 999)
+    bo[77] = np.uint64(2**63)
+    d_blobs = torch.from_numpy(arch["blobs"].copy()).cuda()
+    total = n * sz
+    cut = total - 3 * sz + 100                                   # the last three rows do not fit
+    d_out = torch.full((total + 64,), 0xCD, dtype=torch.uint8, device="cuda")
+    bitmap = np.packbits(arch["compressed"].astype(bool), bitorder="little")
+    rt = hip.RowTable(gpu_ctx_roles, bo, arch["blob_size"], arch["usize"], arch["out_off"], bitmap, arch["checksum"])
+    counters, corrupt, status = rt.decode_verify(d_blobs, d_out, out_cap=cut, blob_cap=len(arch["blobs"]))
+    want = np.zeros(n, np.int32)
+    want[[10, 77]] = _lib.E_CORRUPT
+    want[-3:] = _lib.E_DST_SMALL
+    assert np.array_equal(status, want)
+    assert counters["decode_errors"] == 5 and counters["verified_bytes"] == (n - 5) * sz and counters["corrupt_rows"] == 0
+    host = d_out.cpu().numpy()
+    for r in range(n):
+        row = host[r * sz:(r + 1) * sz]
+        if want[r] == 0:
+            assert row.tobytes() == entries[r]
+        else:
+            assert (row == 0xCD).all()
+    assert (host[total:] == 0xCD).all()

@@ -76,7 +76,9 @@ struct znippy_ctx {
         unsigned lds_pad = 0;    // ZNIPPY_LDS_PAD
         bool no_block_items = false, no_fused_blocks = false, ddbg = false, edbg = false, no_fused_store = false,
              nohash = false, no_roles = false;
+        unsigned roles_min = 2048;  // ZNIPPY_ROLES_MIN: small tiles from which the role-split kernel takes the table
     } sw;
+    int cus = 256;
 };
 
 static void read_switches(znippy_ctx *ctx) {
@@ -90,6 +92,7 @@ static void read_switches(znippy_ctx *ctx) {
     ctx->sw.no_fused_store = on("ZNIPPY_NO_FUSED_STORE");
     ctx->sw.nohash = on("ZNIPPY_NOHASH");
     ctx->sw.no_roles = on("ZNIPPY_NO_ROLES");
+    if (const char *e = getenv("ZNIPPY_ROLES_MIN")) ctx->sw.roles_min = (unsigned)atoi(e);
 }
 
 static void *pinned_take(znippy_ctx *ctx, size_t bytes, size_t *cap) {
@@ -284,6 +287,8 @@ struct znippy_rows {
     uint32_t *bt_tile = nullptr, *bt_item = nullptr;
     uint8_t *tile_done = nullptr, *item_done = nullptr;
     uint32_t *todo = nullptr;  // items left to the block decoder (count: third word of the control block)
+    uint32_t n_small_tiles = 0;     // tiles of whole small rows (the fused kernels' work)
+    uint32_t *slow_list = nullptr;  // tiles the role-split kernel leaves to k_fused_small (count: fourth word of the control block)
     DevPlan plan;
 };
 
@@ -399,6 +404,7 @@ int znippy_ctx_create(int device, void *hip_stream, znippy_ctx **out) {
     {
         hipDeviceProp_t p;
         int cus = hipGetDeviceProperties(&p, device) == hipSuccess ? p.multiProcessorCount : 256;
+        ctx->cus = cus;
         ctx->encode_grid = cus * 8;         // 16 KiB hash table per wave
         ctx->encode_grid_small = cus * 16;  // 4 KiB hash table per wave
     }
@@ -507,7 +513,7 @@ void znippy_rows_destroy(znippy_rows *r) {
     void *ptrs[] = {r->blob_off, r->blob_size, r->usize, r->out_off, r->compressed, r->checksum,
                     r->status, r->digests, r->counters, r->corrupt, r->list_a, r->pending,
                     r->cand_row, r->cand_base, r->cand_nblocks, r->item_row, r->item_k, r->item_src, r->row_flag, r->pending2,
-                    r->bt_tile, r->bt_item, r->tile_done, r->item_done, r->todo, r->status_init};
+                    r->bt_tile, r->bt_item, r->tile_done, r->item_done, r->todo, r->status_init, r->slow_list};
     for (void *p : ptrs)
         tfree(r->ctx, p);
     if (r->h_counters) (void)hipHostFree(r->h_counters);
@@ -574,6 +580,11 @@ int znippy_rows_create(znippy_ctx *ctx, const uint64_t *blob_offset, const uint6
     if ((rc = upload_plan(ctx, p, r->plan))) {
         znippy_rows_destroy(r);
         return rc;
+    }
+    for (const Tile &t : p.tiles) r->n_small_tiles += t.n_units != 0;
+    if (r->n_small_tiles && tmalloc(ctx, &r->slow_list, 4 * (size_t)p.tiles.size()) != hipSuccess) {
+        znippy_rows_destroy(r);
+        return ZNIPPY_E_NOMEM;
     }
     // compressed rows above 64 KiB: frames of >= 2 blocks (and < 4 GiB) are tried block by block (each block a work
     // item), the others go straight to the general decoder
@@ -736,9 +747,24 @@ int znippy_decode_verify_rows_async(znippy_ctx *ctx, znippy_rows *r, const void 
         }
         if (f.dbg & (16 | 32 | 64)) set_fused_abl(f.dbg);
         f.lds_pad = ctx->sw.lds_pad;
-        ktime_begin(ctx, "decode_verify_fused");
-        launch_fused_small(f, s);
-        ktime_end(ctx);
+        // Tables with enough small tiles go to the role-split persistent kernel first (loader + hasher waves: tiles whose
+        // rows are all whole-leaf rows of the recognised periodic shape); what it leaves on its list — and small
+        // tables, where a persistent grid only adds start-up latency — is k_fused_small's.
+        const bool roles = !ctx->sw.no_roles && r->n_small_tiles >= ctx->sw.roles_min && r->n_small_tiles > 0 &&
+                           !(f.dbg & (1 | 2 | 4 | 8 | 128));
+        if (roles) {
+            f.cursor = ctx->cursor + 2;
+            f.tile_list = r->slow_list;
+            f.tile_count = r->pending_count + 3;
+            ktime_begin(ctx, "decode_verify_roles");
+            launch_fused_roles(f, ctx->cus, s);
+            ktime_end(ctx);
+        }
+        if (r->n_small_tiles) {
+            ktime_begin(ctx, "decode_verify_fused");
+            launch_fused_small(f, s, roles ? ctx->cus * 5 : 0);
+            ktime_end(ctx);
+        }
     }
     // 2) the two decode paths run side by side: block items (frames of >= 2 blocks, every block a work item) on the
     //    auxiliary stream, the general decoder (single-block big rows + whatever the fused kernel handed over) on the

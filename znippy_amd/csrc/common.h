@@ -105,6 +105,11 @@ struct FusedArgs {
     unsigned long long *dbg_buf;  // diagnostic stamps (ZNIPPY_DBG & 8)
     uint32_t lds_pad;  // extra dynamic LDS per block: caps blocks/CU (in-flight footprint vs Infinity Cache)
     int preset;        // != 0: status[] was initialised with the host's verdicts — a row with status < 0 is left alone
+    // role-split kernel (k_fused_roles): global work cursor over the plan's tiles, and the tiles it leaves to
+    // k_fused_small (any tile that is not all "whole-leaf rows of the recognised periodic shape")
+    uint32_t *cursor;
+    uint32_t *tile_list;         // k_fused_roles: slow list (out); k_fused_small: tiles to process (nullptr = all)
+    uint32_t *tile_count;
 };
 
 // Block items of the common shape (fused_small.hip, k_fused_blocks): the big-slice tiles of block-candidate rows.
@@ -121,7 +126,8 @@ struct FusedBlocksArgs {
 void launch_fused_blocks(const FusedBlocksArgs &a, hipStream_t s);
 
 void launch_hash_tiles(const HashArgs &a, hipStream_t s);
-void launch_fused_small(const FusedArgs &a, hipStream_t s);
+void launch_fused_small(const FusedArgs &a, hipStream_t s, int grid_cap = 0);
+void launch_fused_roles(const FusedArgs &a, int cus, hipStream_t s);
 void init_fused_tables();
 void launch_merge_big(const BigUnit *big, uint32_t n_big, uint32_t *tile_cv, uint32_t *digests, const uint32_t *grp_big,
                       const uint32_t *grp_k, uint32_t n_grp, hipStream_t s);

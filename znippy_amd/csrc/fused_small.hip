@@ -21,6 +21,7 @@
 #include "common.h"
 #include "hash_dev.h"
 
+#include <algorithm>
 #include <cstring>
 
 namespace zn {
@@ -614,7 +615,7 @@ __device__ __forceinline__ FastRow parse_fast_block(const uint8_t *w, uint32_t p
     ok &= (lh & 3) == 0;  // raw literals
     const uint32_t sf = (lh >> 2) & 3;
     const uint32_t regen = (sf & 1) == 0 ? (lh & 0xFF) >> 3 : (sf == 1 ? (lh & 0xFFFF) >> 4 : (lh & 0xFFFFFF) >> 4);
-    const uint32_t lit_at = pos + ((sf & 1) == 0 ? 1u : sf);
+    const uint32_t lit_at = pos + ((sf & 1) == 0 ? 1u : (sf == 1 ? 2u : 3u));  // Size_Format 00/10: 1 byte, 01: 2, 11: 3 (RFC 8878 3.1.1.3.1.1)
     ok &= regen <= WIN;
     uint32_t sp = lit_at + regen;  // sequences section
     ok &= sp + 3 <= bend;
@@ -1030,21 +1031,288 @@ __global__ __launch_bounds__(256, 5) void k_fused_small(FusedArgs a) {
     __shared__ uint32_t s_tab[3][4 * FOLD_UNITS];
     const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const BlockFold bf{s_nodes, s_tab[0], s_tab[1], s_tab[2]};
-    if (lane < FOLD_UNITS) bf.tab_n[w * FOLD_UNITS + lane] = 0;
-    const uint32_t wave = blockIdx.x * 4 + w;
-    if (wave < a.h.n_tiles) fused_tile(a, wave, bf);
-    lds_barrier();
-    // the folding wave changes from block to block, so that over the blocks resident on a CU the extra passes
-    // spread over its four SIMDs
-    if (w != (blockIdx.x * 2654435761u) >> 30) return;
-    FoldQueue<4> fq;
-    fq.n_tab = 4 * FOLD_UNITS;
-    fq.tb_n = bf.tab_n[lane];
-    fq.tb_off = bf.tab_off[lane];
-    fq.tb_out = bf.tab_out[lane];
-    fq.tb_root = 1;
-    if (__ballot(fq.tb_n != 0) == 0ull) return;
-    fq.fold_and_write(s_nodes, a.h);
+    // the work: every tile of the plan, or the tiles k_fused_roles left on its list (count known on the device only:
+    // the grid is capped and strides over it, so an empty list costs a launch of blocks that exit at once)
+    const uint32_t n_work = a.tile_list ? *a.tile_count : a.h.n_tiles;
+    for (uint32_t base = blockIdx.x * 4, it = 0; base < n_work; base += gridDim.x * 4, it++) {
+        if (lane < FOLD_UNITS) bf.tab_n[w * FOLD_UNITS + lane] = 0;
+        const uint32_t idx = base + w;
+        if (idx < n_work) fused_tile(a, a.tile_list ? a.tile_list[idx] : idx, bf);
+        lds_barrier();
+        // the folding wave changes from block to block, so that over the blocks resident on a CU the extra passes
+        // spread over its four SIMDs
+        if (w == ((blockIdx.x + it) * 2654435761u) >> 30) {
+            FoldQueue<4> fq;
+            fq.n_tab = 4 * FOLD_UNITS;
+            fq.tb_n = bf.tab_n[lane];
+            fq.tb_off = bf.tab_off[lane];
+            fq.tb_out = bf.tab_out[lane];
+            fq.tb_root = 1;
+            if (__ballot(fq.tb_n != 0) != 0ull) fq.fold_and_write(s_nodes, a.h);
+        }
+        if (base + gridDim.x * 4 < n_work) lds_barrier();  // the node array and the tables are reused by the next round
+    }
+}
+
+// ---- role-split persistent kernel ---------------------------------------------------------------------------
+// Tiles whose rows are ALL whole-leaf rows of the recognised periodic shape (every BASELINE text row) are taken by
+// persistent workgroups of one LOADER wave and seven HASHER waves:
+//   loader : pulls four tiles at a time from a global cursor, loads their index columns and frames (lane = row),
+//            recognises the rows lane-parallel (parse_fast), extends each window by 64 period bytes, WRITES the rows
+//            — 1 KiB of contiguous output per store instruction, read straight from the window — and publishes the
+//            four windows as slots of a ring in LDS.  It owns every global load of the workgroup.
+//   hasher : takes the next ready slot, hashes its <= 64 leaves straight from the window (an all-LDS loop: no vector
+//            memory instruction at all), leaves the chaining values in the slot, and the wave that completes a group of
+//            four slots folds their parent trees together and writes the digests.
+// What this removes from k_fused_small's timeline: every wave there runs prologue -> parse -> hash -> fold in
+// lockstep with all the others (equal work per tile keeps the generations aligned), so the memory latency of the
+// prologue and the fold barrier are exposed once per generation; and the hash lanes pay for the row stores (64
+// different cache lines per store instruction).  Here the hashers never wait on vmcnt, the loader runs ahead by up to
+// 16 slots, and the stores are whole lines.  Any other tile goes to the slow list and k_fused_small afterwards.
+constexpr uint32_t R_SLOTS = 16, R_GROUP = 4, R_WAVES = 8;
+constexpr uint32_t R_SLOT_BYTES = WROWS * WSTRIDE;        // the windows; afterwards the tile's leaf CVs (first 2 KiB)
+constexpr uint32_t R_SLOT_NODES = R_SLOT_BYTES / 32;
+static_assert(R_SLOT_BYTES % 32 == 0 && R_SLOT_BYTES >= 64 * 32, "a slot must hold 64 chaining values, node-aligned");
+
+struct RolesShared {
+    uint8_t slots[R_SLOTS][R_SLOT_BYTES];
+    uint64_t oo[R_SLOTS][WROWS];
+    uint32_t len[R_SLOTS][WROWS];
+    uint32_t tn[R_SLOTS][WROWS], toff[R_SLOTS][WROWS];  // fold table of the slot's units (written by its hasher)
+    uint16_t dy[R_SLOTS][WROWS], dB[R_SLOTS][WROWS], doff[R_SLOTS][WROWS];
+    uint32_t first[R_SLOTS], nunits[R_SLOTS], nleaves[R_SLOTS];
+    uint32_t ready, take, finished;      // slots published / claimed so far; the loader is done
+    uint32_t cnt[R_SLOTS / R_GROUP];     // hashed slots of the group's current use
+    uint32_t gen[R_SLOTS / R_GROUP];     // completed uses of the group (the loader refills it when gen == its next use)
+};
+
+__device__ __forceinline__ uint32_t lds_ld(const uint32_t *p) { return *(const volatile uint32_t *)p; }
+__device__ __forceinline__ void lds_st(uint32_t *p, uint32_t v) { *(volatile uint32_t *)p = v; }
+__device__ __forceinline__ void lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
+// One recognised row from its window, the whole wave: out[i] = Y[i] for i < L0 + 64 (the literals + 64 bytes of the
+// period), Y[B + (i - B) mod off] after that, B = L0 - off — any 16 output bytes are 16 contiguous window bytes.
+// Aligned 16-byte stores, 1 KiB per instruction, four in flight; head and tail bytes lane-parallel.
+__device__ __forceinline__ void emit_periodic_row(const uint8_t *Y, uint32_t L0, uint32_t off, uint8_t *out, uint32_t osize, uint32_t lane) {
+    const uint32_t B = L0 - off, lim = L0 + 64;
+    const float inv = 1.0f / (float)off;
+    const uint32_t head = (uint32_t)((16 - ((uintptr_t)out & 15)) & 15);
+    const uint32_t body16 = (osize - head) >> 4;
+    const uint32_t step = smod(1024, off), rb = smod(B, off);
+    if (lane < head) out[lane] = Y[lane];
+    const uint32_t tail = (osize - head) & 15, p = head + 16 * body16 + lane;
+    if (lane < tail) {
+        uint32_t rt = lmod(p, off, inv) + off - rb;
+        if (rt >= off) rt -= off;
+        out[p] = p < lim ? Y[p] : Y[B + rt];
+    }
+    uint32_t x = head + 16 * lane;
+    uint32_t r = lmod(x, off, inv) + off - rb;  // (x - B) mod off
+    if (r >= off) r -= off;
+    for (uint32_t i0 = 0; i0 < body16; i0 += 256) {
+        const uint32_t i = i0 + lane;
+        uint4 v0 = make_uint4(0, 0, 0, 0), v1 = v0, v2 = v0, v3 = v0;
+        const uint32_t r0 = r;
+        uint32_t r1 = r0 + step; if (r1 >= off) r1 -= off;
+        uint32_t r2 = r1 + step; if (r2 >= off) r2 -= off;
+        uint32_t r3 = r2 + step; if (r3 >= off) r3 -= off;
+        r = r3 + step; if (r >= off) r -= off;
+        const bool p0 = i < body16, p1 = i + 64 < body16, p2 = i + 128 < body16, p3 = i + 192 < body16;
+        if (p0) v0 = lds16(x + 16 <= lim ? Y + x : Y + B + r0);
+        if (p1) v1 = lds16(x + 1040 <= lim ? Y + x + 1024 : Y + B + r1);
+        if (p2) v2 = lds16(x + 2064 <= lim ? Y + x + 2048 : Y + B + r2);
+        if (p3) v3 = lds16(x + 3088 <= lim ? Y + x + 3072 : Y + B + r3);
+        uint8_t *d = out + x;
+        if (p0) *reinterpret_cast<uint4 *>(d) = v0;
+        if (p1) *reinterpret_cast<uint4 *>(d + 1024) = v1;
+        if (p2) *reinterpret_cast<uint4 *>(d + 2048) = v2;
+        if (p3) *reinterpret_cast<uint4 *>(d + 3072) = v3;
+        x += 4096;
+    }
+}
+
+__device__ __forceinline__ void roles_loader(const FusedArgs &a, RolesShared &S) {
+    const uint32_t lane = threadIdx.x & 63, j = lane >> 4, u = lane & 15;  // 16 lanes per tile, lane u = row u of tile j
+    FastTabs T;
+    {
+        const DTab eL = c_dll[lane], eM = c_dml[lane], eO = c_dof[lane & 31];
+        T.ll = eL.base | (uint32_t)eL.addbits << 24;
+        T.ml = eM.base | (uint32_t)eM.addbits << 24;
+        T.of = eO.addbits;
+        T.lls = lane < 36 ? c_llb[lane] | (uint32_t)c_lla[lane] << 24 : 0u;
+        T.mls = lane < 53 ? c_mlb[lane] | (uint32_t)c_mla[lane] << 24 : 0u;
+    }
+    for (uint32_t iter = 0;; iter++) {
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(a.cursor, R_GROUP);
+        base = uni(base);
+        if (base >= a.h.n_tiles) break;
+        const uint32_t grp = iter & (R_SLOTS / R_GROUP - 1), use = iter / (R_SLOTS / R_GROUP);
+        // ---- the four tiles' index columns: issued before the wait for the group, they travel meanwhile ----
+        const uint32_t ti = base + j;
+        Tile t{0, 0, 0, 0, 0, 0};
+        if (ti < a.h.n_tiles) t = a.h.tiles[ti];
+        const bool small = t.n_units >= 1;                // (a slice of a big row otherwise: not this kernel's)
+        const bool cand = small && t.n_units <= WROWS;    // every row gets a window
+        const bool rowv = cand && u < t.n_units;
+        uint32_t c_sel = 0, c_bs = 0;
+        uint64_t c_len = 0, c_src = 0, c_oo = 0;
+        int32_t c_st = 0;
+        if (rowv) {
+            const uint32_t row = t.first_unit + u;
+            if (a.preset) c_st = a.status[row];
+            c_sel = a.h.sel[row];
+            c_len = a.h.len[row];
+            c_src = a.h.offA[row] - a.h.baseA;
+            c_oo = a.h.offB[row];
+            const uint64_t bs = a.blob_size[row];
+            c_bs = bs > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)bs;
+        }
+        const bool want = rowv && c_sel && c_st == 0 && c_len != 0 && (c_len & 1023) == 0 && c_len <= 0x10000 &&
+                          c_oo + c_len <= a.out_cap && c_bs >= 12 && c_bs <= WIN;
+        // ---- the frames, lane = row: 16 bytes per step into the row's window (the last partial piece bytewise: the
+        // blob region promises nothing behind its last byte) ----
+        while (lds_ld(&S.gen[grp]) != use) __builtin_amdgcn_s_sleep(4);  // the group's previous use has been folded
+        const uint32_t slot = grp * R_GROUP + j;
+        uint8_t *const win = S.slots[slot] + (u < WROWS ? u : 0) * WSTRIDE;
+        const uint8_t *const src = a.h.srcA + c_src;
+        const uint32_t nb = want ? c_bs : 0, full = nb >> 4, tail = nb & 15;
+        for (uint32_t i = 0; __ballot(i < full) != 0ull; i++)
+            if (i < full) {
+                const uint4 v = ld16(src + 16 * i);
+                *reinterpret_cast<uint4 *>(win + 16 * i) = v;
+            }
+        if (tail) {
+            uint32_t w4[4] = {0, 0, 0, 0};
+            for (uint32_t k = 0; k < tail; k++) w4[k >> 2] |= (uint32_t)src[16 * full + k] << (8 * (k & 3));
+            *reinterpret_cast<uint4 *>(win + 16 * full) = make_uint4(w4[0], w4[1], w4[2], w4[3]);
+        }
+        const FastRow fr = parse_fast(win, c_bs, c_len, want, T);
+        const uint64_t badm = __ballot(rowv && !fr.ok);
+        const bool fast = cand && ((badm >> (16 * j)) & 0xFFFFull) == 0;
+        if (small && !fast && u == 0) a.tile_list[atomicAdd(a.tile_count, 1u)] = ti;  // k_fused_small takes it
+        if (u == 0) {
+            S.first[slot] = t.first_unit;
+            S.nunits[slot] = fast ? t.n_units : 0u;
+            S.nleaves[slot] = t.n_leaves;
+        }
+        const bool mine = fast && rowv;
+        if (mine) {
+            S.len[slot][u] = (uint32_t)c_len;
+            S.oo[slot][u] = c_oo;
+            S.dy[slot][u] = (uint16_t)(u * WSTRIDE + fr.lit_at);
+            S.dB[slot][u] = (uint16_t)(fr.L0 - fr.off);
+            S.doff[slot][u] = (uint16_t)fr.off;
+            // 64 more bytes of the period behind the literals: y[L0 + i] = y[L0 + i - off], in order
+            uint8_t *y = win + fr.lit_at + fr.L0;
+            if (fr.off >= 16) {
+#pragma unroll
+                for (uint32_t i = 0; i < 64; i += 16) {
+                    uint4 v;
+                    __builtin_memcpy(&v, y + i - fr.off, 16);
+                    __builtin_memcpy(y + i, &v, 16);
+                }
+            } else {
+                for (uint32_t i = 0; i < 64; i++) y[i] = y[(int32_t)i - (int32_t)fr.off];
+            }
+        }
+        lds_fence();
+        // ---- the rows themselves: written here, whole lines, while the hashers work on earlier slots ----
+        if (!(a.dbg & 16)) {
+            for (uint64_t m = __ballot(mine); m; m &= m - 1) {
+                const uint32_t l = (uint32_t)__builtin_ctzll(m);
+                const uint32_t sl = grp * R_GROUP + (l >> 4);
+                const uint32_t lit_at = __builtin_amdgcn_readlane(fr.lit_at, l), L0 = __builtin_amdgcn_readlane(fr.L0, l),
+                               off = __builtin_amdgcn_readlane(fr.off, l), osize = __builtin_amdgcn_readlane((uint32_t)c_len, l);
+                const uint64_t oo = ((uint64_t)__builtin_amdgcn_readlane((uint32_t)(c_oo >> 32), l) << 32) |
+                                    __builtin_amdgcn_readlane((uint32_t)c_oo, l);
+                emit_periodic_row(S.slots[sl] + (l & 15) * WSTRIDE + lit_at, L0, off, a.h.srcB + oo, osize, lane);
+            }
+        }
+        lds_fence();
+        if (lane == 0) lds_st(&S.ready, (iter + 1) * R_GROUP);
+    }
+    lds_fence();
+    if (lane == 0) lds_st(&S.finished, 1u);
+}
+
+__device__ __forceinline__ void roles_hasher(const FusedArgs &a, RolesShared &S) {
+    const uint32_t lane = threadIdx.x & 63;
+    HashArgs h = a.h;
+    h.pass = PASS_ALL;
+    for (;;) {
+        uint32_t take = 0;
+        if (lane == 0) take = atomicAdd(&S.take, 1u);
+        take = uni(take);
+        for (;;) {
+            if (lds_ld(&S.ready) > take) break;
+            if (lds_ld(&S.finished)) {
+                if (lds_ld(&S.ready) > take) break;
+                return;  // nothing more will be published
+            }
+            __builtin_amdgcn_s_sleep(2);
+        }
+        asm volatile("" ::: "memory");
+        const uint32_t slot = take & (R_SLOTS - 1), grp = slot / R_GROUP;
+        const uint32_t nu = lds_ld(&S.nunits[slot]);
+        if (nu) {
+            const Tile t{lds_ld(&S.first[slot]), nu, 0, lds_ld(&S.nleaves[slot]), 0, 0};
+            const uint32_t lu = lane < nu ? lane : 0;
+            LdsSrc ls{S.slots[slot], S.dy[slot], S.dB[slot], S.doff[slot], WROWS, nullptr,
+                      lane < nu ? (uint64_t)S.len[slot][lu] : 0ull, 0ull, S.oo[slot][lu], 1u, 0u, 0ull};
+            LeafOut lo;
+            hash_tile_leaves<false, true>(h, t, &ls, lo);
+            // the window is dead (every lane has read its last block): the leaf CVs take its place
+            if (lo.active) {
+                uint4 *d = reinterpret_cast<uint4 *>(S.slots[slot] + lane * 32);
+                d[0] = make_uint4(lo.cv[0], lo.cv[1], lo.cv[2], lo.cv[3]);
+                d[1] = make_uint4(lo.cv[4], lo.cv[5], lo.cv[6], lo.cv[7]);
+            }
+            const uint32_t act = __shfl(lo.active ? 1u : 0u, lo.u_head & 63);
+            if (lane < WROWS) {
+                S.tn[slot][lane] = (lane < nu && act) ? lo.u_cnt : 0u;
+                S.toff[slot][lane] = (slot % R_GROUP) * R_SLOT_NODES + lo.u_head;
+            }
+        } else if (lane < WROWS) {
+            S.tn[slot][lane] = 0u;
+        }
+        lds_fence();
+        uint32_t old = 0;
+        if (lane == 0) old = atomicAdd(&S.cnt[grp], 1u);
+        old = uni(old);
+        if (old == R_GROUP - 1) {
+            // this wave hashed the group's last slot: fold the four tiles' parent trees together, write the digests
+            asm volatile("" ::: "memory");
+            const uint32_t jj = lane >> 4, uu = lane & 15, sl = grp * R_GROUP + jj;
+            FoldQueue<4> fq;
+            fq.n_tab = 64;
+            fq.tb_n = uu < WROWS ? S.tn[sl][uu] : 0u;
+            fq.tb_off = uu < WROWS ? S.toff[sl][uu] : 0u;
+            fq.tb_out = S.first[sl] + uu;
+            fq.tb_root = 1;
+            if (__ballot(fq.tb_n != 0) != 0ull) fq.fold_and_write(reinterpret_cast<uint32_t *>(S.slots[grp * R_GROUP]), h);
+            lds_fence();
+            if (lane == 0) {
+                lds_st(&S.cnt[grp], 0u);
+                lds_st(&S.gen[grp], lds_ld(&S.gen[grp]) + 1u);
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(R_WAVES * 64, 2) void k_fused_roles(FusedArgs a) {
+    __shared__ __attribute__((aligned(16))) RolesShared S;
+    if (threadIdx.x == 0) { S.ready = 0; S.take = 0; S.finished = 0; }
+    if (threadIdx.x < R_SLOTS / R_GROUP) { S.cnt[threadIdx.x] = 0; S.gen[threadIdx.x] = 0; }
+    __syncthreads();
+    if (threadIdx.x < 64) roles_loader(a, S);
+    else roles_hasher(a, S);
+}
+
+void launch_fused_roles(const FusedArgs &a, int cus, hipStream_t s) {
+    if (!a.h.n_tiles) return;
+    const uint32_t want = (a.h.n_tiles + R_GROUP - 1) / R_GROUP;  // one group per workgroup at least
+    hipLaunchKernelGGL(k_fused_roles, dim3(std::min<uint32_t>((uint32_t)cus * 2, want)), dim3(R_WAVES * 64), 0, s, a);
 }
 
 // ---- big rows: block items of the common shape --------------------------------------------------------
@@ -1158,9 +1426,11 @@ void launch_fused_blocks(const FusedBlocksArgs &a, hipStream_t s) {
 void set_fused_dbg(unsigned long long *) {}
 void set_fused_abl(int v) { (void)hipMemcpyToSymbol(HIP_SYMBOL(g_abl), &v, sizeof v); }
 
-void launch_fused_small(const FusedArgs &a, hipStream_t s) {
+void launch_fused_small(const FusedArgs &a, hipStream_t s, int grid_cap) {
     if (!a.h.n_tiles) return;
-    hipLaunchKernelGGL(k_fused_small, dim3((a.h.n_tiles + 3) / 4), dim3(256), a.lds_pad, s, a);
+    uint32_t grid = (a.h.n_tiles + 3) / 4;
+    if (grid_cap > 0 && grid > (uint32_t)grid_cap) grid = (uint32_t)grid_cap;
+    hipLaunchKernelGGL(k_fused_small, dim3(grid), dim3(256), a.lds_pad, s, a);
 }
 
 }  // namespace zn
