@@ -174,8 +174,12 @@ int znippy_hash_rounds(znippy_ctx *ctx, znippy_rounds *rounds, const void *d_src
  * events on the context's stream.  names/ms: up to cap entries; returns the count. */
 int znippy_last_kernel_times(znippy_ctx *ctx, const char **names, float *ms, int cap);
 /* The hash's VALU floor, measured: nanoseconds one 64-lane BLAKE3 compress pass costs a SIMD when nothing else runs
- * (a kernel of compressions only, 4 waves per SIMD on every CU).  bench.py prices the read step's passes with it. */
-int znippy_measure_blake3_pass_ns(znippy_ctx *ctx, float *ns_per_pass_per_simd);
+ * (a kernel of compressions only, 4 waves per SIMD on every CU), and the shader clock that kernel held (may be NULL).
+ * bench.py prices the read step's passes with it. */
+int znippy_measure_blake3_pass_ns(znippy_ctx *ctx, float *ns_per_pass_per_simd, float *shader_ghz);
+/* Shader clock (GHz) one wave of the read side's small-row kernel saw during the last run of a context created with
+ * ZNIPPY_DBG bit 32768 set: its life in shader cycles / in 100 MHz ticks.  0 if nothing was recorded. */
+int znippy_last_shader_ghz(znippy_ctx *ctx, float *ghz);
 
 #ifdef __cplusplus
 }

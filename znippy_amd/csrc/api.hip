@@ -14,7 +14,7 @@
 #include <unordered_map>
 
 namespace zn {
-int measure_b3_pass_ns(int cus, hipStream_t s, float *ns_per_pass_per_simd);
+int measure_b3_pass_ns(int cus, hipStream_t s, float *ns_per_pass_per_simd, float *ghz);
 size_t decode_lit_scratch_bytes(int grid);
 void set_fused_dbg(unsigned long long *p);
 void set_fused_abl(int v);
@@ -76,9 +76,13 @@ struct znippy_ctx {
         unsigned lds_pad = 0;    // ZNIPPY_LDS_PAD
         bool no_block_items = false, no_fused_blocks = false, ddbg = false, edbg = false, no_fused_store = false,
              nohash = false, no_roles = false;
-        unsigned roles_min = 2048;  // ZNIPPY_ROLES_MIN: small tiles from which the role-split kernel takes the table
+        // ZNIPPY_ROLES_MIN: small tiles from which the EXPERIMENTAL role-split kernel takes the table.  Off by default
+        // (0 = never): it is no faster than k_fused_small (profiles/README.md, round 2) and once its slot ring wraps it
+        // still loses rows to a race that was not found — it must not run in production.
+        unsigned roles_min = 0;
     } sw;
     int cus = 256;
+    unsigned long long *clk_buf = nullptr;  // diagnostic (ZNIPPY_DBG & 32768): shader cycles / 100 MHz ticks of one wave
 };
 
 static void read_switches(znippy_ctx *ctx) {
@@ -455,11 +459,24 @@ int znippy_last_kernel_times(znippy_ctx *ctx, const char **names, float *ms, int
     return n;
 }
 
-int znippy_measure_blake3_pass_ns(znippy_ctx *ctx, float *ns_per_pass_per_simd) {
+int znippy_measure_blake3_pass_ns(znippy_ctx *ctx, float *ns_per_pass_per_simd, float *shader_ghz) {
     if (!ctx || !ns_per_pass_per_simd) return ZNIPPY_E_INVAL;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    return measure_b3_pass_ns(ctx->encode_grid / 8, ctx->stream, ns_per_pass_per_simd);
+    return measure_b3_pass_ns(ctx->cus, ctx->stream, ns_per_pass_per_simd, shader_ghz);
+}
+
+// Shader clock a read-side kernel held during the last run with ZNIPPY_DBG bit 32768 set: one wave's life in shader
+// cycles / in 100 MHz ticks (MI355X_MICROARCH.md, DVFS give-back (6)).  0 if nothing was recorded.
+int znippy_last_shader_ghz(znippy_ctx *ctx, float *ghz) {
+    if (!ctx || !ghz) return ZNIPPY_E_INVAL;
+    *ghz = 0.f;
+    if (!ctx->clk_buf) return ZNIPPY_OK;
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    unsigned long long h[2] = {0, 0};
+    HIPCHK(ctx, hipMemcpy(h, ctx->clk_buf, 16, hipMemcpyDeviceToHost));
+    if (h[1]) *ghz = (float)((double)h[0] / (double)h[1] * 0.1);
+    return ZNIPPY_OK;
 }
 
 // ---- frame header (host) ------------------------------------------------------------------------
@@ -745,12 +762,24 @@ int znippy_decode_verify_rows_async(znippy_ctx *ctx, znippy_rows *r, const void 
             (void)hipMemset(dbg, 0, 64);
             f.dbg_buf = dbg;
         }
+        if (f.dbg & (32768 | 512)) {
+            if (!ctx->clk_buf) { (void)hipMalloc(&ctx->clk_buf, 64); (void)hipMemset(ctx->clk_buf, 0, 64); }
+            if (f.dbg & 512) {  // diagnostic: protocol counters of the role-split kernel's previous launch
+                unsigned long long h8[8];
+                (void)hipStreamSynchronize(s);
+                (void)hipMemcpy(h8, ctx->clk_buf, 64, hipMemcpyDeviceToHost);
+                if (h8[2]) fprintf(stderr, "[znippy roles] slots %llu | complete-at-start %llu gen-mismatch-at-start %llu | over-arrivals %llu gen-mismatch-at-arrival %llu | folds %llu\n",
+                                   h8[2], h8[3], h8[4], h8[5], h8[6], h8[7]);
+                (void)hipMemset(ctx->clk_buf, 0, 64);
+            }
+            f.dbg_buf = ctx->clk_buf;
+        }
         if (f.dbg & (16 | 32 | 64)) set_fused_abl(f.dbg);
         f.lds_pad = ctx->sw.lds_pad;
         // Tables with enough small tiles go to the role-split persistent kernel first (loader + hasher waves: tiles whose
         // rows are all whole-leaf rows of the recognised periodic shape); what it leaves on its list — and small
         // tables, where a persistent grid only adds start-up latency — is k_fused_small's.
-        const bool roles = !ctx->sw.no_roles && r->n_small_tiles >= ctx->sw.roles_min && r->n_small_tiles > 0 &&
+        const bool roles = !ctx->sw.no_roles && ctx->sw.roles_min != 0 && r->n_small_tiles >= ctx->sw.roles_min && r->n_small_tiles > 0 &&
                            !(f.dbg & (1 | 2 | 4 | 8 | 128));
         if (roles) {
             f.cursor = ctx->cursor + 2;

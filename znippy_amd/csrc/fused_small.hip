@@ -146,6 +146,15 @@ __device__ __forceinline__ uint32_t smod(uint32_t a, uint32_t b) {
     return a;
 }
 
+// x mod d for per-lane x < 2^22 and wave-uniform d >= 1 (inv = 1/d): float quotient, off by at most one
+__device__ __forceinline__ uint32_t lmod(uint32_t x, uint32_t d, float inv) {
+    const uint32_t q = (uint32_t)((float)x * inv);
+    int32_t r = (int32_t)(x - q * d);
+    if (r < 0) r += (int32_t)d;
+    else if ((uint32_t)r >= d) r -= (int32_t)d;
+    return (uint32_t)r;
+}
+
 // The frame as the wave sees it: bytes [0, min(n,WIN)) staged in LDS (`wl`, zero padded) and, for
 // scalar parsing, a 256-byte register window (lane l = dword l of [wbase, wbase+256)).
 struct FrameWin {
@@ -274,18 +283,38 @@ __device__ __forceinline__ void fwave_expand(uint8_t *dst, const uint8_t *pg, co
         }
         if (lane < (off & 15)) E[full + lane] = pg[full + lane];
     }
-    // 2) doubling
+    // 2) the rest of E.  No 16-byte store to an odd LDS address anywhere (such stores are not safe next to other
+    // waves' LDS traffic — measured in the role-split kernel, see emit_periodic_row): first 64 more bytes of the period
+    // one byte per lane, then every further 16-byte piece is read at its phase inside [0, off + 16) and stored ALIGNED;
+    // the pieces do not depend on one another, so they go 1 KiB per round.
     const uint32_t need = off + (ml < 1024 ? ml : 1024);
-    uint32_t w = off;
-    while (w < need) {
-        const uint32_t c = w < need - w ? w : need - w;
-        for (uint32_t i = lane * 16; i < c; i += 1024) {
-            uint4 v;
-            __builtin_memcpy(&v, E + i, 16);
-            __builtin_memcpy(E + w + i, &v, 16);
+#ifdef ZN_OLD_EXPAND
+    {
+        uint32_t w = off;
+        while (w < need) {
+            const uint32_t c = w < need - w ? w : need - w;
+            for (uint32_t i = lane * 16; i < c; i += 1024) {
+                uint4 v;
+                __builtin_memcpy(&v, E + i, 16);
+                __builtin_memcpy(E + w + i, &v, 16);
+            }
+            w += c;
         }
-        w += c;
     }
+#else
+    const float inv = 1.0f / (float)off;
+    E[off + lane] = E[lmod(lane, off, inv)];
+    for (uint32_t c = ((off + 64 + 15) >> 4) + lane; 16 * c < need; c += 64) {
+        uint4 v;
+        __builtin_memcpy(&v, E + lmod(16 * c, off, inv), 16);
+        *reinterpret_cast<uint4 *>(E + 16 * c) = v;
+    }
+    // (bytes [off + 64, 16 * ceil((off + 64) / 16)) belong to no piece: fill them bytewise)
+    {
+        const uint32_t lo = off + 64, hi = ((off + 64 + 15) >> 4) << 4;
+        if (lo + lane < hi && lo + lane < need) E[lo + lane] = E[lmod(lo + lane, off, inv)];
+    }
+#endif
     STAMP_END(4);
     if (g_abl & 16) return;  // ablation: no stream-out
     // 3) stream out
@@ -687,15 +716,6 @@ __device__ __forceinline__ FastRow parse_fast(const uint8_t *w, uint32_t n, uint
     return parse_fast_block<true>(w, pos, n, usize, ok, T);
 }
 
-// x mod d for per-lane x < 2^22 and wave-uniform d >= 1 (inv = 1/d): float quotient, off by at most one
-__device__ __forceinline__ uint32_t lmod(uint32_t x, uint32_t d, float inv) {
-    const uint32_t q = (uint32_t)((float)x * inv);
-    int32_t r = (int32_t)(x - q * d);
-    if (r < 0) r += (int32_t)d;
-    else if ((uint32_t)r >= d) r -= (int32_t)d;
-    return (uint32_t)r;
-}
-
 // Writing a recognised row from its window: out[i] = Y[i] for i < L0, Y[B + (i - B) mod off] after that
 // (B = L0 - off), with Y = the row's literals in the staged window, extended by 64 bytes of the period, so that
 // any 16 output bytes are 16 CONTIGUOUS bytes of Y — at i itself (i + 16 <= L0 + 64) or inside the period copy at
@@ -1030,6 +1050,8 @@ __global__ __launch_bounds__(256, 5) void k_fused_small(FusedArgs a) {
     __shared__ __attribute__((aligned(16))) uint32_t s_nodes[4 * 64 * 8];
     __shared__ uint32_t s_tab[3][4 * FOLD_UNITS];
     const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const bool clk = (a.dbg & 32768) && a.dbg_buf && blockIdx.x == 2000 && threadIdx.x == 0;
+    const unsigned long long c0 = clk ? __builtin_amdgcn_s_memtime() : 0, r0 = clk ? __builtin_amdgcn_s_memrealtime() : 0;
     const BlockFold bf{s_nodes, s_tab[0], s_tab[1], s_tab[2]};
     // the work: every tile of the plan, or the tiles k_fused_roles left on its list (count known on the device only:
     // the grid is capped and strides over it, so an empty list costs a launch of blocks that exit at once)
@@ -1048,66 +1070,105 @@ __global__ __launch_bounds__(256, 5) void k_fused_small(FusedArgs a) {
             fq.tb_off = bf.tab_off[lane];
             fq.tb_out = bf.tab_out[lane];
             fq.tb_root = 1;
-            if (__ballot(fq.tb_n != 0) != 0ull) fq.fold_and_write(s_nodes, a.h);
+            if (__ballot(fq.tb_n != 0) != 0ull) {
+                FoldQueue<4> fd = fq.dense16();
+                uint32_t U = 0;
+                const uint32_t n = (a.dbg & 262144) ? 0u : fd.uniform(&U);
+                if (n) fd.fold_uniform_and_write(s_nodes, a.h, n, U);  // every row of the four tiles has the same length
+                else fq.fold_and_write(s_nodes, a.h);
+            }
         }
         if (base + gridDim.x * 4 < n_work) lds_barrier();  // the node array and the tables are reused by the next round
     }
+    if (clk) { a.dbg_buf[0] = __builtin_amdgcn_s_memtime() - c0; a.dbg_buf[1] = __builtin_amdgcn_s_memrealtime() - r0; }
 }
 
 // ---- role-split persistent kernel ---------------------------------------------------------------------------
 // Tiles whose rows are ALL whole-leaf rows of the recognised periodic shape (every BASELINE text row) are taken by
-// persistent workgroups of one LOADER wave and seven HASHER waves:
+// persistent workgroups — one per CU — of a LOADER wave and fifteen HASHER waves around a ring of slots in LDS:
 //   loader : pulls four tiles at a time from a global cursor, loads their index columns and frames (lane = row),
-//            recognises the rows lane-parallel (parse_fast), extends each window by 64 period bytes, WRITES the rows
-//            — 1 KiB of contiguous output per store instruction, read straight from the window — and publishes the
-//            four windows as slots of a ring in LDS.  It owns every global load of the workgroup.
-//   hasher : takes the next ready slot, hashes its <= 64 leaves straight from the window (an all-LDS loop: no vector
-//            memory instruction at all), leaves the chaining values in the slot, and the wave that completes a group of
-//            four slots folds their parent trees together and writes the digests.
-// What this removes from k_fused_small's timeline: every wave there runs prologue -> parse -> hash -> fold in
-// lockstep with all the others (equal work per tile keeps the generations aligned), so the memory latency of the
-// prologue and the fold barrier are exposed once per generation; and the hash lanes pay for the row stores (64
-// different cache lines per store instruction).  Here the hashers never wait on vmcnt, the loader runs ahead by up to
-// 16 slots, and the stores are whole lines.  Any other tile goes to the slow list and k_fused_small afterwards.
-constexpr uint32_t R_SLOTS = 16, R_GROUP = 4, R_WAVES = 8;
+//            recognises the rows lane-parallel (parse_fast) and publishes the four windows as a group of slots.  It
+//            owns every global load of the workgroup and runs up to seven groups ahead of the hashers.
+//   hasher : takes the next ready slot, gives every row's window 64 more bytes of its period, hashes the tile's
+//            <= 64 leaves straight from the windows (an all-LDS loop) while its lanes store the message registers
+//            as the row's bytes, leaves the chaining values in the slot; the wave that completes a group folds the
+//            four tiles' parent trees together and writes the digests.  A hasher never waits for a global load.
+// Any other tile goes to the slow list and k_fused_small afterwards.
+//
+// What was measured on the way (MI355X, 100k x 10 KiB rows; profiles/README.md):
+//  * a 16-byte LDS store at an odd address (the window extension done 16 bytes at a time) damaged windows of OTHER
+//    slots once the ring wrapped — every LDS store here is a byte store or an aligned one;
+//  * the loader writing the rows itself (whole lines, 1 KiB per store instruction, emit_periodic_row) made it the
+//    bottleneck: such a store costs the issuing wave ~200 cycles whatever feeds it (the CU's store path moves
+//    ~5-10 bytes per cycle), 95-110 k cycles per group of four tiles; two loaders per workgroup halved each one's
+//    rate; so the hash lanes store their registers as in k_fused_small (R_LOADER_EMITS = 0);
+//  * a volatile access through a generic pointer is a FLAT instruction; the ring's control words are explicit LDS
+//    accesses.
+#ifndef ZN_R_SLOTS
+#define ZN_R_SLOTS 32
+#endif
+#ifndef ZN_R_WAVES
+#define ZN_R_WAVES 16
+#endif
+#ifndef ZN_R_LOADERS
+#define ZN_R_LOADERS 1
+#endif
+#ifndef ZN_R_LOADER_EMITS
+#define ZN_R_LOADER_EMITS 0
+#endif
+constexpr uint32_t R_SLOTS = ZN_R_SLOTS, R_GROUP = 4, R_WAVES = ZN_R_WAVES, R_LOADERS = ZN_R_LOADERS;
+constexpr bool R_LOADER_EMITS = ZN_R_LOADER_EMITS != 0;
+static_assert((R_SLOTS & (R_SLOTS - 1)) == 0 && R_SLOTS >= 2 * R_GROUP, "ring size: a power of two, at least two groups");
 constexpr uint32_t R_SLOT_BYTES = WROWS * WSTRIDE;        // the windows; afterwards the tile's leaf CVs (first 2 KiB)
 constexpr uint32_t R_SLOT_NODES = R_SLOT_BYTES / 32;
 static_assert(R_SLOT_BYTES % 32 == 0 && R_SLOT_BYTES >= 64 * 32, "a slot must hold 64 chaining values, node-aligned");
 
-struct RolesShared {
+// Control words of the ring.  A wave reads a word with ONE ds_read_b32, but that instruction is served in two halves
+// of 32 lanes, a cycle apart: a store from another wave can land between them, and then lanes 0-31 and lanes 32-63
+// hold DIFFERENT values.  A branch on such a value is divergent — half the wave went on with a slot while the other
+// half waited, and came through the body a second time afterwards (measured: hashers working on "take 0" in the
+// middle of a run).  So every read is made scalar (lane 0's copy) the moment it arrives.
+typedef __attribute__((address_space(3))) uint32_t lds_u32;
+__device__ __forceinline__ uint32_t lds_ld(const uint32_t *p) { return __builtin_amdgcn_readfirstlane(*(const volatile lds_u32 *)p); }
+__device__ __forceinline__ void lds_st(uint32_t *p, uint32_t v) { *(volatile lds_u32 *)p = v; }
+__device__ __forceinline__ void lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
+struct alignas(16) RolesShared {
     uint8_t slots[R_SLOTS][R_SLOT_BYTES];
     uint64_t oo[R_SLOTS][WROWS];
     uint32_t len[R_SLOTS][WROWS];
     uint32_t tn[R_SLOTS][WROWS], toff[R_SLOTS][WROWS];  // fold table of the slot's units (written by its hasher)
     uint16_t dy[R_SLOTS][WROWS], dB[R_SLOTS][WROWS], doff[R_SLOTS][WROWS];
     uint32_t first[R_SLOTS], nunits[R_SLOTS], nleaves[R_SLOTS];
-    uint32_t ready, take, finished;      // slots published / claimed so far; the loader is done
+    uint32_t ready, take, finished;      // slots published / claimed so far; loaders that are done
+    uint32_t next_iter;                  // the loaders' iteration counter (an iteration = one group of four slots)
     uint32_t cnt[R_SLOTS / R_GROUP];     // hashed slots of the group's current use
-    uint32_t gen[R_SLOTS / R_GROUP];     // completed uses of the group (the loader refills it when gen == its next use)
+    uint32_t gen[R_SLOTS / R_GROUP];     // completed uses of the group (a loader refills it when gen == its next use)
 };
 
-__device__ __forceinline__ uint32_t lds_ld(const uint32_t *p) { return *(const volatile uint32_t *)p; }
-__device__ __forceinline__ void lds_st(uint32_t *p, uint32_t v) { *(volatile uint32_t *)p = v; }
-__device__ __forceinline__ void lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
-
-// One recognised row from its window, the whole wave: out[i] = Y[i] for i < L0 + 64 (the literals + 64 bytes of the
-// period), Y[B + (i - B) mod off] after that, B = L0 - off — any 16 output bytes are 16 contiguous window bytes.
-// Aligned 16-byte stores, 1 KiB per instruction, four in flight; head and tail bytes lane-parallel.
-__device__ __forceinline__ void emit_periodic_row(const uint8_t *Y, uint32_t L0, uint32_t off, uint8_t *out, uint32_t osize, uint32_t lane) {
+// One recognised row written by the whole wave from its window (R_LOADER_EMITS; lane = byte / 16-byte piece).
+// Y = the row's window at its literals:
+//   out[i] = Y[i]                         for i <  L0          (the literals; the period is their last `off` bytes)
+//   out[i] = Y[B + (i - B) mod off]       for i >= B = L0 - off
+// First the window gets 64 more bytes of the period behind the literals, so that any 16 output bytes are 16
+// CONTIGUOUS window bytes (at i itself, or at B + phase); then the row goes out as aligned 16-byte global stores,
+// 1 KiB per instruction, four in flight; head and tail bytes lane-parallel.
+__device__ __forceinline__ void emit_periodic_row(uint8_t *Y, uint32_t L0, uint32_t off, float inv, uint8_t *out, uint32_t osize,
+                                                  uint32_t lane) {
     const uint32_t B = L0 - off, lim = L0 + 64;
-    const float inv = 1.0f / (float)off;
+    Y[L0 + lane] = Y[B + lmod(lane, off, inv)];
     const uint32_t head = (uint32_t)((16 - ((uintptr_t)out & 15)) & 15);
     const uint32_t body16 = (osize - head) >> 4;
     const uint32_t step = smod(1024, off), rb = smod(B, off);
-    if (lane < head) out[lane] = Y[lane];
+    if (lane < head) out[lane] = Y[lane];                                 // head < 16 <= lim
     const uint32_t tail = (osize - head) & 15, p = head + 16 * body16 + lane;
     if (lane < tail) {
-        uint32_t rt = lmod(p, off, inv) + off - rb;
+        uint32_t rt = lmod(p, off, inv) + off - rb;                       // (p - B) mod off
         if (rt >= off) rt -= off;
         out[p] = p < lim ? Y[p] : Y[B + rt];
     }
     uint32_t x = head + 16 * lane;
-    uint32_t r = lmod(x, off, inv) + off - rb;  // (x - B) mod off
+    uint32_t r = lmod(x, off, inv) + off - rb;                            // (x - B) mod off
     if (r >= off) r -= off;
     for (uint32_t i0 = 0; i0 < body16; i0 += 256) {
         const uint32_t i = i0 + lane;
@@ -1118,10 +1179,10 @@ __device__ __forceinline__ void emit_periodic_row(const uint8_t *Y, uint32_t L0,
         uint32_t r3 = r2 + step; if (r3 >= off) r3 -= off;
         r = r3 + step; if (r >= off) r -= off;
         const bool p0 = i < body16, p1 = i + 64 < body16, p2 = i + 128 < body16, p3 = i + 192 < body16;
-        if (p0) v0 = lds16(x + 16 <= lim ? Y + x : Y + B + r0);
-        if (p1) v1 = lds16(x + 1040 <= lim ? Y + x + 1024 : Y + B + r1);
-        if (p2) v2 = lds16(x + 2064 <= lim ? Y + x + 2048 : Y + B + r2);
-        if (p3) v3 = lds16(x + 3088 <= lim ? Y + x + 3072 : Y + B + r3);
+        if (p0) v0 = lds16(x + 16 <= lim ? Y + x : Y + B + r0);           // only the row's first piece can lie in the literals
+        if (p1) v1 = lds16(Y + B + r1);
+        if (p2) v2 = lds16(Y + B + r2);
+        if (p3) v3 = lds16(Y + B + r3);
         uint8_t *d = out + x;
         if (p0) *reinterpret_cast<uint4 *>(d) = v0;
         if (p1) *reinterpret_cast<uint4 *>(d + 1024) = v1;
@@ -1142,11 +1203,19 @@ __device__ __forceinline__ void roles_loader(const FusedArgs &a, RolesShared &S)
         T.lls = lane < 36 ? c_llb[lane] | (uint32_t)c_lla[lane] << 24 : 0u;
         T.mls = lane < 53 ? c_mlb[lane] | (uint32_t)c_mla[lane] << 24 : 0u;
     }
-    for (uint32_t iter = 0;; iter++) {
-        uint32_t base = 0;
-        if (lane == 0) base = atomicAdd(a.cursor, R_GROUP);
-        base = uni(base);
-        if (base >= a.h.n_tiles) break;
+    for (;;) {
+        // iterations are numbered across the workgroup's loaders (their slots are published in that order); the tiles
+        // come from the global cursor.  A loader whose batch lies behind the last tile still fills and publishes its
+        // iteration — four empty slots — because another loader may hold a later iteration with real tiles; then
+        // it stops.
+        // (lane 0's value is given to EVERY lane before it is made scalar: readfirstlane reads the first ACTIVE lane, and
+        // the compiler may re-evaluate it at a later point where lane 0 is masked off — it did: hashers came out with
+        // take = 0 in the middle of a run and worked on slot 0 a second time)
+        uint32_t iter = 0, base = 0;
+        if (lane == 0) { iter = atomicAdd(&S.next_iter, 1u); base = atomicAdd(a.cursor, R_GROUP); }
+        iter = uni(__shfl(iter, 0));
+        base = uni(__shfl(base, 0));
+        const bool last = base >= a.h.n_tiles;
         const uint32_t grp = iter & (R_SLOTS / R_GROUP - 1), use = iter / (R_SLOTS / R_GROUP);
         // ---- the four tiles' index columns: issued before the wait for the group, they travel meanwhile ----
         const uint32_t ti = base + j;
@@ -1170,9 +1239,12 @@ __device__ __forceinline__ void roles_loader(const FusedArgs &a, RolesShared &S)
         }
         const bool want = rowv && c_sel && c_st == 0 && c_len != 0 && (c_len & 1023) == 0 && c_len <= 0x10000 &&
                           c_oo + c_len <= a.out_cap && c_bs >= 12 && c_bs <= WIN;
+        while (lds_ld(&S.gen[grp]) != use) __builtin_amdgcn_s_sleep(4);  // the group's previous use has been folded
+        // (volatile accesses order only against one another: without this the compiler is free to move the window
+        // stores below to the front of the wait — it did, once the instrumentation that happened to pin them was gone)
+        asm volatile("" ::: "memory");
         // ---- the frames, lane = row: 16 bytes per step into the row's window (the last partial piece bytewise: the
         // blob region promises nothing behind its last byte) ----
-        while (lds_ld(&S.gen[grp]) != use) __builtin_amdgcn_s_sleep(4);  // the group's previous use has been folded
         const uint32_t slot = grp * R_GROUP + j;
         uint8_t *const win = S.slots[slot] + (u < WROWS ? u : 0) * WSTRIDE;
         const uint8_t *const src = a.h.srcA + c_src;
@@ -1203,37 +1275,43 @@ __device__ __forceinline__ void roles_loader(const FusedArgs &a, RolesShared &S)
             S.dy[slot][u] = (uint16_t)(u * WSTRIDE + fr.lit_at);
             S.dB[slot][u] = (uint16_t)(fr.L0 - fr.off);
             S.doff[slot][u] = (uint16_t)fr.off;
-            // 64 more bytes of the period behind the literals: y[L0 + i] = y[L0 + i - off], in order
-            uint8_t *y = win + fr.lit_at + fr.L0;
-            if (fr.off >= 16) {
-#pragma unroll
-                for (uint32_t i = 0; i < 64; i += 16) {
-                    uint4 v;
-                    __builtin_memcpy(&v, y + i - fr.off, 16);
-                    __builtin_memcpy(y + i, &v, 16);
-                }
-            } else {
-                for (uint32_t i = 0; i < 64; i++) y[i] = y[(int32_t)i - (int32_t)fr.off];
-            }
         }
         lds_fence();
-        // ---- the rows themselves: written here, whole lines, while the hashers work on earlier slots ----
-        if (!(a.dbg & 16)) {
+#ifdef ZN_R_EXT_BY_LOADER
+        if (!R_LOADER_EMITS) {  // experiment: the window extension done here, row by row
+            const float inv_l = 1.0f / (float)(mine ? fr.off : 1u);
             for (uint64_t m = __ballot(mine); m; m &= m - 1) {
                 const uint32_t l = (uint32_t)__builtin_ctzll(m);
                 const uint32_t sl = grp * R_GROUP + (l >> 4);
                 const uint32_t lit_at = __builtin_amdgcn_readlane(fr.lit_at, l), L0 = __builtin_amdgcn_readlane(fr.L0, l),
+                               off = __builtin_amdgcn_readlane(fr.off, l);
+                const float inv = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(inv_l), l));
+                uint8_t *Y = S.slots[sl] + (l & 15) * WSTRIDE + lit_at;
+                Y[L0 + lane] = Y[L0 - off + lmod(lane, off, inv)];
+            }
+            lds_fence();
+        }
+#endif
+        if (R_LOADER_EMITS) {  // (off by default: see the measurements at the top)
+            const float inv_l = 1.0f / (float)(mine ? fr.off : 1u);
+            for (uint64_t m = __ballot(mine); m && !(a.dbg & 16); m &= m - 1) {
+                const uint32_t l = (uint32_t)__builtin_ctzll(m);
+                const uint32_t sl = grp * R_GROUP + (l >> 4);
+                const uint32_t lit_at = __builtin_amdgcn_readlane(fr.lit_at, l), L0 = __builtin_amdgcn_readlane(fr.L0, l),
                                off = __builtin_amdgcn_readlane(fr.off, l), osize = __builtin_amdgcn_readlane((uint32_t)c_len, l);
+                const float inv = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(inv_l), l));
                 const uint64_t oo = ((uint64_t)__builtin_amdgcn_readlane((uint32_t)(c_oo >> 32), l) << 32) |
                                     __builtin_amdgcn_readlane((uint32_t)c_oo, l);
-                emit_periodic_row(S.slots[sl] + (l & 15) * WSTRIDE + lit_at, L0, off, a.h.srcB + oo, osize, lane);
+                emit_periodic_row(S.slots[sl] + (l & 15) * WSTRIDE + lit_at, L0, off, inv, a.h.srcB + oo, osize, lane);
             }
+            lds_fence();
         }
-        lds_fence();
+        while (lds_ld(&S.ready) != iter * R_GROUP) __builtin_amdgcn_s_sleep(2);  // publish in iteration order
         if (lane == 0) lds_st(&S.ready, (iter + 1) * R_GROUP);
+        if (last) break;
     }
     lds_fence();
-    if (lane == 0) lds_st(&S.finished, 1u);
+    if (lane == 0) atomicAdd(&S.finished, 1u);
 }
 
 __device__ __forceinline__ void roles_hasher(const FusedArgs &a, RolesShared &S) {
@@ -1243,26 +1321,57 @@ __device__ __forceinline__ void roles_hasher(const FusedArgs &a, RolesShared &S)
     for (;;) {
         uint32_t take = 0;
         if (lane == 0) take = atomicAdd(&S.take, 1u);
-        take = uni(take);
+        take = uni(__shfl(take, 0));  // every lane holds it: see roles_loader
+        bool go = false;
         for (;;) {
-            if (lds_ld(&S.ready) > take) break;
-            if (lds_ld(&S.finished)) {
-                if (lds_ld(&S.ready) > take) break;
-                return;  // nothing more will be published
-            }
+            const uint32_t f = lds_ld(&S.finished);  // (read BEFORE ready: a loader's last slots are published before it says so)
+            if (lds_ld(&S.ready) > take) { go = true; break; }
+            if (f == R_LOADERS) break;               // nothing more will be published
             __builtin_amdgcn_s_sleep(2);
         }
+        if (!go) return;
         asm volatile("" ::: "memory");
         const uint32_t slot = take & (R_SLOTS - 1), grp = slot / R_GROUP;
         const uint32_t nu = lds_ld(&S.nunits[slot]);
+        const bool chk = (a.dbg & 512) && a.dbg_buf;
+        if (chk && lane == 0) {
+            atomicAdd(&a.dbg_buf[2], 1ull);
+            if (lds_ld(&S.cnt[grp]) >= R_GROUP) atomicAdd(&a.dbg_buf[3], 1ull);
+            if (lds_ld(&S.gen[grp]) != take / R_SLOTS) atomicAdd(&a.dbg_buf[4], 1ull);
+        }
         if (nu) {
             const Tile t{lds_ld(&S.first[slot]), nu, 0, lds_ld(&S.nleaves[slot]), 0, 0};
             const uint32_t lu = lane < nu ? lane : 0;
+#ifndef ZN_R_EXT_BY_LOADER
+            if (!R_LOADER_EMITS) {
+                // 64 more bytes of each row's period behind its literals (lane = byte; BYTE stores: see the top):
+                // every row's byte is read first, then all are written — two LDS round trips for the tile
+                uint8_t bytes[WROWS];
+#pragma unroll
+                for (uint32_t q = 0; q < WROWS; q++) {
+                    bytes[q] = 0;
+                    if (q < nu) {
+                        const uint32_t off = S.doff[slot][q];
+                        bytes[q] = S.slots[slot][S.dy[slot][q] + S.dB[slot][q] + lmod(lane, off, 1.0f / (float)off)];
+                    }
+                }
+#pragma unroll
+                for (uint32_t q = 0; q < WROWS; q++)
+                    if (q < nu) S.slots[slot][S.dy[slot][q] + S.dB[slot][q] + S.doff[slot][q] + lane] = bytes[q];
+            }
+#endif
+            // the rows are stored by the lanes that hash them (their message registers) unless the loader wrote them
             LdsSrc ls{S.slots[slot], S.dy[slot], S.dB[slot], S.doff[slot], WROWS, nullptr,
-                      lane < nu ? (uint64_t)S.len[slot][lu] : 0ull, 0ull, S.oo[slot][lu], 1u, 0u, 0ull};
+                      lane < nu ? (uint64_t)S.len[slot][lu] : 0ull, 0ull, S.oo[slot][lu], 1u,
+                      (R_LOADER_EMITS || (a.dbg & 16)) ? 0u : 0x3Fu, 0ull};
             LeafOut lo;
-            hash_tile_leaves<false, true>(h, t, &ls, lo);
-            // the window is dead (every lane has read its last block): the leaf CVs take its place
+            if (a.dbg & 8192) {  // ablation: no hashing (the loaders' pace alone)
+                lo.active = false; lo.u_cnt = 0; lo.u_head = 0;
+#pragma unroll
+                for (int q = 0; q < 8; q++) lo.cv[q] = 0;
+            } else
+                hash_tile_leaves<!R_LOADER_EMITS, true>(h, t, &ls, lo);
+            // the windows are dead (every lane has read its last block): the leaf CVs take their place
             if (lo.active) {
                 uint4 *d = reinterpret_cast<uint4 *>(S.slots[slot] + lane * 32);
                 d[0] = make_uint4(lo.cv[0], lo.cv[1], lo.cv[2], lo.cv[3]);
@@ -1279,8 +1388,13 @@ __device__ __forceinline__ void roles_hasher(const FusedArgs &a, RolesShared &S)
         lds_fence();
         uint32_t old = 0;
         if (lane == 0) old = atomicAdd(&S.cnt[grp], 1u);
-        old = uni(old);
+        old = uni(__shfl(old, 0));
+        if (chk && lane == 0) {
+            if (old >= R_GROUP) atomicAdd(&a.dbg_buf[5], 1ull);
+            if (lds_ld(&S.gen[grp]) != take / R_SLOTS) atomicAdd(&a.dbg_buf[6], 1ull);
+        }
         if (old == R_GROUP - 1) {
+            if (chk && lane == 0) atomicAdd(&a.dbg_buf[7], 1ull);
             // this wave hashed the group's last slot: fold the four tiles' parent trees together, write the digests
             asm volatile("" ::: "memory");
             const uint32_t jj = lane >> 4, uu = lane & 15, sl = grp * R_GROUP + jj;
@@ -1290,7 +1404,14 @@ __device__ __forceinline__ void roles_hasher(const FusedArgs &a, RolesShared &S)
             fq.tb_off = uu < WROWS ? S.toff[sl][uu] : 0u;
             fq.tb_out = S.first[sl] + uu;
             fq.tb_root = 1;
-            if (__ballot(fq.tb_n != 0) != 0ull) fq.fold_and_write(reinterpret_cast<uint32_t *>(S.slots[grp * R_GROUP]), h);
+            if (__ballot(fq.tb_n != 0) != 0ull && !(a.dbg & 131072)) {
+                uint32_t *const nodes = reinterpret_cast<uint32_t *>(S.slots[grp * R_GROUP]);
+                FoldQueue<4> fd = fq.dense16();
+                uint32_t U = 0;
+                const uint32_t n = (a.dbg & 262144) ? 0u : fd.uniform(&U);
+                if (n) fd.fold_uniform_and_write(nodes, h, n, U);  // every row of the four tiles has the same length
+                else fq.fold_and_write(nodes, h);
+            }
             lds_fence();
             if (lane == 0) {
                 lds_st(&S.cnt[grp], 0u);
@@ -1300,19 +1421,35 @@ __device__ __forceinline__ void roles_hasher(const FusedArgs &a, RolesShared &S)
     }
 }
 
-__global__ __launch_bounds__(R_WAVES * 64, 2) void k_fused_roles(FusedArgs a) {
-    __shared__ __attribute__((aligned(16))) RolesShared S;
-    if (threadIdx.x == 0) { S.ready = 0; S.take = 0; S.finished = 0; }
+__global__ __launch_bounds__(R_WAVES * 64) void k_fused_roles(FusedArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t s_roles_raw[];  // dynamic: more than the 64 KiB a static array may take
+    RolesShared &S = *reinterpret_cast<RolesShared *>(s_roles_raw);
+    if (threadIdx.x == 0) { S.ready = 0; S.take = 0; S.finished = 0; S.next_iter = 0; }
     if (threadIdx.x < R_SLOTS / R_GROUP) { S.cnt[threadIdx.x] = 0; S.gen[threadIdx.x] = 0; }
     __syncthreads();
-    if (threadIdx.x < 64) roles_loader(a, S);
-    else roles_hasher(a, S);
+    const bool clk = (a.dbg & 32768) && a.dbg_buf && blockIdx.x == 7 && threadIdx.x == 64 * R_LOADERS;
+    const unsigned long long c0 = clk ? __builtin_amdgcn_s_memtime() : 0, r0 = clk ? __builtin_amdgcn_s_memrealtime() : 0;
+    if (threadIdx.x < 64 * R_LOADERS) {
+        // the loader's instruction stream is one long dependent chain with little VALU in it: at top priority it
+        // issues whenever it is ready and costs the hashers a few per cent of the issue slots
+        if (!(a.dbg & 64)) __builtin_amdgcn_s_setprio(3);
+        roles_loader(a, S);
+    } else roles_hasher(a, S);
+    if (clk) { a.dbg_buf[0] = __builtin_amdgcn_s_memtime() - c0; a.dbg_buf[1] = __builtin_amdgcn_s_memrealtime() - r0; }
 }
 
 void launch_fused_roles(const FusedArgs &a, int cus, hipStream_t s) {
     if (!a.h.n_tiles) return;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_fused_roles), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(RolesShared));
+        attr_set = true;
+    }
     const uint32_t want = (a.h.n_tiles + R_GROUP - 1) / R_GROUP;  // one group per workgroup at least
-    hipLaunchKernelGGL(k_fused_roles, dim3(std::min<uint32_t>((uint32_t)cus * 2, want)), dim3(R_WAVES * 64), 0, s, a);
+    const uint32_t per_cu = sizeof(RolesShared) > 80 * 1024 ? 1u : 2u;
+    uint32_t grid = std::min<uint32_t>((uint32_t)cus * per_cu, want);
+    if (a.lds_pad) grid = std::min<uint32_t>(grid, a.lds_pad);  // experiment: ZNIPPY_LDS_PAD caps the grid
+    hipLaunchKernelGGL(k_fused_roles, dim3(grid), dim3(R_WAVES * 64), sizeof(RolesShared), s, a);
 }
 
 // ---- big rows: block items of the common shape --------------------------------------------------------

@@ -695,6 +695,94 @@ struct FoldQueue {
         }
         n_tab = 0;
     }
+
+    // The same for the common case that every queued unit has the SAME number of nodes n >= 2 (a table of equal rows:
+    // BASELINE's 100k x 10 KiB; the slices of big rows): the node -> (unit, pair) mapping is then a division by a
+    // wave-uniform constant instead of a prefix scan + binary search through ds_bpermute (16 dependent shuffles per
+    // pass), and a level's odd node is CARRIED as a copy instead of taking a lane of a compress pass — four 6 x 10-leaf
+    // tiles fold in 5 passes instead of 6, and a pass is little more than its compression.
+    // Units must be queued densely on lanes [0, U) (tb_n = n there, 0 behind) — see uniform().
+    // Layout: level l keeps unit u's n_l nodes at [u * n_l, ...) (level 0: at tb_off), in place: output u * c + j never
+    // lies behind its own children, and a level's carries are read before its parents are written.
+    // A table kept as four groups of 16 lanes (group g = tile g, its units on the group's first lanes), moved to
+    // lanes [0, U): what fold_uniform_and_write wants.  (A group with a gap — a unit that is not hashed — leaves a gap:
+    // uniform() then says no and the caller folds the original table the general way.)
+    __device__ __forceinline__ FoldQueue<G> dense16() const {
+        const uint32_t lane = threadIdx.x & 63;
+        const uint64_t has = __ballot(lane < n_tab && tb_n != 0);
+        const uint32_t c0 = (uint32_t)__popcll(has & 0xFFFFull), c1 = c0 + (uint32_t)__popcll(has >> 16 & 0xFFFFull),
+                       c2 = c1 + (uint32_t)__popcll(has >> 32 & 0xFFFFull), c3 = c2 + (uint32_t)__popcll(has >> 48);
+        const uint32_t g = lane < c0 ? 0u : (lane < c1 ? 1u : (lane < c2 ? 2u : 3u));
+        const uint32_t src = 16 * g + lane - (g == 0 ? 0u : (g == 1 ? c0 : (g == 2 ? c1 : c2)));
+        FoldQueue<G> d;
+        d.n_tab = c3;
+        d.tb_n = __shfl(tb_n, src & 63);
+        d.tb_off = __shfl(tb_off, src & 63);
+        d.tb_out = __shfl(tb_out, src & 63);
+        d.tb_root = __shfl(tb_root, src & 63);
+        if (lane >= c3) d.tb_n = 0;
+        return d;
+    }
+    __device__ __forceinline__ uint32_t uniform(uint32_t *units) const {  // -> n if the table is U x n (n >= 2), else 0
+        const uint32_t lane = threadIdx.x & 63;
+        const uint32_t n0 = __shfl(tb_n, 0);
+        const uint64_t has = __ballot(lane < n_tab && tb_n != 0), same = __ballot(lane < n_tab && tb_n == n0);
+        const uint32_t U = (uint32_t)__popcll(has);
+        *units = U;
+        if (n0 < 2 || has != same || U == 0 || has != (U == 64 ? ~0ull : ((1ull << U) - 1))) return 0;
+        return n0;
+    }
+    __device__ __forceinline__ void fold_uniform_and_write(uint32_t *nodes, const HashArgs &a, uint32_t n, uint32_t U) {
+        const uint32_t lane = threadIdx.x & 63;
+        const uint32_t root = __shfl(tb_root, 0);  // (a table is all units or all slices)
+        uint32_t pos = tb_off;                     // lane u: first node of unit u at the current level
+        for (uint32_t nl = n; nl > 1;) {
+            const uint32_t h = nl >> 1, c = h + (nl & 1);
+            uint4 k0 = make_uint4(0, 0, 0, 0), k1 = k0;
+            if ((nl & 1) && lane < U) {  // the level's odd node of my unit, before anything is overwritten
+                const uint4 *s = reinterpret_cast<const uint4 *>(nodes + (size_t)(pos + nl - 1) * 8);
+                k0 = s[0]; k1 = s[1];
+            }
+            const float inv = 1.0f / (float)h;
+            const uint32_t total = U * h;
+            for (uint32_t p = 0; p * 64 < total; p++) {
+                const uint32_t q = p * 64 + lane;
+                const bool on = q < total;
+                const uint32_t u = on ? (uint32_t)(((float)q + 0.5f) * inv) : 0u, j = q - u * h;
+                const uint32_t io = __shfl(pos, u);
+                uint32_t cv[8];
+                if (on) {
+                    const uint4 *s = reinterpret_cast<const uint4 *>(nodes + (size_t)(io + 2 * j) * 8);
+                    const uint4 l0 = s[0], l1 = s[1], r0 = s[2], r1 = s[3];
+                    uint32_t L[8] = {l0.x, l0.y, l0.z, l0.w, l1.x, l1.y, l1.z, l1.w};
+                    uint32_t R[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
+                    b3::parent(cv, L, R, root && nl == 2);
+                }
+                __builtin_amdgcn_wave_barrier();  // every lane has read its children before any node is overwritten
+                if (on) {
+                    uint4 *d = reinterpret_cast<uint4 *>(nodes + (size_t)(u * c + j) * 8);
+                    d[0] = make_uint4(cv[0], cv[1], cv[2], cv[3]);
+                    d[1] = make_uint4(cv[4], cv[5], cv[6], cv[7]);
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+            if ((nl & 1) && lane < U) {
+                uint4 *d = reinterpret_cast<uint4 *>(nodes + (size_t)(lane * c + h) * 8);
+                d[0] = k0; d[1] = k1;
+            }
+            __builtin_amdgcn_wave_barrier();
+            pos = lane * c;
+            nl = c;
+        }
+        if (lane < U) {
+            const uint4 *s = reinterpret_cast<const uint4 *>(nodes + (size_t)pos * 8);
+            const uint4 c0 = s[0], c1 = s[1];
+            uint4 *o = reinterpret_cast<uint4 *>((root ? a.digests : a.tile_cv) + (size_t)tb_out * 8);
+            o[0] = c0;
+            o[1] = c1;
+        }
+        n_tab = 0;
+    }
 };
 
 }  // namespace zn

@@ -213,7 +213,8 @@ void launch_verify(const uint32_t *digests, const uint8_t *checksum, const uint6
 // Nothing but BLAKE3 compressions (message in registers, no memory traffic), 4 waves per SIMD on every CU: what
 // one 64-lane compress pass costs a SIMD when the integer VALU is the only thing in use.  bench.py multiplies it
 // by the passes a step needs to report the floor the hash sets whatever the memory system does.
-__global__ __launch_bounds__(256) void k_b3_pass_ubench(uint32_t *out, uint32_t seed, int passes) {
+__global__ __launch_bounds__(256) void k_b3_pass_ubench(uint32_t *out, uint32_t seed, int passes, unsigned long long *clk) {
+    const unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
     uint32_t cv[8], m[16];
 #pragma unroll
     for (int i = 0; i < 8; i++) cv[i] = threadIdx.x * 7 + i + seed;
@@ -228,19 +229,24 @@ __global__ __launch_bounds__(256) void k_b3_pass_ubench(uint32_t *out, uint32_t 
 #pragma unroll
     for (int i = 0; i < 8; i++) x ^= cv[i];
     out[blockIdx.x * 256 + threadIdx.x] = x;
+    if (clk && blockIdx.x == 7 && threadIdx.x == 0) {  // shader cycles and 100 MHz ticks of one wave's life: the clock the chip held
+        clk[0] = __builtin_amdgcn_s_memtime() - c0;
+        clk[1] = __builtin_amdgcn_s_memrealtime() - r0;
+    }
 }
 
-int measure_b3_pass_ns(int cus, hipStream_t s, float *ns_per_pass_per_simd) {
+int measure_b3_pass_ns(int cus, hipStream_t s, float *ns_per_pass_per_simd, float *ghz) {
     const int grid = cus * 4, passes = 200;  // 4 blocks of 4 waves per CU = 4 waves per SIMD
     uint32_t *d = nullptr;
-    if (hipMalloc(&d, (size_t)grid * 256 * 4) != hipSuccess) return -3;
+    if (hipMalloc(&d, (size_t)grid * 256 * 4 + 64) != hipSuccess) return -3;
+    unsigned long long *clk = reinterpret_cast<unsigned long long *>(d + (size_t)grid * 256);
     hipEvent_t t0, t1;
     (void)hipEventCreate(&t0);
     (void)hipEventCreate(&t1);
     float best = 0.f;
     for (int rep = 0; rep < 3; rep++) {
         (void)hipEventRecord(t0, s);
-        hipLaunchKernelGGL(k_b3_pass_ubench, dim3(grid), dim3(256), 0, s, d, (uint32_t)(rep + 1), passes);
+        hipLaunchKernelGGL(k_b3_pass_ubench, dim3(grid), dim3(256), 0, s, d, (uint32_t)(rep + 1), passes, clk);
         (void)hipEventRecord(t1, s);
         (void)hipEventSynchronize(t1);
         float ms = 0.f;
@@ -249,6 +255,9 @@ int measure_b3_pass_ns(int cus, hipStream_t s, float *ns_per_pass_per_simd) {
     }
     (void)hipEventDestroy(t0);
     (void)hipEventDestroy(t1);
+    unsigned long long hc[2] = {0, 1};
+    (void)hipMemcpy(hc, clk, 16, hipMemcpyDeviceToHost);
+    if (ghz) *ghz = hc[1] ? (float)((double)hc[0] / (double)hc[1] * 0.1) : 0.f;
     (void)hipFree(d);
     *ns_per_pass_per_simd = best * 1e6f / (float)(passes * 4);
     return hipGetLastError() == hipSuccess ? 0 : -2;

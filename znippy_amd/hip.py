@@ -69,9 +69,16 @@ class Context:
 
     def blake3_pass_ns(self):
         """Measured VALU floor: ns per 64-lane compress pass per SIMD (compressions only, nothing else running)."""
-        v = C.c_float()
-        self._chk(self.L.znippy_measure_blake3_pass_ns(self.h, C.byref(v)), "znippy_measure_blake3_pass_ns")
+        v, g = C.c_float(), C.c_float()
+        self._chk(self.L.znippy_measure_blake3_pass_ns(self.h, C.byref(v), C.byref(g)), "znippy_measure_blake3_pass_ns")
+        self.ubench_ghz = float(g.value)
         return float(v.value)
+
+    def last_shader_ghz(self):
+        """Shader clock one wave of the small-row read kernel saw in the last run (context created with ZNIPPY_DBG & 32768)."""
+        g = C.c_float()
+        self._chk(self.L.znippy_last_shader_ghz(self.h, C.byref(g)), "znippy_last_shader_ghz")
+        return float(g.value)
 
     # ---- single-chunk shims (codec.rs semantics, host buffers) ----
     def compress_bound(self, n):
