@@ -76,10 +76,9 @@ struct znippy_ctx {
         unsigned lds_pad = 0;    // ZNIPPY_LDS_PAD
         bool no_block_items = false, no_fused_blocks = false, ddbg = false, edbg = false, no_fused_store = false,
              nohash = false, no_roles = false;
-        // ZNIPPY_ROLES_MIN: small tiles from which the EXPERIMENTAL role-split kernel takes the table.  Off by default
-        // (0 = never): it is no faster than k_fused_small (profiles/README.md, round 2) and once its slot ring wraps it
-        // still loses rows to a race that was not found — it must not run in production.
-        unsigned roles_min = 0;
+        // ZNIPPY_ROLES_MIN: small tiles from which the role-split persistent kernel takes the table (0 = never; below
+        // a few CU-fillings a persistent grid only adds start-up latency)
+        unsigned roles_min = 2048;
     } sw;
     int cus = 256;
     unsigned long long *clk_buf = nullptr;  // diagnostic (ZNIPPY_DBG & 32768): shader cycles / 100 MHz ticks of one wave
@@ -762,16 +761,8 @@ int znippy_decode_verify_rows_async(znippy_ctx *ctx, znippy_rows *r, const void 
             (void)hipMemset(dbg, 0, 64);
             f.dbg_buf = dbg;
         }
-        if (f.dbg & (32768 | 512)) {
+        if (f.dbg & 32768) {
             if (!ctx->clk_buf) { (void)hipMalloc(&ctx->clk_buf, 64); (void)hipMemset(ctx->clk_buf, 0, 64); }
-            if (f.dbg & 512) {  // diagnostic: protocol counters of the role-split kernel's previous launch
-                unsigned long long h8[8];
-                (void)hipStreamSynchronize(s);
-                (void)hipMemcpy(h8, ctx->clk_buf, 64, hipMemcpyDeviceToHost);
-                if (h8[2]) fprintf(stderr, "[znippy roles] slots %llu | complete-at-start %llu gen-mismatch-at-start %llu | over-arrivals %llu gen-mismatch-at-arrival %llu | folds %llu\n",
-                                   h8[2], h8[3], h8[4], h8[5], h8[6], h8[7]);
-                (void)hipMemset(ctx->clk_buf, 0, 64);
-            }
             f.dbg_buf = ctx->clk_buf;
         }
         if (f.dbg & (16 | 32 | 64)) set_fused_abl(f.dbg);

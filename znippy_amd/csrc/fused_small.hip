@@ -283,25 +283,10 @@ __device__ __forceinline__ void fwave_expand(uint8_t *dst, const uint8_t *pg, co
         }
         if (lane < (off & 15)) E[full + lane] = pg[full + lane];
     }
-    // 2) the rest of E.  No 16-byte store to an odd LDS address anywhere (such stores are not safe next to other
-    // waves' LDS traffic — measured in the role-split kernel, see emit_periodic_row): first 64 more bytes of the period
-    // one byte per lane, then every further 16-byte piece is read at its phase inside [0, off + 16) and stored ALIGNED;
-    // the pieces do not depend on one another, so they go 1 KiB per round.
+    // 2) the rest of E: first 64 more bytes of the period one byte per lane, then every further 16-byte piece is read at
+    // its phase inside [0, off + 16) and stored aligned; the pieces do not depend on one another, so they go 1 KiB per
+    // round (the first version doubled the filled part step by step: a chain of dependent LDS round trips).
     const uint32_t need = off + (ml < 1024 ? ml : 1024);
-#ifdef ZN_OLD_EXPAND
-    {
-        uint32_t w = off;
-        while (w < need) {
-            const uint32_t c = w < need - w ? w : need - w;
-            for (uint32_t i = lane * 16; i < c; i += 1024) {
-                uint4 v;
-                __builtin_memcpy(&v, E + i, 16);
-                __builtin_memcpy(E + w + i, &v, 16);
-            }
-            w += c;
-        }
-    }
-#else
     const float inv = 1.0f / (float)off;
     E[off + lane] = E[lmod(lane, off, inv)];
     for (uint32_t c = ((off + 64 + 15) >> 4) + lane; 16 * c < need; c += 64) {
@@ -314,7 +299,6 @@ __device__ __forceinline__ void fwave_expand(uint8_t *dst, const uint8_t *pg, co
         const uint32_t lo = off + 64, hi = ((off + 64 + 15) >> 4) << 4;
         if (lo + lane < hi && lo + lane < need) E[lo + lane] = E[lmod(lo + lane, off, inv)];
     }
-#endif
     STAMP_END(4);
     if (g_abl & 16) return;  // ablation: no stream-out
     // 3) stream out
@@ -1096,8 +1080,12 @@ __global__ __launch_bounds__(256, 5) void k_fused_small(FusedArgs a) {
 // Any other tile goes to the slow list and k_fused_small afterwards.
 //
 // What was measured on the way (MI355X, 100k x 10 KiB rows; profiles/README.md):
-//  * a 16-byte LDS store at an odd address (the window extension done 16 bytes at a time) damaged windows of OTHER
-//    slots once the ring wrapped — every LDS store here is a byte store or an aligned one;
+//  * `if (lane == 0) x = atomicAdd(..); x = readfirstlane(x);` is a trap: x is 0 in the other lanes, and the compiler's
+//    structured control flow ran the loop body a second time for lanes 1..63 with that 0 — hashers went through
+//    "take 0" again in the middle of a run, wrote chaining values over slot 0's fresh windows and arrived at group 0 a
+//    fifth time.  Every atomic here is executed by ALL lanes (lane 0 adds, the others add 0).  (For a while this was
+//    taken for a hardware problem with 16-byte LDS stores at odd addresses and then with half-wave tearing of flag
+//    reads; neither was the cause, but the code keeps byte / aligned LDS stores and scalar flag reads.)
 //  * the loader writing the rows itself (whole lines, 1 KiB per store instruction, emit_periodic_row) made it the
 //    bottleneck: such a store costs the issuing wave ~200 cycles whatever feeds it (the CU's store path moves
 //    ~5-10 bytes per cycle), 95-110 k cycles per group of four tiles; two loaders per workgroup halved each one's
@@ -1124,10 +1112,8 @@ constexpr uint32_t R_SLOT_NODES = R_SLOT_BYTES / 32;
 static_assert(R_SLOT_BYTES % 32 == 0 && R_SLOT_BYTES >= 64 * 32, "a slot must hold 64 chaining values, node-aligned");
 
 // Control words of the ring.  A wave reads a word with ONE ds_read_b32, but that instruction is served in two halves
-// of 32 lanes, a cycle apart: a store from another wave can land between them, and then lanes 0-31 and lanes 32-63
-// hold DIFFERENT values.  A branch on such a value is divergent — half the wave went on with a slot while the other
-// half waited, and came through the body a second time afterwards (measured: hashers working on "take 0" in the
-// middle of a run).  So every read is made scalar (lane 0's copy) the moment it arrives.
+// of 32 lanes: a store from another wave may land between them and leave the halves with different values.  Every
+// read is made scalar (lane 0's copy) the moment it arrives, so that a branch on it is uniform by construction.
 typedef __attribute__((address_space(3))) uint32_t lds_u32;
 __device__ __forceinline__ uint32_t lds_ld(const uint32_t *p) { return __builtin_amdgcn_readfirstlane(*(const volatile lds_u32 *)p); }
 __device__ __forceinline__ void lds_st(uint32_t *p, uint32_t v) { *(volatile lds_u32 *)p = v; }
@@ -1211,10 +1197,12 @@ __device__ __forceinline__ void roles_loader(const FusedArgs &a, RolesShared &S)
         // (lane 0's value is given to EVERY lane before it is made scalar: readfirstlane reads the first ACTIVE lane, and
         // the compiler may re-evaluate it at a later point where lane 0 is masked off — it did: hashers came out with
         // take = 0 in the middle of a run and worked on slot 0 a second time)
-        uint32_t iter = 0, base = 0;
-        if (lane == 0) { iter = atomicAdd(&S.next_iter, 1u); base = atomicAdd(a.cursor, R_GROUP); }
-        iter = uni(__shfl(iter, 0));
-        base = uni(__shfl(base, 0));
+        // (EVERY lane executes the atomic — lane 0 adds, the others add 0 — and lane 0's result is made scalar.  The
+        // usual `if (lane == 0) x = atomicAdd(..)` leaves x = 0 in the other lanes, and the compiler's structured
+        // control flow ran the rest of the loop body a SECOND time for lanes 1..63 with that 0: measured — hashers went
+        // through "take 0" again in the middle of a run and overwrote slot 0.)
+        const uint32_t iter = uni(atomicAdd(&S.next_iter, lane == 0 ? 1u : 0u));
+        const uint32_t base = uni(atomicAdd(a.cursor, lane == 0 ? R_GROUP : 0u));
         const bool last = base >= a.h.n_tiles;
         const uint32_t grp = iter & (R_SLOTS / R_GROUP - 1), use = iter / (R_SLOTS / R_GROUP);
         // ---- the four tiles' index columns: issued before the wait for the group, they travel meanwhile ----
@@ -1240,9 +1228,7 @@ __device__ __forceinline__ void roles_loader(const FusedArgs &a, RolesShared &S)
         const bool want = rowv && c_sel && c_st == 0 && c_len != 0 && (c_len & 1023) == 0 && c_len <= 0x10000 &&
                           c_oo + c_len <= a.out_cap && c_bs >= 12 && c_bs <= WIN;
         while (lds_ld(&S.gen[grp]) != use) __builtin_amdgcn_s_sleep(4);  // the group's previous use has been folded
-        // (volatile accesses order only against one another: without this the compiler is free to move the window
-        // stores below to the front of the wait — it did, once the instrumentation that happened to pin them was gone)
-        asm volatile("" ::: "memory");
+        asm volatile("" ::: "memory");  // (volatile accesses order only against one another: pin the window stores below)
         // ---- the frames, lane = row: 16 bytes per step into the row's window (the last partial piece bytewise: the
         // blob region promises nothing behind its last byte) ----
         const uint32_t slot = grp * R_GROUP + j;
@@ -1277,21 +1263,6 @@ __device__ __forceinline__ void roles_loader(const FusedArgs &a, RolesShared &S)
             S.doff[slot][u] = (uint16_t)fr.off;
         }
         lds_fence();
-#ifdef ZN_R_EXT_BY_LOADER
-        if (!R_LOADER_EMITS) {  // experiment: the window extension done here, row by row
-            const float inv_l = 1.0f / (float)(mine ? fr.off : 1u);
-            for (uint64_t m = __ballot(mine); m; m &= m - 1) {
-                const uint32_t l = (uint32_t)__builtin_ctzll(m);
-                const uint32_t sl = grp * R_GROUP + (l >> 4);
-                const uint32_t lit_at = __builtin_amdgcn_readlane(fr.lit_at, l), L0 = __builtin_amdgcn_readlane(fr.L0, l),
-                               off = __builtin_amdgcn_readlane(fr.off, l);
-                const float inv = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(inv_l), l));
-                uint8_t *Y = S.slots[sl] + (l & 15) * WSTRIDE + lit_at;
-                Y[L0 + lane] = Y[L0 - off + lmod(lane, off, inv)];
-            }
-            lds_fence();
-        }
-#endif
         if (R_LOADER_EMITS) {  // (off by default: see the measurements at the top)
             const float inv_l = 1.0f / (float)(mine ? fr.off : 1u);
             for (uint64_t m = __ballot(mine); m && !(a.dbg & 16); m &= m - 1) {
@@ -1311,7 +1282,7 @@ __device__ __forceinline__ void roles_loader(const FusedArgs &a, RolesShared &S)
         if (last) break;
     }
     lds_fence();
-    if (lane == 0) atomicAdd(&S.finished, 1u);
+    atomicAdd(&S.finished, lane == 0 ? 1u : 0u);
 }
 
 __device__ __forceinline__ void roles_hasher(const FusedArgs &a, RolesShared &S) {
@@ -1319,9 +1290,7 @@ __device__ __forceinline__ void roles_hasher(const FusedArgs &a, RolesShared &S)
     HashArgs h = a.h;
     h.pass = PASS_ALL;
     for (;;) {
-        uint32_t take = 0;
-        if (lane == 0) take = atomicAdd(&S.take, 1u);
-        take = uni(__shfl(take, 0));  // every lane holds it: see roles_loader
+        const uint32_t take = uni(atomicAdd(&S.take, lane == 0 ? 1u : 0u));  // every lane executes it: see roles_loader
         bool go = false;
         for (;;) {
             const uint32_t f = lds_ld(&S.finished);  // (read BEFORE ready: a loader's last slots are published before it says so)
@@ -1333,18 +1302,11 @@ __device__ __forceinline__ void roles_hasher(const FusedArgs &a, RolesShared &S)
         asm volatile("" ::: "memory");
         const uint32_t slot = take & (R_SLOTS - 1), grp = slot / R_GROUP;
         const uint32_t nu = lds_ld(&S.nunits[slot]);
-        const bool chk = (a.dbg & 512) && a.dbg_buf;
-        if (chk && lane == 0) {
-            atomicAdd(&a.dbg_buf[2], 1ull);
-            if (lds_ld(&S.cnt[grp]) >= R_GROUP) atomicAdd(&a.dbg_buf[3], 1ull);
-            if (lds_ld(&S.gen[grp]) != take / R_SLOTS) atomicAdd(&a.dbg_buf[4], 1ull);
-        }
         if (nu) {
             const Tile t{lds_ld(&S.first[slot]), nu, 0, lds_ld(&S.nleaves[slot]), 0, 0};
             const uint32_t lu = lane < nu ? lane : 0;
-#ifndef ZN_R_EXT_BY_LOADER
             if (!R_LOADER_EMITS) {
-                // 64 more bytes of each row's period behind its literals (lane = byte; BYTE stores: see the top):
+                // 64 more bytes of each row's period behind its literals (lane = byte):
                 // every row's byte is read first, then all are written — two LDS round trips for the tile
                 uint8_t bytes[WROWS];
 #pragma unroll
@@ -1359,7 +1321,6 @@ __device__ __forceinline__ void roles_hasher(const FusedArgs &a, RolesShared &S)
                 for (uint32_t q = 0; q < WROWS; q++)
                     if (q < nu) S.slots[slot][S.dy[slot][q] + S.dB[slot][q] + S.doff[slot][q] + lane] = bytes[q];
             }
-#endif
             // the rows are stored by the lanes that hash them (their message registers) unless the loader wrote them
             LdsSrc ls{S.slots[slot], S.dy[slot], S.dB[slot], S.doff[slot], WROWS, nullptr,
                       lane < nu ? (uint64_t)S.len[slot][lu] : 0ull, 0ull, S.oo[slot][lu], 1u,
@@ -1386,15 +1347,8 @@ __device__ __forceinline__ void roles_hasher(const FusedArgs &a, RolesShared &S)
             S.tn[slot][lane] = 0u;
         }
         lds_fence();
-        uint32_t old = 0;
-        if (lane == 0) old = atomicAdd(&S.cnt[grp], 1u);
-        old = uni(__shfl(old, 0));
-        if (chk && lane == 0) {
-            if (old >= R_GROUP) atomicAdd(&a.dbg_buf[5], 1ull);
-            if (lds_ld(&S.gen[grp]) != take / R_SLOTS) atomicAdd(&a.dbg_buf[6], 1ull);
-        }
+        const uint32_t old = uni(atomicAdd(&S.cnt[grp], lane == 0 ? 1u : 0u));
         if (old == R_GROUP - 1) {
-            if (chk && lane == 0) atomicAdd(&a.dbg_buf[7], 1ull);
             // this wave hashed the group's last slot: fold the four tiles' parent trees together, write the digests
             asm volatile("" ::: "memory");
             const uint32_t jj = lane >> 4, uu = lane & 15, sl = grp * R_GROUP + jj;
@@ -1448,7 +1402,7 @@ void launch_fused_roles(const FusedArgs &a, int cus, hipStream_t s) {
     const uint32_t want = (a.h.n_tiles + R_GROUP - 1) / R_GROUP;  // one group per workgroup at least
     const uint32_t per_cu = sizeof(RolesShared) > 80 * 1024 ? 1u : 2u;
     uint32_t grid = std::min<uint32_t>((uint32_t)cus * per_cu, want);
-    if (a.lds_pad) grid = std::min<uint32_t>(grid, a.lds_pad);  // experiment: ZNIPPY_LDS_PAD caps the grid
+    if (a.lds_pad) grid = std::min<uint32_t>(grid, a.lds_pad);  // diagnostic: ZNIPPY_LDS_PAD caps the grid (one workgroup = a deterministic ring)
     hipLaunchKernelGGL(k_fused_roles, dim3(grid), dim3(R_WAVES * 64), sizeof(RolesShared), s, a);
 }
 
