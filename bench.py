@@ -129,7 +129,7 @@ def main():
     if archive_kind == "libzstd19":
         sz = int(lens[0])
         chunk = gen.text(sz)
-        frame = np.frombuffer(O.libzstd_compress(chunk, 19), dtype=np.uint8)  # every C2 chunk is this chunk
+        frame = np.frombuffer(workloads.libzstd_compress(chunk, 19), dtype=np.uint8)  # every C2 chunk is this chunk (system libzstd)
         fl = len(frame)
         archives["libzstd19"] = dict(
             d_blobs=torch.from_numpy(np.concatenate([np.tile(frame, my_rows), np.zeros(64, np.uint8)])).cuda(),

@@ -56,3 +56,23 @@ def build(name, torch):
         return dict(d_src=gen_gpu.random_lcg(size), lens=lens, skip=skip,
                     name="500 MiB LCG blob, 8 MiB slices, " + ("store path (random.jar)" if skip is not None else "codec path (random.bin)"))
     raise SystemExit(f"unknown workload {name}")
+
+
+def libzstd_compress(data, level=19) -> bytes:
+    """One zstd frame made by the system's libzstd (ctypes, no oracle involved): the stand-in for what the
+    reference's level-19 codec writes into an archive (common_config.rs:L37).  Input generation only."""
+    import ctypes as C
+    z = C.CDLL("libzstd.so.1")
+    z.ZSTD_compressBound.restype = C.c_size_t
+    z.ZSTD_compressBound.argtypes = [C.c_size_t]
+    z.ZSTD_compress.restype = C.c_size_t
+    z.ZSTD_compress.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int]
+    z.ZSTD_isError.restype = C.c_uint
+    z.ZSTD_isError.argtypes = [C.c_size_t]
+    raw = bytes(data)
+    cap = z.ZSTD_compressBound(len(raw))
+    out = C.create_string_buffer(cap)
+    r = z.ZSTD_compress(out, cap, raw, len(raw), level)
+    if z.ZSTD_isError(r):
+        raise RuntimeError("ZSTD_compress failed")
+    return out.raw[:r]
