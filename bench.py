@@ -202,7 +202,13 @@ def main():
                 self.last = rounds.results_lagged(0)
                 self.pending = 0
 
+    # HIP events in the timed region: around the dominant read kernels (decode_verify_*) for the small-row workloads —
+    # a pair around every one of the step's near-empty follow-up launches costs the stream ~30 us of markers per step
+    # (tools/ab_ktime.sh) — around every kernel otherwise (the dominant kernel of c3/c4store/c5 is not a decode_verify_* one)
+    timed_level = 1 if args.workload in ("c2", "c2small") else 2
+
     def timed(leg, steps, warmup):
+        ctx.set_kernel_timing(timed_level)
         for _ in range(warmup):
             leg.step()
         leg.drain()
@@ -216,6 +222,7 @@ def main():
         # per-kernel durations (HIP events the library records around each launch on its own streams): read back in
         # a few extra, untimed steps so that the event queries are not part of the timed region
         ktimes = {}
+        ctx.set_kernel_timing(2)
         for _ in range(min(steps, 10)):
             leg.step()
             leg.drain()

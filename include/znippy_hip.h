@@ -173,6 +173,10 @@ int znippy_hash_rounds(znippy_ctx *ctx, znippy_rounds *rounds, const void *d_src
 /* ---- measurement hooks (bench.py): device time of the last async call's kernels, by HIP
  * events on the context's stream.  names/ms: up to cap entries; returns the count. */
 int znippy_last_kernel_times(znippy_ctx *ctx, const char **names, float *ms, int cap);
+/* How many of those event pairs a call records: 2 = around every kernel (default), 1 = around the dominant read
+ * kernels only (decode_verify_*), 0 = none (a caller that never asks for kernel times: each pair costs the stream
+ * two markers).  ZNIPPY_KTIME in the environment sets the initial level. */
+int znippy_ctx_set_kernel_timing(znippy_ctx *ctx, int level);
 /* The hash's VALU floor, measured: nanoseconds one 64-lane BLAKE3 compress pass costs a SIMD when nothing else runs
  * (a kernel of compressions only, 4 waves per SIMD on every CU), and the shader clock that kernel held (may be NULL).
  * bench.py prices the read step's passes with it. */

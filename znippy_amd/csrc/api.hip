@@ -62,6 +62,7 @@ struct znippy_ctx {
     // kernel timing
     std::vector<KTime> ktimes;
     int n_ktimes = 0;
+    bool ktime_open = false;
     // page-locked host buffers handed back by destroyed tables: locking pages costs ~1 ms per 4 MB, more than a
     // whole C2 encode pass, so a table takes its result mirror from here when one is big enough
     std::vector<std::pair<size_t, void *>> pinned_pool;
@@ -79,6 +80,7 @@ struct znippy_ctx {
         // ZNIPPY_ROLES_MIN: small tiles from which the role-split persistent kernel takes the table (0 = never; below
         // a few CU-fillings a persistent grid only adds start-up latency)
         unsigned roles_min = 2048;
+        int ktime = 2;  // per-kernel HIP events: 2 = every kernel, 1 = the dominant read kernels only, 0 = none
     } sw;
     int cus = 256;
     unsigned long long *clk_buf = nullptr;  // diagnostic (ZNIPPY_DBG & 32768): shader cycles / 100 MHz ticks of one wave
@@ -96,6 +98,7 @@ static void read_switches(znippy_ctx *ctx) {
     ctx->sw.nohash = on("ZNIPPY_NOHASH");
     ctx->sw.no_roles = on("ZNIPPY_NO_ROLES");
     if (const char *e = getenv("ZNIPPY_ROLES_MIN")) ctx->sw.roles_min = (unsigned)atoi(e);
+    if (const char *e = getenv("ZNIPPY_KTIME")) ctx->sw.ktime = atoi(e);
 }
 
 static void *pinned_take(znippy_ctx *ctx, size_t bytes, size_t *cap) {
@@ -256,9 +259,15 @@ struct znippy_rows {
     uint32_t n_compressed = 0;
     uint64_t *blob_off = nullptr, *blob_size = nullptr, *usize = nullptr, *out_off = nullptr;
     uint8_t *compressed = nullptr, *checksum = nullptr;
+    // One allocation, cleared (or preset) by ONE stream operation per run: [counters 8 x u64][hand-over counts 16 x u32]
+    // [work cursors 16 x u32][pad 64 B][status n x i32]
+    uint8_t *ctl = nullptr;
+    static constexpr size_t CTL_HEAD = 256;
+    size_t ctl_bytes = 0;
     int32_t *status = nullptr;
     uint32_t *digests = nullptr;
-    uint64_t *counters = nullptr;  // 8 x u64 (+ pending_count behind them)
+    uint64_t *counters = nullptr;
+    uint32_t *cursor = nullptr;
     // pinned mirror of the counters, filled by the run's own D2H copy.  Two slots + one event each: run k uses slot
     // k & 1, so the counters of run k can be read while run k + 1 is already executing (znippy_rows_results_lagged)
     uint64_t *h_counters = nullptr;
@@ -272,7 +281,7 @@ struct znippy_rows {
     uint64_t val_base = 0, val_bcap = 0, val_ocap = 0;
     bool val_done = false;
     uint32_t n_bad = 0;
-    int32_t *status_init = nullptr;
+    uint8_t *status_init = nullptr;  // image of ctl with the host-decided statuses (rows_validate)
     bool odd_out = false;  // some stored row's output offset is not a multiple of 16 (store-path kernel variant)
     uint64_t *corrupt = nullptr;
     uint32_t corrupt_cap = 0;
@@ -336,7 +345,12 @@ struct znippy_rounds {
 };
 
 // ------------------------------------------------------------------------------------------------
+static bool ktime_on(const znippy_ctx *ctx, const char *name) {
+    return ctx->sw.ktime >= 2 || (ctx->sw.ktime == 1 && !strncmp(name, "decode_verify_", 14));
+}
 static void ktime_begin(znippy_ctx *ctx, const char *name, hipStream_t on = nullptr) {
+    ctx->ktime_open = ktime_on(ctx, name);
+    if (!ctx->ktime_open) return;
     if ((int)ctx->ktimes.size() <= ctx->n_ktimes) {
         KTime k{name, nullptr, nullptr};
         (void)hipEventCreate(&k.t0);
@@ -347,6 +361,7 @@ static void ktime_begin(znippy_ctx *ctx, const char *name, hipStream_t on = null
     (void)hipEventRecord(ctx->ktimes[ctx->n_ktimes].t0, on ? on : ctx->stream);
 }
 static void ktime_end(znippy_ctx *ctx, hipStream_t on = nullptr) {
+    if (!ctx->ktime_open) return;
     (void)hipEventRecord(ctx->ktimes[ctx->n_ktimes].t1, on ? on : ctx->stream);
     ctx->n_ktimes++;
 }
@@ -458,6 +473,12 @@ int znippy_last_kernel_times(znippy_ctx *ctx, const char **names, float *ms, int
     return n;
 }
 
+int znippy_ctx_set_kernel_timing(znippy_ctx *ctx, int level) {
+    if (!ctx || level < 0 || level > 2) return ZNIPPY_E_INVAL;
+    ctx->sw.ktime = level;
+    return ZNIPPY_OK;
+}
+
 int znippy_measure_blake3_pass_ns(znippy_ctx *ctx, float *ns_per_pass_per_simd, float *shader_ghz) {
     if (!ctx || !ns_per_pass_per_simd) return ZNIPPY_E_INVAL;
     HIPCHK(ctx, hipSetDevice(ctx->device));
@@ -527,7 +548,7 @@ void znippy_rows_destroy(znippy_rows *r) {
     if (!r) return;
     (void)hipSetDevice(r->ctx->device);
     void *ptrs[] = {r->blob_off, r->blob_size, r->usize, r->out_off, r->compressed, r->checksum,
-                    r->status, r->digests, r->counters, r->corrupt, r->list_a, r->pending,
+                    r->ctl, r->digests, r->corrupt, r->list_a, r->pending,
                     r->cand_row, r->cand_base, r->cand_nblocks, r->item_row, r->item_k, r->item_src, r->row_flag, r->pending2,
                     r->bt_tile, r->bt_item, r->tile_done, r->item_done, r->todo, r->status_init, r->slow_list};
     for (void *p : ptrs)
@@ -581,9 +602,9 @@ int znippy_rows_create(znippy_ctx *ctx, const uint64_t *blob_offset, const uint6
         return rc;
     }
     r->corrupt_cap = std::max<uint32_t>(n, 1);
-    if (tmalloc(ctx, &r->status, std::max<size_t>(4 * (size_t)n, 16)) != hipSuccess ||
+    r->ctl_bytes = znippy_rows::CTL_HEAD + std::max<size_t>(4 * (size_t)n, 16);
+    if (tmalloc(ctx, &r->ctl, r->ctl_bytes) != hipSuccess ||
         tmalloc(ctx, &r->digests, std::max<size_t>(32 * (size_t)n, 32)) != hipSuccess ||
-        tmalloc(ctx, &r->counters, 128) != hipSuccess ||  // [counters 8 x u64][pending_count] : one memset per run
         hipHostMalloc(&r->h_counters, 128) != hipSuccess ||
         hipEventCreateWithFlags(&r->ev_done[0], hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&r->ev_done[1], hipEventDisableTiming) != hipSuccess ||
@@ -591,6 +612,10 @@ int znippy_rows_create(znippy_ctx *ctx, const uint64_t *blob_offset, const uint6
         znippy_rows_destroy(r);
         return ZNIPPY_E_NOMEM;
     }
+    r->counters = reinterpret_cast<uint64_t *>(r->ctl);
+    r->pending_count = reinterpret_cast<uint32_t *>(r->ctl + 64);
+    r->cursor = reinterpret_cast<uint32_t *>(r->ctl + 128);
+    r->status = reinterpret_cast<int32_t *>(r->ctl + znippy_rows::CTL_HEAD);
     PlanBuf p;
     build_plan(uncompressed_size + row_begin, n, p);
     if ((rc = upload_plan(ctx, p, r->plan))) {
@@ -670,7 +695,6 @@ int znippy_rows_create(znippy_ctx *ctx, const uint64_t *blob_offset, const uint6
         znippy_rows_destroy(r);
         return rc;
     }
-    r->pending_count = reinterpret_cast<uint32_t *>(r->counters + 8);
     if (tmalloc(ctx, &r->pending, std::max<size_t>(4 * (size_t)n, 16)) != hipSuccess ||
         false) {
         znippy_rows_destroy(r);
@@ -706,8 +730,12 @@ static int rows_validate(znippy_ctx *ctx, znippy_rows *r, uint64_t blob_base, ui
         }
     }
     if (bad) {
-        if (!r->status_init && tmalloc(ctx, &r->status_init, 4 * (size_t)r->n) != hipSuccess) return ZNIPPY_E_NOMEM;
-        HIPCHK(ctx, hipMemcpy(r->status_init, init.data(), 4 * (size_t)r->n, hipMemcpyHostToDevice));
+        // image of the whole control block: zero head + the preset status column
+        if (!r->status_init) {
+            if (tmalloc(ctx, &r->status_init, r->ctl_bytes) != hipSuccess) return ZNIPPY_E_NOMEM;
+            HIPCHK(ctx, hipMemset(r->status_init, 0, r->ctl_bytes));
+        }
+        HIPCHK(ctx, hipMemcpy(r->status_init + znippy_rows::CTL_HEAD, init.data(), 4 * (size_t)r->n, hipMemcpyHostToDevice));
     }
     r->n_bad = bad;
     r->val_base = blob_base; r->val_bcap = r->blob_cap; r->val_ocap = out_cap;
@@ -725,11 +753,9 @@ int znippy_decode_verify_rows_async(znippy_ctx *ctx, znippy_rows *r, const void 
     { const int rc0 = ensure_decoder(ctx); if (rc0) return rc0; }
     { const int rc0 = rows_validate(ctx, r, blob_base, out_cap); if (rc0) return rc0; }
     const int preset = r->n_bad ? 1 : 0;
-    if (preset) HIPCHK(ctx, hipMemcpyAsync(r->status, r->status_init, 4 * (size_t)r->n, hipMemcpyDeviceToDevice, s));
-    else
-    HIPCHK(ctx, hipMemsetAsync(r->status, 0, std::max<size_t>(4 * (size_t)r->n, 16), s));
-    HIPCHK(ctx, hipMemsetAsync(r->counters, 0, 128, s));  // counters + pending_count
-    HIPCHK(ctx, hipMemsetAsync(ctx->cursor, 0, 64, s));
+    // counters, hand-over counts, work cursors and the status column: one stream operation
+    if (preset) HIPCHK(ctx, hipMemcpyAsync(r->ctl, r->status_init, r->ctl_bytes, hipMemcpyDeviceToDevice, s));
+    else HIPCHK(ctx, hipMemsetAsync(r->ctl, 0, r->ctl_bytes, s));
     if (!r->n) { r->run_seq++; return ZNIPPY_OK; }
     // 1) fused small-row kernel: decode simple frames + hash (+ copy stored rows), one wave per tile
     HashArgs h{};
@@ -773,7 +799,7 @@ int znippy_decode_verify_rows_async(znippy_ctx *ctx, znippy_rows *r, const void 
         const bool roles = !ctx->sw.no_roles && ctx->sw.roles_min != 0 && r->n_small_tiles >= ctx->sw.roles_min && r->n_small_tiles > 0 &&
                            !(f.dbg & (1 | 2 | 4 | 8 | 128));
         if (roles) {
-            f.cursor = ctx->cursor + 2;
+            f.cursor = r->cursor + 2;
             f.tile_list = r->slow_list;
             f.tile_count = r->pending_count + 3;
             ktime_begin(ctx, "decode_verify_roles");
@@ -832,7 +858,7 @@ int znippy_decode_verify_rows_async(znippy_ctx *ctx, znippy_rows *r, const void 
         a.blob_off = r->blob_off; a.blob_size = r->blob_size; a.usize = r->usize; a.out_off = r->out_off;
         a.compressed = r->compressed;
         a.out = (uint8_t *)d_out; a.out_cap = out_cap;
-        a.status = r->status; a.n_rows = r->n; a.cursor = ctx->cursor + 4;
+        a.status = r->status; a.n_rows = r->n; a.cursor = r->cursor + 4;
         a.lit_scratch = ctx->lit_scratch_b;
         if (ctx->sw.ddbg) {  // diagnostic: phase shares of the previous block-item launch
             static unsigned long long *dbg = nullptr;
@@ -861,7 +887,7 @@ int znippy_decode_verify_rows_async(znippy_ctx *ctx, znippy_rows *r, const void 
         a.blob_off = r->blob_off; a.blob_size = r->blob_size; a.usize = r->usize; a.out_off = r->out_off;
         a.compressed = r->compressed;
         a.out = (uint8_t *)d_out; a.out_cap = out_cap;
-        a.status = r->status; a.n_rows = r->n; a.cursor = ctx->cursor;
+        a.status = r->status; a.n_rows = r->n; a.cursor = r->cursor;
         a.lit_scratch = ctx->lit_scratch;
         ktime_begin(ctx, "zstd_decode_general");
         launch_decode(a, std::min<int>(ctx->decode_grid, (int)r->n_compressed), r->wide_rows, s);
@@ -871,7 +897,7 @@ int znippy_decode_verify_rows_async(znippy_ctx *ctx, znippy_rows *r, const void 
             launch_finish_blocks(b, s);
             a.list_a = nullptr; a.n_list_a = 0;
             a.pending = r->pending2; a.pending_count = r->pending_count + 1;
-            a.cursor = ctx->cursor + 8;
+            a.cursor = r->cursor + 8;
             ktime_begin(ctx, "zstd_decode_fallback");
             launch_decode(a, std::min<int>(ctx->decode_grid, (int)r->n_cand), r->wide_rows, s);
             ktime_end(ctx);

@@ -67,6 +67,10 @@ class Context:
         n = self.L.znippy_last_kernel_times(self.h, names, ms, 16)
         return [(names[i].decode(), float(ms[i])) for i in range(n)]
 
+    def set_kernel_timing(self, level):
+        """2 = HIP events around every kernel (default), 1 = around the dominant read kernels only, 0 = none."""
+        self._chk(self.L.znippy_ctx_set_kernel_timing(self.h, int(level)), "znippy_ctx_set_kernel_timing")
+
     def blake3_pass_ns(self):
         """Measured VALU floor: ns per 64-lane compress pass per SIMD (compressions only, nothing else running)."""
         v, g = C.c_float(), C.c_float()
