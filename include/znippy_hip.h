@@ -177,6 +177,10 @@ int znippy_last_kernel_times(znippy_ctx *ctx, const char **names, float *ms, int
  * kernels only (decode_verify_*), 0 = none (a caller that never asks for kernel times: each pair costs the stream
  * two markers).  ZNIPPY_KTIME in the environment sets the initial level. */
 int znippy_ctx_set_kernel_timing(znippy_ctx *ctx, int level);
+/* Statistics of the last run's two-phase path for foreign multi-block frames (frames another zstd writer produced;
+ * codec.rs:L67-78 decodes whatever the archive holds): stats[0] literal-pool bytes and stats[1] sequence-pool records
+ * handed out, stats[2] frames decoded by that path, stats[3] blocks it left to the serial decoder.  Synchronises. */
+int znippy_rows_foreign_stats(znippy_ctx *ctx, znippy_rows *rows, uint64_t stats[4]);
 /* The hash's VALU floor, measured: nanoseconds one 64-lane BLAKE3 compress pass costs a SIMD when nothing else runs
  * (a kernel of compressions only, 4 waves per SIMD on every CU), and the shader clock that kernel held (may be NULL).
  * bench.py prices the read step's passes with it. */

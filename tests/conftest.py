@@ -50,3 +50,24 @@ def gpu_ctx_roles():
             os.environ["ZNIPPY_ROLES_MIN"] = old
     yield ctx
     ctx.close()
+
+
+@pytest.fixture(scope="session")
+def gpu_ctx_fz_only():
+    """A context with NO serial fallback behind the two-phase foreign-frame path (ZNIPPY_FZ_ONLY=1): a frame that path
+    does not finish shows up as a corrupt row, so a clean result proves the two-phase kernels decoded it."""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from znippy_amd import hip
+    old = os.environ.get("ZNIPPY_FZ_ONLY")
+    os.environ["ZNIPPY_FZ_ONLY"] = "1"
+    try:
+        ctx = hip.Context(0)
+    finally:
+        if old is None:
+            del os.environ["ZNIPPY_FZ_ONLY"]
+        else:
+            os.environ["ZNIPPY_FZ_ONLY"] = old
+    yield ctx
+    ctx.close()

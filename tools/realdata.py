@@ -71,7 +71,7 @@ def run(kind, cap):
             ts.append(time.perf_counter() - t0)
         ok = bool((d_out[:total] == d_src[:total]).all())
         print(f"[{kind}] GPU decode+verify of {name}: {min(ts)*1e3:.2f} ms ({total/2**20/min(ts):.0f} MB/s) ok={ok} corrupt={c['corrupt_rows']} errs={c['decode_errors']}",
-              dict(ctx.kernel_times()))
+              dict(ctx.kernel_times()), "foreign path:", rows.foreign_stats())
     # where the time goes: the many small frames vs the single largest one (one workgroup decodes one frame)
     bo, bs, ck = res[19]["blob_offset"], res[19]["blob_size"], res[19]["checksum"]
     blobs19 = torch.from_numpy(np.concatenate([res[19]["blobs"], np.zeros(64, np.uint8)])).cuda()

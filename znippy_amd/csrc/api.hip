@@ -58,6 +58,11 @@ struct znippy_ctx {
     hipStream_t aux = nullptr;
     hipStream_t copy = nullptr;  // result read-back of the write side (D2H beside the next run's kernels)
     uint8_t *lit_scratch_b = nullptr;  // literal scratch of the block-item launch (runs next to the general decoder)
+    // pools of the two-phase path for foreign frames: decoded literals and 8-byte sequence records of every block of
+    // every candidate frame of a run (grow-only, sized by the largest table seen; see ensure_fz_pools)
+    uint8_t *fz_lit_pool = nullptr;
+    unsigned long long *fz_seq_pool = nullptr;
+    uint64_t fz_lit_cap = 0, fz_seq_cap = 0;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     // kernel timing
     std::vector<KTime> ktimes;
@@ -76,7 +81,7 @@ struct znippy_ctx {
         int dbg = 0;             // ZNIPPY_DBG bit set (FusedArgs::dbg)
         unsigned lds_pad = 0;    // ZNIPPY_LDS_PAD
         bool no_block_items = false, no_fused_blocks = false, ddbg = false, edbg = false, no_fused_store = false,
-             nohash = false, no_roles = false;
+             nohash = false, no_roles = false, no_fz = false, fz_only = false;
         // ZNIPPY_ROLES_MIN: small tiles from which the role-split persistent kernel takes the table (0 = never; below
         // a few CU-fillings a persistent grid only adds start-up latency)
         unsigned roles_min = 2048;
@@ -97,6 +102,8 @@ static void read_switches(znippy_ctx *ctx) {
     ctx->sw.no_fused_store = on("ZNIPPY_NO_FUSED_STORE");
     ctx->sw.nohash = on("ZNIPPY_NOHASH");
     ctx->sw.no_roles = on("ZNIPPY_NO_ROLES");
+    ctx->sw.no_fz = on("ZNIPPY_NO_FZ");
+    ctx->sw.fz_only = on("ZNIPPY_FZ_ONLY");  // test hook: no serial fallback behind the two-phase path (what it leaves shows up as corrupt rows)
     if (const char *e = getenv("ZNIPPY_ROLES_MIN")) ctx->sw.roles_min = (unsigned)atoi(e);
     if (const char *e = getenv("ZNIPPY_KTIME")) ctx->sw.ktime = atoi(e);
 }
@@ -293,6 +300,12 @@ struct znippy_rows {
     // block items: compressed rows of >= 2 blocks are tried block by block first
     uint32_t n_cand = 0, n_items = 0;
     uint32_t *cand_row = nullptr, *cand_base = nullptr, *cand_nblocks = nullptr, *pending2 = nullptr;
+    // two-phase path for the candidates the block-item path gives up on (foreign frames): item slots per candidate
+    // (2 x the expected blocks + 8: a writer may split blocks), the work list of the run, pool demand
+    uint32_t *fz_base = nullptr, *fz_cap = nullptr, *fz_it_cand = nullptr, *fz_nb = nullptr, *fz_work = nullptr;
+    zn::FzItem *fz_items = nullptr;
+    uint32_t fz_total = 0;
+    uint64_t fz_bytes = 0;  // content bytes of all candidates
     uint32_t *item_row = nullptr, *item_k = nullptr, *item_src = nullptr, *row_flag = nullptr;
     // fused block kernel: big-slice tiles of the candidate rows, the item each belongs to, and what it got done
     uint32_t n_bt = 0;
@@ -380,6 +393,31 @@ static int ensure_decoder(znippy_ctx *ctx) {
     if (hipMalloc(&ctx->lit_scratch, decode_lit_scratch_bytes(ctx->decode_grid)) != hipSuccess) return ZNIPPY_E_NOMEM;
     return ZNIPPY_OK;
 }
+// Pools of the two-phase foreign-frame path.  Literals: a block's literals never exceed what it regenerates, so the
+// candidates' content bytes (+ 80 bytes of slack per item) always suffice.  Sequence records (8 bytes each): real data
+// runs at one sequence per 8-20 bytes; 1.5 bytes of pool per content byte covers one per 5.3 bytes, and a block that
+// finds the pool empty simply stays with the serial decoder.  Both are capped (a 100 GB archive does not get 250 GB
+// of scratch): what does not fit is decoded serially.
+static int ensure_fz_pools(znippy_ctx *ctx, uint64_t content_bytes, uint32_t items) {
+    constexpr uint64_t CAP = 48ull << 30;
+    const uint64_t lit = std::min<uint64_t>(content_bytes + 80ull * items + 4096, CAP);
+    const uint64_t seq = std::min<uint64_t>(content_bytes * 3 / 2 + 4096, CAP) / 8;
+    if (lit > ctx->fz_lit_cap) {
+        (void)hipStreamSynchronize(ctx->stream);
+        if (ctx->fz_lit_pool) (void)hipFree(ctx->fz_lit_pool);
+        ctx->fz_lit_pool = nullptr; ctx->fz_lit_cap = 0;
+        if (hipMalloc(&ctx->fz_lit_pool, lit) != hipSuccess) { (void)hipGetLastError(); ctx->fz_lit_pool = nullptr; return ZNIPPY_OK; }  // no pool: the serial decoder keeps the frames
+        ctx->fz_lit_cap = lit;
+    }
+    if (seq > ctx->fz_seq_cap) {
+        (void)hipStreamSynchronize(ctx->stream);
+        if (ctx->fz_seq_pool) (void)hipFree(ctx->fz_seq_pool);
+        ctx->fz_seq_pool = nullptr; ctx->fz_seq_cap = 0;
+        if (hipMalloc(&ctx->fz_seq_pool, seq * 8) != hipSuccess) { (void)hipGetLastError(); ctx->fz_seq_pool = nullptr; return ZNIPPY_OK; }
+        ctx->fz_seq_cap = seq;
+    }
+    return ZNIPPY_OK;
+}
 static int ensure_encoder(znippy_ctx *ctx) {
     if (ctx->enc_tabs) return ZNIPPY_OK;
     EncTables t;
@@ -437,6 +475,8 @@ void znippy_ctx_destroy(znippy_ctx *ctx) {
     for (auto &k : ctx->ktimes) { (void)hipEventDestroy(k.t0); (void)hipEventDestroy(k.t1); }
     if (ctx->lit_scratch) (void)hipFree(ctx->lit_scratch);
     if (ctx->lit_scratch_b) (void)hipFree(ctx->lit_scratch_b);
+    if (ctx->fz_lit_pool) (void)hipFree(ctx->fz_lit_pool);
+    if (ctx->fz_seq_pool) (void)hipFree(ctx->fz_seq_pool);
     if (ctx->cursor) (void)hipFree(ctx->cursor);
     if (ctx->shim_in) (void)hipFree(ctx->shim_in);
     if (ctx->shim_out) (void)hipFree(ctx->shim_out);
@@ -471,6 +511,14 @@ int znippy_last_kernel_times(znippy_ctx *ctx, const char **names, float *ms, int
         (void)hipEventElapsedTime(&ms[i], ctx->ktimes[i].t0, ctx->ktimes[i].t1);
     }
     return n;
+}
+
+int znippy_rows_foreign_stats(znippy_ctx *ctx, znippy_rows *r, uint64_t stats[4]) {
+    if (!ctx || !r || r->ctx != ctx || !stats) return ZNIPPY_E_INVAL;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    HIPCHK(ctx, hipMemcpy(stats, r->ctl + 192, 32, hipMemcpyDeviceToHost));
+    return ZNIPPY_OK;
 }
 
 int znippy_ctx_set_kernel_timing(znippy_ctx *ctx, int level) {
@@ -549,7 +597,7 @@ void znippy_rows_destroy(znippy_rows *r) {
     (void)hipSetDevice(r->ctx->device);
     void *ptrs[] = {r->blob_off, r->blob_size, r->usize, r->out_off, r->compressed, r->checksum,
                     r->ctl, r->digests, r->corrupt, r->list_a, r->pending,
-                    r->cand_row, r->cand_base, r->cand_nblocks, r->item_row, r->item_k, r->item_src, r->row_flag, r->pending2,
+                    r->cand_row, r->cand_base, r->cand_nblocks, r->fz_base, r->fz_cap, r->fz_it_cand, r->fz_nb, r->fz_work, r->fz_items, r->item_row, r->item_k, r->item_src, r->row_flag, r->pending2,
                     r->bt_tile, r->bt_item, r->tile_done, r->item_done, r->todo, r->status_init, r->slow_list};
     for (void *p : ptrs)
         tfree(r->ctx, p);
@@ -630,7 +678,7 @@ int znippy_rows_create(znippy_ctx *ctx, const uint64_t *blob_offset, const uint6
     // compressed rows above 64 KiB: frames of >= 2 blocks (and < 4 GiB) are tried block by block (each block a work
     // item), the others go straight to the general decoder
     constexpr uint64_t BLK = 128 * 1024;
-    std::vector<uint32_t> la, cand_row, cand_base, cand_nb, item_row, item_k;
+    std::vector<uint32_t> la, cand_row, cand_base, cand_nb, item_row, item_k, fz_base, fz_cap, fz_it_cand;
     uint64_t big_bytes = 0, big_blob = 0, n_big = 0;
     for (uint32_t i = 0; i < n; i++) {
         const uint64_t us = uncompressed_size[row_begin + i];
@@ -644,6 +692,13 @@ int znippy_rows_create(znippy_ctx *ctx, const uint64_t *blob_offset, const uint6
             cand_base.push_back((uint32_t)item_row.size());
             cand_nb.push_back((uint32_t)nb);
             for (uint32_t k = 0; k < nb; k++) { item_row.push_back(i); item_k.push_back(k); }
+            if (!ctx->sw.no_fz && fz_it_cand.size() + 2 * nb + 8 < 0x7FFFFFFFull) {
+                const uint32_t cap = (uint32_t)(2 * nb + 8);
+                fz_base.push_back((uint32_t)fz_it_cand.size());
+                fz_cap.push_back(cap);
+                fz_it_cand.insert(fz_it_cand.end(), cap, (uint32_t)cand_row.size() - 1);
+                r->fz_bytes += us;
+            } else { fz_base.push_back(0); fz_cap.push_back(0); }
         } else la.push_back(i);
     }
     r->n_list_a = (uint32_t)la.size();
@@ -666,6 +721,20 @@ int znippy_rows_create(znippy_ctx *ctx, const uint64_t *blob_offset, const uint6
             tmalloc(ctx, &r->pending2, std::max<size_t>(4 * (size_t)r->n_cand, 16)) != hipSuccess) {
             znippy_rows_destroy(r);
             return ZNIPPY_E_NOMEM;
+        }
+        r->fz_total = (uint32_t)fz_it_cand.size();
+        if (r->fz_total) {
+            if ((rc = dev_upload(ctx, &r->fz_base, fz_base.data(), fz_base.size())) ||
+                (rc = dev_upload(ctx, &r->fz_cap, fz_cap.data(), fz_cap.size())) ||
+                (rc = dev_upload(ctx, &r->fz_it_cand, fz_it_cand.data(), fz_it_cand.size()))) {
+                znippy_rows_destroy(r);
+                return rc;
+            }
+            if (tmalloc(ctx, &r->fz_nb, 4 * (size_t)r->n_cand) != hipSuccess || tmalloc(ctx, &r->fz_work, 4 * (size_t)r->fz_total) != hipSuccess ||
+                tmalloc(ctx, &r->fz_items, sizeof(zn::FzItem) * (size_t)r->fz_total) != hipSuccess) {
+                znippy_rows_destroy(r);
+                return ZNIPPY_E_NOMEM;
+            }
         }
     }
     if (r->n_cand && !ctx->sw.no_fused_blocks) {
@@ -752,6 +821,7 @@ int znippy_decode_verify_rows_async(znippy_ctx *ctx, znippy_rows *r, const void 
     ctx->n_ktimes = 0;
     { const int rc0 = ensure_decoder(ctx); if (rc0) return rc0; }
     { const int rc0 = rows_validate(ctx, r, blob_base, out_cap); if (rc0) return rc0; }
+    if (r->fz_total) { const int rc0 = ensure_fz_pools(ctx, r->fz_bytes, r->fz_total); if (rc0) return rc0; }
     const int preset = r->n_bad ? 1 : 0;
     // counters, hand-over counts, work cursors and the status column: one stream operation
     if (preset) HIPCHK(ctx, hipMemcpyAsync(r->ctl, r->status_init, r->ctl_bytes, hipMemcpyDeviceToDevice, s));
@@ -894,11 +964,31 @@ int znippy_decode_verify_rows_async(znippy_ctx *ctx, znippy_rows *r, const void 
         ktime_end(ctx);
         if (r->n_cand) {  // join, then the frames the block path gave up on
             HIPCHK(ctx, hipStreamWaitEvent(s, ctx->ev_join, 0));
+            if (r->fz_total) {  // foreign frames: entropy-decode every block at once, then execute frame by frame
+                FzArgs z{};
+                z.cand_row = r->cand_row; z.cand_fzbase = r->fz_base; z.cand_fzcap = r->fz_cap; z.n_cand = r->n_cand;
+                z.it_cand = r->fz_it_cand; z.total_items = r->fz_total; z.cand_nb = r->fz_nb; z.items = r->fz_items;
+                z.blobs = (const uint8_t *)d_blobs; z.blob_base = blob_base;
+                z.blob_off = r->blob_off; z.blob_size = r->blob_size; z.usize = r->usize; z.out_off = r->out_off; z.out_cap = out_cap;
+                z.out = (uint8_t *)d_out;
+                z.row_flag = r->row_flag; z.status = r->status; z.preset = preset;
+                z.lit_pool = ctx->fz_lit_pool; z.lit_cap = ctx->fz_lit_cap; z.seq_pool = ctx->fz_seq_pool; z.seq_cap = ctx->fz_seq_cap;
+                z.pool_used = reinterpret_cast<unsigned long long *>(r->ctl + 192);  // [lit bytes, seq records], zeroed with the control block
+                z.cursor = r->cursor + 12;
+                launch_fz_scan(z, r->fz_work, r->cursor + 13, s);
+                ktime_begin(ctx, "zstd_foreign_entropy");
+                launch_fz_entropy(z, ctx->cus, r->fz_work, r->cursor + 13, s);
+                ktime_end(ctx);
+                ktime_begin(ctx, "zstd_foreign_execute");
+                launch_fz_exec(z, s);
+                ktime_end(ctx);
+            }
             launch_finish_blocks(b, s);
             a.list_a = nullptr; a.n_list_a = 0;
             a.pending = r->pending2; a.pending_count = r->pending_count + 1;
             a.cursor = r->cursor + 8;
             ktime_begin(ctx, "zstd_decode_fallback");
+            if (!ctx->sw.fz_only)
             launch_decode(a, std::min<int>(ctx->decode_grid, (int)r->n_cand), r->wide_rows, s);
             ktime_end(ctx);
         }

@@ -154,4 +154,44 @@ void launch_scan_blocks(const BlockScanArgs &a, hipStream_t s);
 void launch_compact_items(const uint8_t *item_done, uint32_t n_items, uint32_t *todo, uint32_t *n_todo, hipStream_t s);
 void launch_finish_blocks(const BlockScanArgs &a, hipStream_t s);
 
+// Foreign frames in two phases (zstd_decode.hip, k_fz_*): frames of >= 2 blocks that the block-item path gave up on
+// (another writer's frames: repeat offsets, reused entropy tables, matches reaching into earlier blocks, any block
+// size) are decoded block-PARALLEL where the format allows it — every block's literals and sequences are entropy-
+// decoded by its own workgroup into scratch pools — and only the byte-moving sequence execution walks a frame in order.
+struct FzItem {
+    uint32_t src;       // offset of the block header inside the frame (written by the scan)
+    uint32_t out;       // bytes the block regenerates
+    uint32_t nseq;
+    uint32_t lit_len;
+    uint64_t seq_off;   // first record in the sequence pool
+    uint64_t lit_off;   // lit_kind 0: offset inside the frame's blob; 1: the byte; 2: offset in the literal pool
+    uint32_t lit_kind;
+    int32_t err;        // != 0: this block needs the serial decoder (which also produces the error code)
+};
+struct FzArgs {
+    const uint32_t *cand_row, *cand_fzbase, *cand_fzcap;  // candidate -> row, first item slot, item slots
+    uint32_t n_cand;
+    const uint32_t *it_cand;  // item slot -> candidate
+    uint32_t total_items;
+    uint32_t *cand_nb;        // blocks found per candidate (0: not taken by this path)
+    FzItem *items;
+    const uint8_t *blobs;
+    uint64_t blob_base;
+    const uint64_t *blob_off, *blob_size, *usize, *out_off;
+    uint64_t out_cap;
+    uint8_t *out;
+    uint32_t *row_flag;       // in: != 0 = the block-item path gave up; out: 0 once the frame is decoded here
+    const int32_t *status;
+    int preset;
+    uint8_t *lit_pool;
+    uint64_t lit_cap;         // bytes
+    unsigned long long *seq_pool;
+    uint64_t seq_cap;         // records
+    unsigned long long *pool_used;  // [0] literal bytes, [1] sequence records handed out, [2] frames decoded, [3] blocks given up (zeroed per run)
+    uint32_t *cursor;
+};
+void launch_fz_scan(const FzArgs &a, uint32_t *work, uint32_t *work_count, hipStream_t s);
+void launch_fz_entropy(const FzArgs &a, int cus, const uint32_t *work, const uint32_t *work_count, hipStream_t s);
+void launch_fz_exec(const FzArgs &a, hipStream_t s);
+
 }  // namespace zn

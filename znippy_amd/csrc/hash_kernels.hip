@@ -162,25 +162,28 @@ __global__ __launch_bounds__(256) void k_verify(const uint32_t *digests, const u
                                                 const uint64_t *usize, const int32_t *status, uint32_t n_rows,
                                                 uint64_t row_begin, unsigned long long *counters,
                                                 uint64_t *corrupt_rows, uint32_t corrupt_cap) {
-    const uint32_t r = blockIdx.x * 256 + threadIdx.x;
     unsigned long long v[6] = {0, 0, 0, 0, 0, 0};
-    if (r < n_rows) {
-        v[0] = 1;
+    // grid-stride: a few dozen workgroups, so that the counters' cache line takes a few hundred atomics per run
+    // (one workgroup per 256 rows put 1,200 on it for 100k rows: ~13 us of the step)
+    for (uint32_t r = blockIdx.x * 256 + threadIdx.x; r < n_rows; r += gridDim.x * 256) {
+        v[0] += 1;
         if (status && status[r] < 0) {
-            v[5] = 1;
+            v[5] += 1;
         } else {
             const unsigned long long len = usize[r];
-            v[1] = len;
+            v[1] += len;
             bool ok = true;
             if (checksum) {
-                const uint32_t *want = reinterpret_cast<const uint32_t *>(checksum) + (size_t)r * 8;
-#pragma unroll
-                for (int i = 0; i < 8; i++) ok = ok && (want[i] == digests[(size_t)r * 8 + i]);
+                const uint4 *want = reinterpret_cast<const uint4 *>(checksum) + (size_t)r * 2;
+                const uint4 *got = reinterpret_cast<const uint4 *>(digests) + (size_t)r * 2;
+                const uint4 w0 = want[0], w1 = want[1], g0 = got[0], g1 = got[1];
+                ok = w0.x == g0.x && w0.y == g0.y && w0.z == g0.z && w0.w == g0.w &&
+                     w1.x == g1.x && w1.y == g1.y && w1.z == g1.z && w1.w == g1.w;
             }
-            if (ok) v[2] = len;
+            if (ok) v[2] += len;
             else {
-                v[3] = len;
-                v[4] = 1;
+                v[3] += len;
+                v[4] += 1;
                 unsigned long long slot = atomicAdd(&counters[6], 1ull);
                 if (corrupt_rows && slot < corrupt_cap) corrupt_rows[slot] = row_begin + r;
             }
@@ -205,7 +208,7 @@ void launch_verify(const uint32_t *digests, const uint8_t *checksum, const uint6
                    const int32_t *status, uint32_t n_rows, uint64_t row_begin, uint64_t *counters,
                    uint64_t *corrupt_rows, uint32_t corrupt_cap, hipStream_t s) {
     if (!n_rows) return;
-    hipLaunchKernelGGL(k_verify, dim3((n_rows + 255) / 256), dim3(256), 0, s, digests, checksum, usize, status,
+    hipLaunchKernelGGL(k_verify, dim3(std::min<uint32_t>((n_rows + 255) / 256, 128)), dim3(256), 0, s, digests, checksum, usize, status,
                        n_rows, row_begin, reinterpret_cast<unsigned long long *>(counters), corrupt_rows, corrupt_cap);
 }
 

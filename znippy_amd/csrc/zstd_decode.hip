@@ -1446,6 +1446,649 @@ void launch_finish_blocks(const BlockScanArgs &a, hipStream_t s) {
     if (a.n_cand) hipLaunchKernelGGL(k_finish_blocks, dim3((a.n_cand + 63) / 64), dim3(64), 0, s, a);
 }
 
+// =============================================================================================
+// Foreign frames in two phases.  A frame of >= 2 blocks that the block-item path gave up on (another writer's
+// frame: repeat offsets, entropy tables reused from earlier blocks, matches that reach into earlier blocks, blocks
+// of any size) used to be decoded by ONE workgroup from front to back.  Most of that work does not depend on the
+// bytes in front of the block: Huffman-decoding the literals and FSE-decoding the sequences need only the block's own
+// section (plus, for Treeless / Repeat_Mode, the table description of an earlier block, which is re-read).  So:
+//   k_fz_scan     one wave per frame: frame header, then the chain of block headers -> one item per block
+//   k_fz_entropy  one workgroup (2 waves) per BLOCK, all blocks of all frames at once: wave 0 reads the Huffman tree
+//                 and decodes the literal streams into the literal pool, wave 1 builds the FSE tables and decodes the
+//                 sequences into 8-byte records {literal length, match length, offset value} in the sequence pool
+//   k_fz_exec     one wave per frame, blocks in order: repeat offsets, bounds, and the byte-moving execution — 64
+//                 sequences at a time, one per lane, inside an LDS window that is streamed out in whole chunks
+// Anything unexpected (a checksum trailer, an offset past 2^29, pools exhausted, an error of any kind) leaves the
+// frame flagged: the serial decoder then takes it and produces the error code.
+// =============================================================================================
+constexpr uint32_t FZ_BACK = 16;  // how far back a Treeless / Repeat_Mode block looks for its table
+
+struct FzTmp {  // scratch of fse_read_ncount / fse_build / huf_read_tree: one per wave
+    int16_t norm[256];
+    uint16_t fse_next[256];
+    uint8_t fse_sym[512];
+    uint8_t weights[256];
+    uint16_t sym_start[256];
+    uint16_t sym_len[256];
+    uint32_t seq_ll[128];  // 64 FseEntry: the FSE table of the Huffman weights
+    uint32_t huf_log;
+};
+
+struct FzShared {
+    FseEntry ll[512], ml[512], of[256];
+    FseEntry dll[64], dml[64], dof[32];
+    FseEntry rle[3];
+    uint16_t huf[2048];
+    FzTmp ta, tb;
+    uint32_t claim;
+    int32_t err;
+    uint32_t lit_type, lit_kind, lit_len, lit_rle, lit_hdr, lit_comp;
+    uint64_t lit_off;
+    uint32_t n_streams, stream_off[4], stream_len[4], stream_out[4], stream_n[4];
+    uint32_t seq_pos;  // where the sequences section starts inside the block
+    uint32_t sel[3], log_[3];
+    uint32_t nseq, bs_off, st_ll, st_of, st_ml;
+    int32_t bs_pos;
+    uint64_t seq_off;
+    uint32_t sum_ll, sum_ml;
+};
+
+struct LitHdr { uint32_t type, regen, comp, hdr, streams; };
+
+// Literals_Section_Header (RFC 8878 §3.1.1.3.1.1) of the block content [b, b + n)
+__device__ int fz_lit_header(const uint8_t *b, uint32_t n, LitHdr &h) {
+    if (n < 1) return E_TRUNC;
+    const uint32_t b0 = b[0], sf = (b0 >> 2) & 3;
+    h.type = b0 & 3; h.comp = 0; h.streams = 0;
+    if (h.type <= 1) {
+        if ((sf & 1) == 0) { h.regen = b0 >> 3; h.hdr = 1; }
+        else if (sf == 1) { if (n < 2) return E_TRUNC; h.regen = (b0 >> 4) + ((uint32_t)b[1] << 4); h.hdr = 2; }
+        else { if (n < 3) return E_TRUNC; h.regen = (b0 >> 4) + ((uint32_t)b[1] << 4) + ((uint32_t)b[2] << 12); h.hdr = 3; }
+        if (h.regen > BLOCK_MAX) return E_CORRUPT;
+        if (h.hdr + (h.type == 0 ? h.regen : 1u) > n) return E_TRUNC;
+        return 0;
+    }
+    uint64_t v = 0;
+    for (uint32_t i = 0; i < 5 && i < n; i++) v |= (uint64_t)b[i] << (8 * i);
+    if (sf == 0) { h.streams = 1; h.regen = (v >> 4) & 0x3FF; h.comp = (v >> 14) & 0x3FF; h.hdr = 3; }
+    else if (sf == 1) { h.streams = 4; h.regen = (v >> 4) & 0x3FF; h.comp = (v >> 14) & 0x3FF; h.hdr = 3; }
+    else if (sf == 2) { h.streams = 4; h.regen = (v >> 4) & 0x3FFF; h.comp = (v >> 18) & 0x3FFF; h.hdr = 4; }
+    else { h.streams = 4; h.regen = (v >> 4) & 0x3FFFF; h.comp = (v >> 22) & 0x3FFFF; h.hdr = 5; }
+    if (h.hdr + h.comp > n) return E_TRUNC;
+    if (h.regen > BLOCK_MAX) return E_CORRUPT;
+    return 0;
+}
+__device__ __forceinline__ uint32_t fz_lit_section_bytes(const LitHdr &h) {
+    return h.hdr + (h.type == 0 ? h.regen : (h.type == 1 ? 1u : h.comp));
+}
+
+__global__ __launch_bounds__(64) void k_fz_scan(FzArgs a, uint32_t *work, uint32_t *work_count) {
+    // one wave per candidate frame; every lane walks the same addresses (broadcast loads)
+    const uint32_t c = blockIdx.x, lane = threadIdx.x;
+    if (c >= a.n_cand) return;
+    const uint32_t row = a.cand_row[c], base = a.cand_fzbase[c], cap = a.cand_fzcap[c];
+    uint32_t nb = 0;
+    if (a.row_flag[row] != 0 && !(a.preset && a.status[row] < 0)) {
+        const uint8_t *src = a.blobs + (a.blob_off[row] - a.blob_base);
+        const uint64_t n = a.blob_size[row], fcs_want = a.usize[row];
+        bool ok = n >= 9 && n < 0xFFFF0000ull && (src[0] | (src[1] << 8) | (src[2] << 16) | ((uint32_t)src[3] << 24)) == 0xFD2FB528u;
+        uint64_t pos = 5;
+        if (ok) {
+            const uint32_t fhd = src[4];
+            const uint32_t fcs_flag = fhd >> 6, single = (fhd >> 5) & 1, did_flag = fhd & 3;
+            const uint32_t fcs_bytes = fcs_flag == 0 ? single : (1u << fcs_flag);
+            ok = !(fhd & 8) && !((fhd >> 2) & 1) && did_flag == 0 && fcs_bytes != 0;  // a checksum trailer is the serial decoder's
+            if (ok) {
+                if (!single) pos++;
+                ok = pos + fcs_bytes <= n;
+                uint64_t fcs = 0;
+                for (uint32_t i = 0; ok && i < fcs_bytes; i++) fcs |= (uint64_t)src[pos + i] << (8 * i);
+                if (fcs_bytes == 2) fcs += 256;
+                pos += fcs_bytes;
+                ok = ok && fcs == fcs_want && fcs < 0xFFFFFFFFull && a.out_off[row] + fcs <= a.out_cap;
+            }
+        }
+        uint32_t k = 0;
+        bool last = false;
+        while (ok && !last) {
+            if (k >= cap || pos + 3 > n) { ok = false; break; }
+            const uint32_t bh = src[pos] | (src[pos + 1] << 8) | (src[pos + 2] << 16);
+            const uint32_t type = (bh >> 1) & 3, size = bh >> 3;
+            const uint64_t step = 3 + (type == 1 ? 1 : size);
+            if (type == 3 || size > BLOCK_MAX || pos + step > n) { ok = false; break; }
+            if (lane == 0) a.items[base + k].src = (uint32_t)pos;
+            pos += step;
+            last = bh & 1;
+            k++;
+        }
+        ok = ok && pos == n;
+        nb = ok ? k : 0;
+    }
+    uint32_t start = 0;
+    if (nb) start = uni(atomicAdd(work_count, lane == 0 ? nb : 0u));  // every lane executes the atomic (lane 0 adds)
+    for (uint32_t i = lane; i < nb; i += 64) work[start + i] = base + i;
+    if (lane == 0) a.cand_nb[c] = nb;
+}
+
+// Treeless literals: the tree of the nearest earlier block of the frame that carries a description.
+__device__ int fz_find_tree(FzTmp &T, const FzArgs &a, const uint8_t *src, const uint8_t *blob_end, uint32_t base, uint32_t k) {
+    for (uint32_t back = 1; back <= FZ_BACK && back <= k; back++) {
+        const uint32_t pos = a.items[base + k - back].src;
+        const uint32_t bh = src[pos] | (src[pos + 1] << 8) | (src[pos + 2] << 16);
+        if (((bh >> 1) & 3) != 2) continue;  // raw / RLE blocks pass the tree on
+        const uint8_t *b = src + pos + 3;
+        LitHdr h;
+        if (fz_lit_header(b, bh >> 3, h)) return E_CORRUPT;
+        if (h.type == 2) {
+            uint32_t tu = 0;
+            return huf_read_tree(T, b + h.hdr, h.comp, blob_end, &tu);
+        }
+        // raw / RLE literals and treeless blocks pass it on as well
+    }
+    return E_UNSUP;
+}
+
+// Sequences_Section_Header of the section [q, q + n): number of sequences, then the three table descriptions.  Kinds in
+// `want` (bit 0 LL, 1 OF, 2 ML) that are described here are set up; those in Repeat_Mode come back in *missing.
+__device__ int fz_seq_tables(FzShared &S, FzTmp &T, const uint8_t *q, uint32_t n, uint32_t want, uint32_t *missing,
+                             uint32_t *nseq_out, uint32_t *bits_at) {
+    if (n < 1) return E_TRUNC;
+    uint32_t p = 0, nseq = 0;
+    const uint32_t b0 = q[0];
+    if (b0 == 0) { nseq = 0; p = 1; }
+    else if (b0 < 128) { nseq = b0; p = 1; }
+    else if (b0 < 255) { if (n < 2) return E_TRUNC; nseq = ((b0 - 128) << 8) + q[1]; p = 2; }
+    else { if (n < 3) return E_TRUNC; nseq = q[1] + ((uint32_t)q[2] << 8) + 0x7F00; p = 3; }
+    *nseq_out = nseq;
+    *missing = want;
+    *bits_at = p;
+    if (!nseq) return 0;
+    if (p >= n) return E_TRUNC;
+    const uint32_t modes = q[p++];
+    if (modes & 3) return E_CORRUPT;
+    const int shifts[3] = {6, 4, 2};
+    const int kinds[3] = {K_LL, K_OF, K_ML};
+    const int maxlog[3] = {9, 8, 9};
+    const int maxsym[3] = {35, 31, 52};
+    const int deflog[3] = {6, 5, 6};
+    uint32_t miss = 0;
+    for (int k = 0; k < 3; k++) {
+        const uint32_t mode = (modes >> shifts[k]) & 3;
+        const bool wanted = (want >> k) & 1;
+        if (mode == 0) { if (wanted) { S.sel[k] = 0; S.log_[k] = deflog[k]; } }
+        else if (mode == 1) {
+            if (p >= n) return E_TRUNC;
+            if (wanted) {
+                const int rc = fse_set_rle(&S.rle[k], q[p], kinds[k]);
+                if (rc) return rc;
+                S.sel[k] = 1; S.log_[k] = 0;
+            }
+            p++;
+        } else if (mode == 2) {
+            int nsym, log;
+            uint32_t used;
+            int rc = fse_read_ncount(T, q + p, n - p, maxlog[k], maxsym[k], &nsym, &log, &used);
+            if (rc) return rc;
+            if (wanted) {
+                rc = fse_build(T, k == 0 ? S.ll : (k == 1 ? S.of : S.ml), nsym, log, kinds[k]);
+                if (rc) return rc;
+                S.sel[k] = 2; S.log_[k] = log;
+            }
+            p += used;
+        } else if (wanted) miss |= 1u << k;
+    }
+    *missing = miss;
+    *bits_at = p;
+    return 0;
+}
+
+// One lane, one Huffman stream.  While 64 or more bits are unread four symbols (<= 44 bits) come out of one 8-byte
+// load with no end-of-stream case and leave as one 4-byte store; the last few go through the guarded reader.
+__device__ int fz_huf_stream(const uint16_t *huf, uint32_t log, const uint8_t *p, uint32_t n, const uint8_t *blob_end,
+                             uint8_t *dst, uint32_t n_out) {
+    BitR b;
+    if (!b.init(p, n, blob_end)) return E_CORRUPT;
+    const uint32_t mask = (1u << log) - 1;
+    uint32_t i = 0;
+    int64_t pos = b.pos;
+    while (i + 4 <= n_out && pos >= 64) {
+        const int64_t b0 = ((pos + 7) >> 3) - 8;
+        uint64_t c;
+        __builtin_memcpy(&c, p + b0, 8);
+        int32_t avail = (int32_t)(pos - b0 * 8);  // 57..64 bits of c lie below `pos`
+        uint32_t w = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const uint32_t e = huf[(uint32_t)(c >> (avail - (int32_t)log)) & mask];
+            w |= (e & 0xFFu) << (8 * j);
+            avail -= (int32_t)(e >> 8);
+        }
+        pos = b0 * 8 + avail;
+        __builtin_memcpy(dst + i, &w, 4);
+        i += 4;
+    }
+    b.pos = pos;
+    b.refill();
+    for (; i < n_out; i++) {
+        const uint32_t e = huf[b.peek(log)];
+        dst[i] = (uint8_t)e;
+        b.pos -= e >> 8;
+    }
+    return b.pos == 0 ? 0 : E_CORRUPT;
+}
+
+__global__ __launch_bounds__(128) void k_fz_entropy(FzArgs a, const uint32_t *work, const uint32_t *work_count) {
+    __shared__ FzShared S;
+    const uint32_t tid = threadIdx.x, lane = tid & 63;
+    const bool wave0 = tid < 64;
+    const uint32_t n_work = *work_count;
+    if (n_work == 0) return;
+    if (tid == 0) {
+        for (int i = 0; i < 36; i++) S.ta.norm[i] = c_ll_default[i];
+        fse_build(S.ta, S.dll, 36, 6, K_LL);
+        for (int i = 0; i < 53; i++) S.ta.norm[i] = c_ml_default[i];
+        fse_build(S.ta, S.dml, 53, 6, K_ML);
+        for (int i = 0; i < 29; i++) S.ta.norm[i] = c_of_default[i];
+        fse_build(S.ta, S.dof, 29, 5, K_OF);
+    }
+    __syncthreads();
+    for (;;) {
+        if (tid == 0) S.claim = atomicAdd(a.cursor, 1u);
+        __syncthreads();
+        const uint32_t wi = S.claim;
+        if (wi >= n_work) break;
+        const uint32_t slot = work[wi];
+        const uint32_t c = a.it_cand[slot];
+        const uint32_t base = a.cand_fzbase[c], k = slot - base, row = a.cand_row[c];
+        const uint8_t *const src = a.blobs + (a.blob_off[row] - a.blob_base);
+        const uint8_t *const blob_end = src + a.blob_size[row];
+        const uint32_t pos = a.items[slot].src;
+        const uint32_t bh = src[pos] | (src[pos + 1] << 8) | (src[pos + 2] << 16);
+        const uint32_t btype = (bh >> 1) & 3, bsize = bh >> 3;
+        const uint8_t *const bsrc = src + pos + 3;
+        if (btype != 2) {  // raw / RLE block: literals only
+            if (tid == 0) {
+                FzItem it;
+                it.src = pos; it.out = bsize; it.nseq = 0; it.lit_len = bsize; it.seq_off = 0;
+                it.lit_kind = btype == 0 ? 0u : 1u;
+                it.lit_off = btype == 0 ? (uint64_t)pos + 3 : (uint64_t)bsrc[0];
+                it.err = 0;
+                a.items[slot] = it;
+            }
+            __syncthreads();
+            continue;
+        }
+        if (tid == 0) {
+            LitHdr h;
+            int err = fz_lit_header(bsrc, bsize, h);
+            S.lit_type = h.type; S.lit_len = h.regen; S.lit_hdr = h.hdr; S.lit_comp = h.comp; S.n_streams = 0;
+            if (!err) {
+                if (h.type == 0) { S.lit_kind = 0; S.lit_off = (uint64_t)pos + 3 + h.hdr; }
+                else if (h.type == 1) { S.lit_kind = 1; S.lit_off = bsrc[h.hdr]; }
+                else { S.lit_kind = 2; S.n_streams = h.streams; }
+                S.seq_pos = fz_lit_section_bytes(h);
+            }
+            S.err = err;
+            S.nseq = 0; S.sum_ll = 0; S.sum_ml = 0; S.seq_off = 0;
+        }
+        __syncthreads();
+        if (S.err == 0) {
+            if (wave0) {
+                // ---- literals: tree, table, streams ----
+                if (S.lit_kind == 2) {
+                    if (lane == 0) {
+                        int err = 0;
+                        uint32_t p = S.lit_hdr, remain = S.lit_comp;
+                        const uint32_t regen = S.lit_len;
+                        if (S.lit_type == 2) {
+                            uint32_t tu = 0;
+                            err = huf_read_tree(S.ta, bsrc + p, remain, blob_end, &tu);
+                            if (!err) { p += tu; remain -= tu; }
+                        } else err = fz_find_tree(S.ta, a, src, blob_end, base, k);
+                        if (!err) {
+                            if (S.n_streams == 1) {
+                                S.stream_off[0] = p; S.stream_len[0] = remain; S.stream_out[0] = 0; S.stream_n[0] = regen;
+                            } else {
+                                const uint32_t seg = (regen + 3) / 4;
+                                if (remain < 6 || 3 * seg > regen) err = E_CORRUPT;
+                                else {
+                                    const uint32_t s1 = bsrc[p] | (bsrc[p + 1] << 8), s2 = bsrc[p + 2] | (bsrc[p + 3] << 8),
+                                                   s3 = bsrc[p + 4] | (bsrc[p + 5] << 8);
+                                    if (6 + s1 + s2 + s3 > remain) err = E_CORRUPT;
+                                    else {
+                                        const uint32_t s4 = remain - 6 - s1 - s2 - s3;
+                                        p += 6;
+                                        S.stream_off[0] = p; S.stream_len[0] = s1; S.stream_out[0] = 0; S.stream_n[0] = seg;
+                                        S.stream_off[1] = p + s1; S.stream_len[1] = s2; S.stream_out[1] = seg; S.stream_n[1] = seg;
+                                        S.stream_off[2] = p + s1 + s2; S.stream_len[2] = s3; S.stream_out[2] = 2 * seg; S.stream_n[2] = seg;
+                                        S.stream_off[3] = p + s1 + s2 + s3; S.stream_len[3] = s4; S.stream_out[3] = 3 * seg; S.stream_n[3] = regen - 3 * seg;
+                                    }
+                                }
+                            }
+                        }
+                        if (!err) {
+                            const uint64_t room = ((uint64_t)regen + 79) & ~15ull;
+                            const uint64_t off = atomicAdd(&a.pool_used[0], (unsigned long long)room);
+                            if (off + room > a.lit_cap) err = E_UNSUP;
+                            S.lit_off = off;
+                        }
+                        if (err) atomicMin(&S.err, err);
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                    if (S.err == 0) {
+                        const uint32_t hlog = S.ta.huf_log;
+                        for (uint32_t sym = lane; sym < 256; sym += 64) {
+                            const uint32_t len = S.ta.sym_len[sym];
+                            if (len) {
+                                const uint32_t st = S.ta.sym_start[sym];
+                                const uint16_t e = (uint16_t)(sym | ((hlog + 1 - S.ta.weights[sym]) << 8));
+                                for (uint32_t i = 0; i < len; i++) S.huf[st + i] = e;
+                            }
+                        }
+                        __builtin_amdgcn_wave_barrier();
+                        if (lane < S.n_streams) {
+                            const int rc = fz_huf_stream(S.huf, hlog, bsrc + S.stream_off[lane], S.stream_len[lane], blob_end,
+                                                         a.lit_pool + S.lit_off + S.stream_out[lane], S.stream_n[lane]);
+                            if (rc) atomicMin(&S.err, rc);
+                        }
+                    }
+                }
+            } else {
+                // ---- sequences: header, tables, bitstream ----
+                if (lane == 0) {
+                    int err = 0;
+                    const uint8_t *q = bsrc + S.seq_pos;
+                    const uint32_t qn = bsize - S.seq_pos;
+                    uint32_t miss = 0, nseq = 0, bits_at = 0;
+                    if (S.seq_pos >= bsize) err = E_TRUNC;
+                    if (!err) err = fz_seq_tables(S, S.tb, q, qn, 7u, &miss, &nseq, &bits_at);
+                    if (!err && nseq == 0 && bits_at != qn) err = E_CORRUPT;
+                    if (!err && nseq && miss) {
+                        for (uint32_t back = 1; back <= FZ_BACK && back <= k && miss && !err; back++) {
+                            const uint32_t pj = a.items[base + k - back].src;
+                            const uint32_t bj = src[pj] | (src[pj + 1] << 8) | (src[pj + 2] << 16);
+                            if (((bj >> 1) & 3) != 2) continue;
+                            const uint8_t *b = src + pj + 3;
+                            const uint32_t sz = bj >> 3;
+                            LitHdr h;
+                            if (fz_lit_header(b, sz, h)) { err = E_CORRUPT; break; }
+                            const uint32_t ls = fz_lit_section_bytes(h);
+                            if (ls >= sz) { err = E_CORRUPT; break; }
+                            uint32_t m2 = 0, n2 = 0, at2 = 0;
+                            err = fz_seq_tables(S, S.tb, b + ls, sz - ls, miss, &m2, &n2, &at2);
+                            if (!err && n2) miss = m2;
+                        }
+                        if (!err && miss) err = E_UNSUP;
+                    }
+                    if (!err && nseq) {
+                        if (bits_at >= qn) err = E_TRUNC;
+                        else {
+                            BitR b;
+                            if (!b.init(q + bits_at, qn - bits_at, blob_end)) err = E_CORRUPT;
+                            else {
+                                S.st_ll = b.read(S.log_[0]);
+                                S.st_of = b.read(S.log_[1]);
+                                S.st_ml = b.read(S.log_[2]);
+                                S.bs_pos = (int32_t)b.pos;
+                                S.bs_off = S.seq_pos + bits_at;
+                            }
+                        }
+                    }
+                    if (!err && nseq) {
+                        const uint64_t off = atomicAdd(&a.pool_used[1], (unsigned long long)nseq);
+                        if (off + nseq > a.seq_cap) err = E_UNSUP;
+                        S.seq_off = off;
+                    }
+                    S.nseq = nseq;
+                    if (err) atomicMin(&S.err, err);
+                }
+                __builtin_amdgcn_wave_barrier();
+                const uint32_t nseq = uni(S.nseq);
+                if (S.err == 0 && nseq) {
+                    const uint32_t sel0 = uni(S.sel[0]), sel1 = uni(S.sel[1]), sel2 = uni(S.sel[2]);
+                    const FseEntry *tl = sel0 == 0 ? S.dll : (sel0 == 1 ? &S.rle[0] : S.ll);
+                    const FseEntry *to = sel1 == 0 ? S.dof : (sel1 == 1 ? &S.rle[1] : S.of);
+                    const FseEntry *tm = sel2 == 0 ? S.dml : (sel2 == 1 ? &S.rle[2] : S.ml);
+                    const uint8_t *const bbase = bsrc + uni(S.bs_off);
+                    int32_t left = (int32_t)uni((uint32_t)S.bs_pos), cb = 0;
+                    uint64_t cw = 0;
+                    auto refill = [&]() {
+                        int32_t b0 = ((left + 7) >> 3) - 8;
+                        if (b0 < 0) b0 = 0;
+                        uint64_t v;
+                        __builtin_memcpy(&v, bbase + b0, 8);
+                        cw = uni64(v);
+                        cb = b0 * 8;
+                    };
+                    auto rd = [&](uint32_t nb) -> uint32_t {
+                        const int32_t sh = left - cb - (int32_t)nb;
+                        const uint64_t v = sh >= 0 ? (cw >> sh) : (cw << (sh < -63 ? 63 : -sh));
+                        left -= (int32_t)nb;
+                        return (uint32_t)v & ((1u << nb) - 1u);  // nb <= 31
+                    };
+                    if (((left + 7) >> 3) >= 8) refill();
+                    else cw = uni64(load8_guard(bbase, blob_end));
+                    uint32_t sl = uni(S.st_ll), so = uni(S.st_of), sm = uni(S.st_ml);
+                    const uint2 *const tl2 = reinterpret_cast<const uint2 *>(tl), *const to2 = reinterpret_cast<const uint2 *>(to),
+                                *const tm2 = reinterpret_cast<const uint2 *>(tm);
+                    unsigned long long *const recs = a.seq_pool + uni64(S.seq_off);
+                    uint32_t sum_ll = 0, sum_ml = 0;
+                    int err = 0;
+                    for (uint32_t i = 0; i < nseq; i++) {
+                        const uint2 veo = to2[so], vem = tm2[sm], vel = tl2[sl];
+                        const uint32_t eox = uni(veo.x), eoy = uni(veo.y), emx = uni(vem.x), emy = uni(vem.y), elx = uni(vel.x), ely = uni(vel.y);
+                        const uint32_t ofb = eox >> 24, mlb = emx >> 24, llb = elx >> 24;
+                        const bool more = i + 1 < nseq;
+                        const uint32_t nbl = (elx >> 16) & 0xFF, nbm = (emx >> 16) & 0xFF, nbo = (eox >> 16) & 0xFF;
+                        const int32_t need_v = (int32_t)(ofb + mlb + llb), need_s = more ? (int32_t)(nbl + nbm + nbo) : 0;
+                        if (left - cb < need_v + need_s && cb > 0) refill();
+                        const uint32_t ov = eoy + rd(ofb > 31 ? 31 : ofb);
+                        if (need_v + need_s > 56 && left - cb < need_v + need_s - (int32_t)ofb && cb > 0) refill();
+                        const uint32_t ml = emy + rd(mlb);
+                        const uint32_t ll = ely + rd(llb);
+                        if (more) {
+                            if (need_v + need_s > 56 && left - cb < need_s && cb > 0) refill();
+                            sl = (elx & 0xFFFF) + rd(nbl);
+                            sm = (emx & 0xFFFF) + rd(nbm);
+                            so = (eox & 0xFFFF) + rd(nbo);
+                        }
+                        sum_ll += ll; sum_ml += ml;
+                        if (left < 0 || ofb > 28 || sum_ll + sum_ml > BLOCK_MAX) { err = left < 0 ? E_CORRUPT : E_UNSUP; break; }
+                        if (lane == 0) recs[i] = (unsigned long long)ll | ((unsigned long long)ml << 17) | ((unsigned long long)ov << 35);
+                    }
+                    if (!err && left != 0) err = E_CORRUPT;
+                    if (lane == 0) {
+                        S.sum_ll = sum_ll; S.sum_ml = sum_ml;
+                        if (err) atomicMin(&S.err, err);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        if (tid == 0) {
+            int err = S.err;
+            if (!err && S.sum_ll > S.lit_len) err = E_CORRUPT;
+            if (!err && S.lit_len + S.sum_ml > BLOCK_MAX) err = E_CORRUPT;
+            FzItem it;
+            it.src = pos; it.out = S.lit_len + S.sum_ml; it.nseq = S.nseq; it.lit_len = S.lit_len;
+            it.seq_off = S.seq_off; it.lit_off = S.lit_off; it.lit_kind = S.lit_kind; it.err = err;
+            a.items[slot] = it;
+            if (err) atomicAdd(&a.pool_used[3], 1ull);  // statistics: blocks left to the serial decoder
+        }
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(64) void k_fz_exec(FzArgs a) {
+    __shared__ __attribute__((aligned(16))) uint8_t W[WIN_HIST + WIN_CAP + 64];
+    const uint32_t c = blockIdx.x, lane = threadIdx.x;
+    if (c >= a.n_cand) return;
+    const uint32_t nb = a.cand_nb[c];
+    if (!nb) return;
+    const uint32_t row = a.cand_row[c], base = a.cand_fzbase[c];
+    const uint8_t *const src = a.blobs + (a.blob_off[row] - a.blob_base);
+    uint8_t *const out = a.out + a.out_off[row];
+    const uint64_t fcs = a.usize[row];
+    {   // every block came through the entropy phase and the sizes add up to the frame's content size
+        unsigned long long tot = 0;
+        uint32_t bad = 0;
+        for (uint32_t i = lane; i < nb; i += 64) {
+            bad |= a.items[base + i].err != 0;
+            tot += a.items[base + i].out;
+        }
+        for (int d = 32; d >= 1; d >>= 1) { tot += __shfl_xor(tot, d); bad |= __shfl_xor(bad, d); }
+        if (bad || tot != fcs) return;
+    }
+    uint64_t opos = 0;  // output bytes already streamed to HBM
+    uint32_t win_n = 0, hist_n = 0, r0 = 1, r1 = 4, r2 = 8;
+    bool dirty = false;
+    int err = 0;
+    for (uint32_t k = 0; k < nb && !err; k++) {
+        const FzItem it = a.items[base + k];
+        const uint32_t nseq = uni(it.nseq), lit_len = uni(it.lit_len), kind = uni(it.lit_kind);
+        const uint64_t lit_off = uni64(it.lit_off);
+        const bool rle_lits = kind == 1;
+        const uint8_t rle_byte = (uint8_t)lit_off;
+        const uint8_t *const lit_ptr = kind == 0 ? src + lit_off : a.lit_pool + lit_off;
+        const unsigned long long *const recs = a.seq_pool + uni64(it.seq_off);
+        uint32_t lpos = 0;
+        for (uint32_t g0 = 0; g0 < nseq && !err; g0 += 64) {
+            const uint32_t cnt = nseq - g0 < 64 ? nseq - g0 : 64;
+            const bool on = lane < cnt;
+            const unsigned long long rec = on ? recs[g0 + lane] : 0ull;
+            const uint32_t ll0 = (uint32_t)rec & 0x1FFFFu, ml0 = (uint32_t)(rec >> 17) & 0x3FFFFu;
+            const uint32_t ov = on ? (uint32_t)(rec >> 35) : 4u;
+            uint32_t offset = ov - 3;
+            // repeat offsets: only a group that contains one walks its sequences in order (scalar unit)
+            if (__ballot(on && ov <= 3) != 0ull || cnt < 3) {
+                for (uint32_t j = 0; j < cnt; j++) {
+                    const uint32_t ovj = uni(__shfl(ov, j)), llj = uni(__shfl(ll0, j));
+                    uint32_t o;
+                    if (ovj > 3) { o = ovj - 3; r2 = r1; r1 = r0; r0 = o; }
+                    else {
+                        const uint32_t idx = ovj - 1 + (llj == 0 ? 1 : 0);
+                        if (idx == 0) o = r0;
+                        else {
+                            o = idx == 1 ? r1 : (idx == 2 ? r2 : r0 - 1);
+                            if (o == 0) { err = E_CORRUPT; break; }
+                            if (idx > 1) r2 = r1;
+                            r1 = r0; r0 = o;
+                        }
+                    }
+                    if (lane == j) offset = o;
+                }
+                if (err) break;
+            } else {
+                r0 = uni(__shfl(offset, cnt - 1)); r1 = uni(__shfl(offset, cnt - 2)); r2 = uni(__shfl(offset, cnt - 3));
+            }
+            {
+                uint32_t linc = ll0, pinc = ll0 + ml0;
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) {
+                    const uint32_t y = __shfl_up(linc, d), z = __shfl_up(pinc, d);
+                    if (lane >= (uint32_t)d) { linc += y; pinc += z; }
+                }
+                const bool bad = on && ((uint64_t)offset > opos + win_n + pinc - ml0 || lpos + linc > lit_len);
+                if (__ballot(bad) != 0ull) { err = E_CORRUPT; break; }
+            }
+            // ---- execute the group (the narrow serial decoder's window scheme, one wave) ----
+            uint32_t si = 0;
+            while (si < cnt) {
+                const uint32_t idx = si + lane;
+                const bool v = idx < cnt;
+                uint32_t ll = __shfl(ll0, idx & 63), ml = __shfl(ml0, idx & 63), off = __shfl(offset, idx & 63);
+                if (!v) { ll = 0; ml = 0; off = 1; }
+                const uint32_t tot = ll + ml;
+                const uint64_t bigm = __ballot(v && tot > WIN_SEQ_MAX);
+                const uint32_t nv = cnt - si;
+                const uint32_t ncand = bigm ? (uint32_t)__ffsll((long long)bigm) - 1 : nv;
+                if (ncand == 0) {
+                    // one long sequence, straight to HBM (the window is emptied first)
+                    if (win_n) {
+                        (void)win_flush(W, out, opos, win_n, hist_n, lane, false);
+                        opos += win_n;
+                        win_n = 0;
+                    }
+                    hist_n = 0;
+                    const uint32_t llx = uni(__shfl(ll, 0)), mlx = uni(__shfl(ml, 0)), offx = uni(__shfl(off, 0));
+                    if (llx) {
+                        if (rle_lits) coop_fill(out + opos, rle_byte, llx, lane, 64);
+                        else coop_copy(out + opos, lit_ptr + lpos, llx, lane, 64);
+                        opos += llx; lpos += llx;
+                    }
+                    wave_mem_sync();
+                    coop_match<1>(out + opos, offx, mlx, lane, false, nullptr);
+                    opos += mlx;
+                    dirty = true;
+                    si++;
+                    continue;
+                }
+                uint32_t end = lane < ncand ? tot : 0, lend = lane < ncand ? ll : 0;
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) {
+                    const uint32_t y = __shfl_up(end, d), z = __shfl_up(lend, d);
+                    if (lane >= (uint32_t)d) { end += y; lend += z; }
+                }
+                uint32_t fit = (uint32_t)__popcll(__ballot(lane < ncand && end <= WIN_CAP - win_n));
+                if (fit == 0) {  // chunk full: stream it out, keep the newest bytes as history
+                    (void)win_flush(W, out, opos, win_n, hist_n, lane, true);
+                    hist_n = hist_n + win_n < WIN_HIST ? hist_n + win_n : WIN_HIST;
+                    opos += win_n;
+                    win_n = 0;
+                    fit = (uint32_t)__popcll(__ballot(lane < ncand && end <= WIN_CAP));
+                }
+                if (dirty) { wave_mem_sync(); dirty = false; }
+                const uint32_t want_h = opos < WIN_HIST ? (uint32_t)opos : WIN_HIST;
+                if (win_n == 0 && hist_n < want_h) {  // history lost to a direct copy: read the newest output back
+                    coop_copy(W + WIN_HIST - want_h, out + opos - want_h, want_h, lane, 64);
+                    hist_n = want_h;
+                }
+                win_exec_group(W, out, opos, hist_n, lane, lane < fit, WIN_HIST + win_n + (end - tot), ll, ml, off,
+                               lit_ptr + lpos + (lend - ll), rle_lits, rle_byte);
+                win_n += __shfl(end, fit - 1);
+                lpos += __shfl(lend, fit - 1);
+                si += fit;
+            }
+        }
+        if (err) break;
+        // literals left after the last sequence, then the window goes out (history stays for the next block)
+        const uint32_t rest = lit_len - lpos;
+        if (opos + win_n + rest > fcs) { err = E_CORRUPT; break; }
+        const bool in_win = rest <= WIN_CAP - win_n;
+        if (in_win && rest) {
+            uint8_t *d = W + WIN_HIST + win_n;
+            if (rle_lits) for (uint32_t i = lane; i < rest; i += 64) d[i] = rle_byte;
+            else coop_copy(d, lit_ptr + lpos, rest, lane, 64);
+        }
+        if (dirty) { wave_mem_sync(); dirty = false; }
+        uint32_t h = win_flush(W, out, opos, in_win ? win_n + rest : win_n, hist_n, lane, in_win);
+        if (!in_win) {
+            if (rle_lits) coop_fill(out + opos + win_n, rle_byte, rest, lane, 64);
+            else coop_copy(out + opos + win_n, lit_ptr + lpos, rest, lane, 64);
+            wave_mem_sync();
+            h = 0;
+        }
+        opos += win_n + rest;
+        win_n = 0;
+        hist_n = in_win ? h : 0;
+    }
+    if (!err && opos == fcs && lane == 0) {
+        a.row_flag[row] = 0;  // k_finish_blocks turns this into status 2 (hash me)
+        atomicAdd(&a.pool_used[2], 1ull);  // statistics: frames decoded by this path
+    }
+}
+
+void launch_fz_scan(const FzArgs &a, uint32_t *work, uint32_t *work_count, hipStream_t s) {
+    hipLaunchKernelGGL(k_fz_scan, dim3(a.n_cand), dim3(64), 0, s, a, work, work_count);
+}
+void launch_fz_entropy(const FzArgs &a, int cus, const uint32_t *work, const uint32_t *work_count, hipStream_t s) {
+    const uint32_t grid = std::min<uint32_t>(a.total_items, (uint32_t)cus * 6);
+    hipLaunchKernelGGL(k_fz_entropy, dim3(grid), dim3(128), 0, s, a, work, work_count);
+}
+void launch_fz_exec(const FzArgs &a, hipStream_t s) {
+    hipLaunchKernelGGL(k_fz_exec, dim3(a.n_cand), dim3(64), 0, s, a);
+}
+
 int decode_grid_size(int device) {
     hipDeviceProp_t p;
     if (hipGetDeviceProperties(&p, device) != hipSuccess) return 1024;
