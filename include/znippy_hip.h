@@ -179,8 +179,10 @@ int znippy_last_kernel_times(znippy_ctx *ctx, const char **names, float *ms, int
 int znippy_ctx_set_kernel_timing(znippy_ctx *ctx, int level);
 /* Statistics of the last run's two-phase path for foreign multi-block frames (frames another zstd writer produced;
  * codec.rs:L67-78 decodes whatever the archive holds): stats[0] literal-pool bytes and stats[1] sequence-pool records
- * handed out, stats[2] frames decoded by that path, stats[3] blocks it left to the serial decoder.  Synchronises. */
-int znippy_rows_foreign_stats(znippy_ctx *ctx, znippy_rows *rows, uint64_t stats[4]);
+ * handed out, stats[2] frames decoded by that path, stats[3] blocks it left to the serial decoder, of which stats[4]
+ * for an error the serial decoder will report, stats[5] a Treeless / Repeat_Mode table more than 64 blocks back,
+ * stats[6] a pool that ran out, stats[7] a value outside the record format.  Synchronises. */
+int znippy_rows_foreign_stats(znippy_ctx *ctx, znippy_rows *rows, uint64_t stats[8]);
 /* The hash's VALU floor, measured: nanoseconds one 64-lane BLAKE3 compress pass costs a SIMD when nothing else runs
  * (a kernel of compressions only, 4 waves per SIMD on every CU), and the shader clock that kernel held (may be NULL).
  * bench.py prices the read step's passes with it. */

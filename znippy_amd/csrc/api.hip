@@ -513,11 +513,11 @@ int znippy_last_kernel_times(znippy_ctx *ctx, const char **names, float *ms, int
     return n;
 }
 
-int znippy_rows_foreign_stats(znippy_ctx *ctx, znippy_rows *r, uint64_t stats[4]) {
+int znippy_rows_foreign_stats(znippy_ctx *ctx, znippy_rows *r, uint64_t stats[8]) {
     if (!ctx || !r || r->ctx != ctx || !stats) return ZNIPPY_E_INVAL;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    HIPCHK(ctx, hipMemcpy(stats, r->ctl + 192, 32, hipMemcpyDeviceToHost));
+    HIPCHK(ctx, hipMemcpy(stats, r->ctl + 192, 64, hipMemcpyDeviceToHost));
     return ZNIPPY_OK;
 }
 
@@ -975,6 +975,18 @@ int znippy_decode_verify_rows_async(znippy_ctx *ctx, znippy_rows *r, const void 
                 z.lit_pool = ctx->fz_lit_pool; z.lit_cap = ctx->fz_lit_cap; z.seq_pool = ctx->fz_seq_pool; z.seq_cap = ctx->fz_seq_cap;
                 z.pool_used = reinterpret_cast<unsigned long long *>(r->ctl + 192);  // [lit bytes, seq records], zeroed with the control block
                 z.cursor = r->cursor + 12;
+                if (ctx->sw.ddbg) {  // diagnostic: where the previous run's execute kernel spent its cycles
+                    static unsigned long long *dbg = nullptr;
+                    if (!dbg) { (void)hipMalloc(&dbg, 256); (void)hipMemset(dbg, 0, 256); }
+                    unsigned long long h[32];
+                    (void)hipStreamSynchronize(s);
+                    (void)hipMemcpy(h, dbg, 256, hipMemcpyDeviceToHost);
+                    if (h[0]) fprintf(stderr, "[znippy ddbg] fz exec: frames=%llu groups=%llu seqs=%llu big=%llu rounds=%llu flushes=%llu histreads=%llu rep_groups=%llu | kcycles/frame: total=%.0f records=%.0f rep+scan=%.0f big=%.0f flush=%.0f histread=%.0f lits=%.0f matches=%.0f tail=%.0f\n",
+                                      h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7], h[8] / 1e3 / h[0], h[9] / 1e3 / h[0], h[10] / 1e3 / h[0], h[11] / 1e3 / h[0],
+                                      h[12] / 1e3 / h[0], h[13] / 1e3 / h[0], h[14] / 1e3 / h[0], h[15] / 1e3 / h[0], h[16] / 1e3 / h[0]);
+                    (void)hipMemset(dbg, 0, 256);
+                    z.dbg = dbg;
+                }
                 launch_fz_scan(z, r->fz_work, r->cursor + 13, s);
                 ktime_begin(ctx, "zstd_foreign_entropy");
                 launch_fz_entropy(z, ctx->cus, r->fz_work, r->cursor + 13, s);

@@ -167,7 +167,13 @@ struct FzItem {
     uint64_t lit_off;   // lit_kind 0: offset inside the frame's blob; 1: the byte; 2: offset in the literal pool
     uint32_t lit_kind;
     int32_t err;        // != 0: this block needs the serial decoder (which also produces the error code)
+    // Repeat offsets are resolved while the sequences are decoded (one scalar walk per block, all blocks at once),
+    // against an UNKNOWN incoming history: a value is an offset, or FZ_SYM | k << 26 | d = "incoming entry k, minus d".
+    // rep[] = the history the block leaves, in the same notation; the execute kernel substitutes frame by frame.
+    uint32_t rep[3];
+    uint32_t pad;
 };
+constexpr uint32_t FZ_SYM = 1u << 28;
 struct FzArgs {
     const uint32_t *cand_row, *cand_fzbase, *cand_fzcap;  // candidate -> row, first item slot, item slots
     uint32_t n_cand;
@@ -189,6 +195,7 @@ struct FzArgs {
     uint64_t seq_cap;         // records
     unsigned long long *pool_used;  // [0] literal bytes, [1] sequence records handed out, [2] frames decoded, [3] blocks given up (zeroed per run)
     uint32_t *cursor;
+    unsigned long long *dbg;  // diagnostic only (ZNIPPY_DDBG): cycle / event counters of the execute kernel
 };
 void launch_fz_scan(const FzArgs &a, uint32_t *work, uint32_t *work_count, hipStream_t s);
 void launch_fz_entropy(const FzArgs &a, int cus, const uint32_t *work, const uint32_t *work_count, hipStream_t s);

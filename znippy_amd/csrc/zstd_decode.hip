@@ -102,6 +102,22 @@ __device__ __forceinline__ int hibit(uint32_t v) { return 31 - __clz(v); }
 __device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 __device__ __forceinline__ uint64_t uni64(uint64_t v) { return ((uint64_t)uni((uint32_t)(v >> 32)) << 32) | uni((uint32_t)v); }
 
+// v_readlane with a wave-uniform (not necessarily constant) lane index: one instruction, where __shfl(v, j) is an LDS
+// crossbar round trip (ds_bpermute, ~100+ cycles)
+__device__ __forceinline__ uint32_t rdlane_u(uint32_t v, uint32_t l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)l); }
+// Inclusive prefix sum over the 64 lanes on the DPP path (row shifts inside the 16-lane rows, then the two row
+// broadcasts gfx9 has): 6 VALU moves + 6 adds.  The shuffle version (6 x __shfl_up) is 6 LDS crossbar round trips —
+// it was 1,500 cycles of every 64-sequence group.
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true);  // row_shr:1
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true);  // row_shr:2
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, true);  // row_shr:4
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, true);  // row_shr:8
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);  // row_bcast:15 -> rows 1, 3
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);  // row_bcast:31 -> rows 2, 3
+    return v;
+}
+
 __device__ __forceinline__ uint64_t load8_guard(const uint8_t *p, const uint8_t *end) {
     if (p + 8 <= end) {
         uint64_t v;
@@ -310,50 +326,175 @@ __device__ __forceinline__ void coop_match(uint8_t *dst, uint32_t off, uint64_t 
 // LDS output window (wave 0).  W = S.ebuf; the chunk starts at W + WIN_HIST and stands for output
 // bytes [chunk_abs, chunk_abs + win_n); `hist_n` bytes in front of it are the output just before.
 // ---------------------------------------------------------------------------------------------
-// per-lane copy, 16 bytes at a time while they fit (never writes past n)
-__device__ __forceinline__ void lane_copy_g2l(uint8_t *d, const uint8_t *g, uint32_t n) {
-    uint32_t k = 0;
-    for (; k + 16 <= n; k += 16) {
-        uint4 v;
-        __builtin_memcpy(&v, g + k, 16);
-        __builtin_memcpy(d + k, &v, 16);
-    }
-    for (; k < n; k++) d[k] = g[k];
+// Per-lane copies.  A wave-wide call costs what its slowest lane costs, and a lane's loop of "load, wait, store" pays
+// one memory round trip per trip (1-2 us from HBM, ~100 cycles from LDS): a 15-byte tail copied byte by byte from
+// global memory held 64 sequences up for 15 round trips.  So: every load of a stretch is issued before its first
+// store (64 bytes per trip), and a tail is 8 + 4 + 2 + 1 bytes (or one 16-byte piece that re-copies bytes already
+// done, where source and destination are disjoint) instead of a byte loop.  None of them writes past n.
+// The window is addressed as LDS (address space 3), not through generic pointers: a generic access is a FLAT
+// instruction, which resolves its aperture in the texture path (~500 cycles per dependent read -> write step, and it
+// ties LDS traffic to vmcnt); ds_read / ds_write take ~100.  gfx950 executes ds_*_b64 / b128 at any alignment.
+typedef __attribute__((address_space(3))) uint8_t lds8;
+#define LDS_CP(dst, src, n) __builtin_memcpy((__attribute__((address_space(3))) void *)(dst), (src), (n))
+#define LDS_LD(dst, src, n) __builtin_memcpy((dst), (const __attribute__((address_space(3))) void *)(src), (n))
+
+__device__ __forceinline__ void lane_tail_copy(lds8 *d, const uint8_t *g, uint32_t n) {  // n < 16, pieces in ascending order
+    uint64_t a = 0; uint32_t b = 0; uint16_t c = 0; uint8_t e = 0;
+    const uint32_t k4 = (n & 8), k2 = (n & 8) + (n & 4), k1 = (n & 8) + (n & 4) + (n & 2);
+    if (n & 8) __builtin_memcpy(&a, g, 8);
+    if (n & 4) __builtin_memcpy(&b, g + k4, 4);
+    if (n & 2) __builtin_memcpy(&c, g + k2, 2);
+    if (n & 1) e = g[k1];
+    if (n & 8) LDS_CP(d, &a, 8);
+    if (n & 4) LDS_CP(d + k4, &b, 4);
+    if (n & 2) LDS_CP(d + k2, &c, 2);
+    if (n & 1) d[k1] = e;
 }
-// forward copy inside LDS; valid for overlapping ranges when the distance is >= 16
-__device__ __forceinline__ void lane_copy_l2l(uint8_t *d, const uint8_t *s, uint32_t n) {
+// global -> LDS (disjoint by construction)
+__device__ __forceinline__ void lane_copy_g2l(lds8 *d, const uint8_t *g, uint32_t n) {
+    uint32_t k = 0;
+    for (; k + 64 <= n; k += 64) {
+        uint4 v0, v1, v2, v3;
+        __builtin_memcpy(&v0, g + k, 16); __builtin_memcpy(&v1, g + k + 16, 16);
+        __builtin_memcpy(&v2, g + k + 32, 16); __builtin_memcpy(&v3, g + k + 48, 16);
+        LDS_CP(d + k, &v0, 16); LDS_CP(d + k + 16, &v1, 16);
+        LDS_CP(d + k + 32, &v2, 16); LDS_CP(d + k + 48, &v3, 16);
+    }
+    const uint32_t rem = n - k;  // < 64
+    if (n >= 16) {
+        // up to three whole pieces + one piece that ends exactly at n (it overlaps the one before: same bytes again)
+        uint4 v0 = make_uint4(0, 0, 0, 0), v1 = v0, v2 = v0, vl;
+        const uint32_t c16 = rem >> 4;
+        if (c16 > 0) __builtin_memcpy(&v0, g + k, 16);
+        if (c16 > 1) __builtin_memcpy(&v1, g + k + 16, 16);
+        if (c16 > 2) __builtin_memcpy(&v2, g + k + 32, 16);
+        __builtin_memcpy(&vl, g + n - 16, 16);
+        if (c16 > 0) LDS_CP(d + k, &v0, 16);
+        if (c16 > 1) LDS_CP(d + k + 16, &v1, 16);
+        if (c16 > 2) LDS_CP(d + k + 32, &v2, 16);
+        if (rem & 15) LDS_CP(d + n - 16, &vl, 16);
+    } else lane_tail_copy(d, g, n);
+}
+// the first n (< 16) bytes of a 16-byte register value, as 8 + 4 + 2 + 1 byte stores
+__device__ __forceinline__ void store_prefix16(lds8 *d, const uint4 v, uint32_t n) {
+    uint64_t cur = (uint64_t)v.x | ((uint64_t)v.y << 32);
+    if (n & 8) { LDS_CP(d, &cur, 8); d += 8; cur = (uint64_t)v.z | ((uint64_t)v.w << 32); }
+    if (n & 4) { const uint32_t x = (uint32_t)cur; LDS_CP(d, &x, 4); d += 4; cur >>= 32; }
+    if (n & 2) { const uint16_t x = (uint16_t)cur; LDS_CP(d, &x, 2); d += 2; cur >>= 16; }
+    if (n & 1) *d = (uint8_t)cur;
+}
+// forward copy inside LDS, d = s + dist with dist >= 16 or dist >= n (ranges may overlap: whole 16-byte pieces go in
+// ascending order — LDS operations of a wave execute in order).  The last n % 16 bytes are ONE 16-byte read (it may
+// run past the source into bytes nobody uses; the caller's buffer has the slack) and up to four register stores: a
+// short match — most of them — is a single LDS round trip.
+__device__ __forceinline__ void lane_copy_l2l(lds8 *d, const lds8 *s, uint32_t n) {
     uint32_t k = 0;
     for (; k + 16 <= n; k += 16) {
         uint4 v;
-        __builtin_memcpy(&v, s + k, 16);
-        __builtin_memcpy(d + k, &v, 16);
+        LDS_LD(&v, s + k, 16);
+        LDS_CP(d + k, &v, 16);
     }
-    for (; k < n; k++) d[k] = s[k];
+    if (k < n) {
+        uint4 v;
+        LDS_LD(&v, s + k, 16);
+        store_prefix16(d + k, v, n - k);
+    }
+}
+// overlapping match with a period below 16 (off < n): 8 <= off: 8-byte pieces are still a valid forward copy;
+// off < 8: the period is widened to 8 bytes in a register once and written out with a rotating phase
+__device__ __forceinline__ void lane_copy_period(lds8 *d, const lds8 *s, uint32_t n, uint32_t off) {
+    uint32_t k = 0;
+    if (off >= 8) {
+        for (; k + 8 <= n; k += 8) { uint64_t v; LDS_LD(&v, s + k, 8); LDS_CP(d + k, &v, 8); }
+        if (k < n) {  // < 8 bytes left, the distance is >= 8: one read, register stores
+            uint64_t cur;
+            LDS_LD(&cur, s + k, 8);
+            const uint32_t r = n - k;
+            if (r & 4) { const uint32_t x = (uint32_t)cur; LDS_CP(d + k, &x, 4); k += 4; cur >>= 32; }
+            if (r & 2) { const uint16_t x = (uint16_t)cur; LDS_CP(d + k, &x, 2); k += 2; cur >>= 16; }
+            if (r & 1) d[k] = (uint8_t)cur;
+        }
+        return;
+    }
+    uint64_t m;
+    LDS_LD(&m, s, 8);  // the period is the first off (<= 7) bytes of this
+    m &= (1ull << (8 * off)) - 1;
+    uint64_t r = m;
+    for (uint32_t w = off; w < 8; w *= 2) r |= r << (8 * w);  // r[i] = m[i % off], i < 8
+    const uint32_t step = 8 % off;
+    uint32_t ph = 0;  // phase of the piece: its first byte is m[ph]
+    for (; k + 8 <= n; k += 8) {
+        const uint64_t v = ph ? (r >> (8 * ph)) | (r << (8 * (off - ph))) : r;
+        LDS_CP(d + k, &v, 8);
+        ph += step;
+        if (ph >= off) ph -= off;
+    }
+    const uint64_t v = ph ? (r >> (8 * ph)) | (r << (8 * (off - ph))) : r;
+    const uint32_t rr = n - k;
+    uint32_t sh = 0;
+    if (rr & 4) { const uint32_t x = (uint32_t)(v >> sh); LDS_CP(d + k, &x, 4); k += 4; sh += 32; }
+    if (rr & 2) { const uint16_t x = (uint16_t)(v >> sh); LDS_CP(d + k, &x, 2); k += 2; sh += 16; }
+    if (rr & 1) d[k] = (uint8_t)(v >> sh);
 }
 
 // One sequence per lane (lanes with on == false idle): literals, then matches in dependency rounds — a
 // match is copied once every byte of its source is final, i.e. lies before the destination of the first
 // match still pending (the high-water mark); the first pending match is always ready (its own overlap is
 // a forward copy).  Text needs 1-3 rounds per 64 sequences.
-__device__ __forceinline__ void win_exec_group(uint8_t *W, const uint8_t *out, uint64_t chunk_abs, uint32_t hist_n, uint32_t lane,
+struct ExecProf { unsigned long long t_lits = 0, t_match = 0, rounds = 0; };
+__device__ __forceinline__ void win_exec_group(uint8_t *Wg, const uint8_t *out, uint64_t chunk_abs, uint32_t hist_n, uint32_t lane,
                                                bool on, uint32_t dpos, uint32_t ll, uint32_t ml, uint32_t off, const uint8_t *lit,
-                                               bool rle, uint8_t rle_byte) {
-    if (on && ll) {
-        uint8_t *d = W + dpos;
+                                               bool rle, uint8_t rle_byte, ExecProf *prof = nullptr) {
+    lds8 *const W = (lds8 *)Wg;
+    unsigned long long t0 = prof ? __builtin_amdgcn_s_memtime() : 0;
+    // The callers fill parts of the window through generic pointers (cooperative copies: FLAT stores, which reach the
+    // LDS through the texture path).  A ds_read issued after such a store can overtake it: drain them first.
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    // A wave-wide call costs what its slowest lane costs: a lane copies up to LANE_MAX bytes itself, anything longer
+    // is moved by all 64 lanes together (16 bytes each per step) once the short ones are done.
+    constexpr uint32_t LANE_MAX = 64;
+    if (on && ll && ll <= LANE_MAX) {
+        lds8 *d = W + dpos;
         if (rle) for (uint32_t k = 0; k < ll; k++) d[k] = rle_byte;
         else lane_copy_g2l(d, lit, ll);
+    }
+    for (uint64_t lm = __ballot(on && ll > LANE_MAX); lm; lm &= lm - 1) {
+        const uint32_t j = (uint32_t)__ffsll((long long)lm) - 1;
+        const uint32_t dj = rdlane_u(dpos, j), nj = rdlane_u(ll, j);
+        const uint64_t lj = ((uint64_t)rdlane_u((uint32_t)((uintptr_t)lit >> 32), j) << 32) | rdlane_u((uint32_t)(uintptr_t)lit, j);
+        if (rle) for (uint32_t k = lane; k < nj; k += 64) W[dj + k] = rle_byte;
+        else {
+            coop_copy(Wg + dj, reinterpret_cast<const uint8_t *>(lj), nj, lane, 64);
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // FLAT stores into the window: done before any ds_read below
+        }
     }
     const uint32_t mdst = dpos + ll;
     const int32_t msrc = (int32_t)mdst - (int32_t)off;  // window coordinate of the match source (may lie before the history)
     const int32_t lds_lo = (int32_t)WIN_HIST - (int32_t)hist_n;
     bool pend = on && ml != 0;
+    if (prof) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); const unsigned long long t1 = __builtin_amdgcn_s_memtime(); prof->t_lits += t1 - t0; t0 = t1; }
     for (;;) {
         __builtin_amdgcn_wave_barrier();
         const uint64_t pm = __ballot(pend);
         if (!pm) break;
+        if (prof) prof->rounds++;
         const uint32_t first = (uint32_t)__ffsll((long long)pm) - 1;
-        const uint32_t hwm = __shfl(mdst, first);
-        if (pend && (lane == first || msrc + (int32_t)ml <= (int32_t)hwm)) {
+        const uint32_t hwm = rdlane_u(mdst, first);
+        const bool ready = pend && (lane == first || msrc + (int32_t)ml <= (int32_t)hwm);
+        // The common round (text: nearly all of them): every ready match is at most 16 bytes, sits in the window and
+        // does not overlap itself -> one 16-byte read and a prefix store per lane.  A single wave has nobody to hide
+        // its instruction latency behind, so a round costs what its instruction COUNT costs.
+        if (__ballot(ready && !(ml <= 16 && msrc >= lds_lo && off >= ml)) == 0ull) {
+            if (ready) {
+                uint4 v;
+                LDS_LD(&v, W + msrc, 16);
+                if (ml == 16) LDS_CP(W + mdst, &v, 16);
+                else store_prefix16(W + mdst, v, ml);
+                pend = false;
+            }
+            continue;
+        }
+        if (ready && ml <= LANE_MAX) {
             uint32_t k = 0;
             if (msrc < lds_lo) {  // (part of) the source was flushed long ago: read it back from HBM
                 const uint32_t nf = (uint32_t)(lds_lo - msrc) < ml ? (uint32_t)(lds_lo - msrc) : ml;
@@ -362,15 +503,47 @@ __device__ __forceinline__ void win_exec_group(uint8_t *W, const uint8_t *out, u
                 k = nf;
             }
             if (k < ml) {
-                uint8_t *d = W + mdst + k;
-                const uint8_t *sp = W + (msrc + (int32_t)k);
+                lds8 *d = W + mdst + k;
+                const lds8 *sp = W + (msrc + (int32_t)k);
                 const uint32_t n = ml - k;
                 if (off >= 16 || off >= ml) lane_copy_l2l(d, sp, n);
-                else for (uint32_t i = 0; i < n; i++) d[i] = sp[i];  // short period: byte-serial extension
+                else if (k == 0) lane_copy_period(d, sp, n, off);  // short period
+                else for (uint32_t i = 0; i < n; i++) d[i] = sp[i];  // short period whose first bytes came from HBM (cannot happen: off < 16 lies inside the history)
             }
-            pend = false;
         }
+        // long matches that are ready, one after the other, 64 lanes each
+        for (uint64_t lm = __ballot(ready && ml > LANE_MAX); lm; lm &= lm - 1) {
+            const uint32_t j = (uint32_t)__ffsll((long long)lm) - 1;
+            const uint32_t dj = rdlane_u(mdst, j), nj = rdlane_u(ml, j), oj = rdlane_u(off, j);
+            const int32_t sj = (int32_t)rdlane_u((uint32_t)msrc, j);
+            uint32_t k = 0;
+            if (sj < lds_lo) {
+                const uint32_t nf = (uint32_t)(lds_lo - sj) < nj ? (uint32_t)(lds_lo - sj) : nj;
+                coop_copy(Wg + dj, out + (chunk_abs - WIN_HIST) + (int64_t)sj, nf, lane, 64);
+                k = nf;
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // FLAT stores into the window, see above
+            }
+            if (k < nj && oj < 16) {  // short period: written from a register by one lane (no reads to wait for)
+                if (lane == 0) lane_copy_period(W + dj + k, W + (sj + (int32_t)k), nj - k, oj);
+                k = nj;
+            }
+            while (k < nj) {  // forward copy in steps no longer than the distance: a step's source is final when it starts
+                const uint32_t lim = oj < 1024 ? oj : 1024u;
+                const uint32_t step = nj - k < lim ? nj - k : lim;
+                const uint32_t i = lane * 16;
+                if (i < step) {
+                    uint4 v;
+                    LDS_LD(&v, W + (sj + (int32_t)(k + i)), 16);
+                    if (step - i >= 16) LDS_CP(W + dj + k + i, &v, 16);
+                    else store_prefix16(W + dj + k + i, v, step - i);
+                }
+                k += step;
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+        if (ready) pend = false;
     }
+    if (prof) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); prof->t_match += __builtin_amdgcn_s_memtime() - t0; }
 }
 
 // chunk -> HBM, then keep the newest bytes as history.  Returns the new history length.
@@ -1026,7 +1199,7 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES == 4 ? 4 : 1) void k_zstd_decod
                         if (__ballot(on && ov <= 3) != 0ull || cnt < 3) {
                             if (no_rep && __ballot(on && ov <= 3) != 0ull) { err = E_CORRUPT; break; }
                             for (uint32_t j = 0; j < cnt; j++) {  // in order, on the scalar unit
-                                const uint32_t ovj = uni(__shfl(ov, j)), llj = uni(__shfl(ll, j));
+                                const uint32_t ovj = rdlane_u(ov, j), llj = rdlane_u(ll, j);
                                 uint32_t o;
                                 if (ovj > 3) { o = ovj - 3; r2 = r1; r1 = r0; r0 = o; }
                                 else {
@@ -1043,20 +1216,16 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES == 4 ? 4 : 1) void k_zstd_decod
                             }
                             if (err) break;
                         } else {  // explicit offsets only: the history is the group's last three
-                            r0 = uni(__shfl(offset, cnt - 1)); r1 = uni(__shfl(offset, cnt - 2)); r2 = uni(__shfl(offset, cnt - 3));
+                            r0 = rdlane_u(offset, cnt - 1); r1 = rdlane_u(offset, cnt - 2); r2 = rdlane_u(offset, cnt - 3);
                         }
                         uint32_t linc = ll, pinc = ll + ml;  // inclusive scans: literals used, bytes produced
-#pragma unroll
-                        for (int d = 1; d < 64; d <<= 1) {
-                            const uint32_t y = __shfl_up(linc, d), z = __shfl_up(pinc, d);
-                            if (lane >= (uint32_t)d) { linc += y; pinc += z; }
-                        }
+linc = wave_incl_scan(linc); pinc = wave_incl_scan(pinc);
                         // a match may reach back over what exists when it starts; literals may not run out
                         const bool bad = on && ((uint64_t)offset > abs0 + produced + pinc - ml || lits + linc > lit_room);
                         if (__ballot(bad) != 0ull) { err = E_CORRUPT; break; }
                         if (on) S.seq_off[buf][g0 + lane] = offset;
-                        lits += uni(__shfl(linc, 63));
-                        produced += uni(__shfl(pinc, 63));
+                        lits += rdlane_u(linc, 63);
+                        produced += rdlane_u(pinc, 63);
                     }
                     if (!err && abs0 + uni64(S.blk_base) + produced > out_end) err = E_CORRUPT;
                     if (!err && seq_done + bn == nseq && left != 0) err = E_CORRUPT;
@@ -1128,11 +1297,7 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES == 4 ? 4 : 1) void k_zstd_decod
                             }
                             // ---- up to 64 short sequences inside the window ----
                             uint32_t end = lane < ncand ? tot : 0, lend = lane < ncand ? ll : 0;
-    #pragma unroll
-                            for (int d = 1; d < 64; d <<= 1) {
-                                const uint32_t y = __shfl_up(end, d), z = __shfl_up(lend, d);
-                                if (lane >= (uint32_t)d) { end += y; lend += z; }
-                            }
+                end = wave_incl_scan(end); lend = wave_incl_scan(lend);
                             uint32_t fit = (uint32_t)__popcll(__ballot(lane < ncand && end <= WIN_CAP - win_n));
                             if (fit == 0) {  // chunk full: stream it out, keep the newest bytes as history
                                 uint32_t h = 0;
@@ -1162,8 +1327,8 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES == 4 ? 4 : 1) void k_zstd_decod
                                 win_exec_group(W, out, opos, hist_n, lane, on, WIN_HIST + win_n + (end - tot), ll, ml, off,
                                                lit_ptr + lpos + (lend - ll), rle_lits, rle_byte);
                             }
-                            win_n += __shfl(end, fit - 1);
-                            lpos += __shfl(lend, fit - 1);
+                            win_n += rdlane_u(end, fit - 1);
+                            lpos += rdlane_u(lend, fit - 1);
                             si += fit;
                         }
                         if (dirty) wave_mem_sync();  // with the barrier below: direct stores of this batch have landed
@@ -1461,7 +1626,7 @@ void launch_finish_blocks(const BlockScanArgs &a, hipStream_t s) {
 // Anything unexpected (a checksum trailer, an offset past 2^29, pools exhausted, an error of any kind) leaves the
 // frame flagged: the serial decoder then takes it and produces the error code.
 // =============================================================================================
-constexpr uint32_t FZ_BACK = 16;  // how far back a Treeless / Repeat_Mode block looks for its table
+constexpr uint32_t FZ_BACK = 64;  // how far back a Treeless / Repeat_Mode block looks for its table
 
 struct FzTmp {  // scratch of fse_read_ncount / fse_build / huf_read_tree: one per wave
     int16_t norm[256];
@@ -1491,6 +1656,8 @@ struct FzShared {
     int32_t bs_pos;
     uint64_t seq_off;
     uint32_t sum_ll, sum_ml;
+    uint32_t rep_out[3];
+    uint32_t why;  // statistics: what sent the block to the serial decoder (1 table too far back, 2 pool full, 3 value range)
 };
 
 struct LitHdr { uint32_t type, regen, comp, hdr, streams; };
@@ -1713,6 +1880,7 @@ __global__ __launch_bounds__(128) void k_fz_entropy(FzArgs a, const uint32_t *wo
                 it.lit_kind = btype == 0 ? 0u : 1u;
                 it.lit_off = btype == 0 ? (uint64_t)pos + 3 : (uint64_t)bsrc[0];
                 it.err = 0;
+                it.rep[0] = FZ_SYM; it.rep[1] = FZ_SYM | (1u << 26); it.rep[2] = FZ_SYM | (2u << 26); it.pad = 0;
                 a.items[slot] = it;
             }
             __syncthreads();
@@ -1729,7 +1897,8 @@ __global__ __launch_bounds__(128) void k_fz_entropy(FzArgs a, const uint32_t *wo
                 S.seq_pos = fz_lit_section_bytes(h);
             }
             S.err = err;
-            S.nseq = 0; S.sum_ll = 0; S.sum_ml = 0; S.seq_off = 0;
+            S.nseq = 0; S.sum_ll = 0; S.sum_ml = 0; S.seq_off = 0; S.why = 0;
+            S.rep_out[0] = FZ_SYM; S.rep_out[1] = FZ_SYM | (1u << 26); S.rep_out[2] = FZ_SYM | (2u << 26);
         }
         __syncthreads();
         if (S.err == 0) {
@@ -1744,7 +1913,7 @@ __global__ __launch_bounds__(128) void k_fz_entropy(FzArgs a, const uint32_t *wo
                             uint32_t tu = 0;
                             err = huf_read_tree(S.ta, bsrc + p, remain, blob_end, &tu);
                             if (!err) { p += tu; remain -= tu; }
-                        } else err = fz_find_tree(S.ta, a, src, blob_end, base, k);
+                        } else { err = fz_find_tree(S.ta, a, src, blob_end, base, k); if (err == E_UNSUP) S.why = 1; }
                         if (!err) {
                             if (S.n_streams == 1) {
                                 S.stream_off[0] = p; S.stream_len[0] = remain; S.stream_out[0] = 0; S.stream_n[0] = regen;
@@ -1769,7 +1938,7 @@ __global__ __launch_bounds__(128) void k_fz_entropy(FzArgs a, const uint32_t *wo
                         if (!err) {
                             const uint64_t room = ((uint64_t)regen + 79) & ~15ull;
                             const uint64_t off = atomicAdd(&a.pool_used[0], (unsigned long long)room);
-                            if (off + room > a.lit_cap) err = E_UNSUP;
+                            if (off + room > a.lit_cap) { err = E_UNSUP; S.why = 2; }
                             S.lit_off = off;
                         }
                         if (err) atomicMin(&S.err, err);
@@ -1818,7 +1987,7 @@ __global__ __launch_bounds__(128) void k_fz_entropy(FzArgs a, const uint32_t *wo
                             err = fz_seq_tables(S, S.tb, b + ls, sz - ls, miss, &m2, &n2, &at2);
                             if (!err && n2) miss = m2;
                         }
-                        if (!err && miss) err = E_UNSUP;
+                        if (!err && miss) { err = E_UNSUP; S.why = 1; }
                     }
                     if (!err && nseq) {
                         if (bits_at >= qn) err = E_TRUNC;
@@ -1836,7 +2005,7 @@ __global__ __launch_bounds__(128) void k_fz_entropy(FzArgs a, const uint32_t *wo
                     }
                     if (!err && nseq) {
                         const uint64_t off = atomicAdd(&a.pool_used[1], (unsigned long long)nseq);
-                        if (off + nseq > a.seq_cap) err = E_UNSUP;
+                        if (off + nseq > a.seq_cap) { err = E_UNSUP; S.why = 2; }
                         S.seq_off = off;
                     }
                     S.nseq = nseq;
@@ -1873,6 +2042,7 @@ __global__ __launch_bounds__(128) void k_fz_entropy(FzArgs a, const uint32_t *wo
                                 *const tm2 = reinterpret_cast<const uint2 *>(tm);
                     unsigned long long *const recs = a.seq_pool + uni64(S.seq_off);
                     uint32_t sum_ll = 0, sum_ml = 0;
+                    uint32_t r0 = FZ_SYM, r1 = FZ_SYM | (1u << 26), r2 = FZ_SYM | (2u << 26);
                     int err = 0;
                     for (uint32_t i = 0; i < nseq; i++) {
                         const uint2 veo = to2[so], vem = tm2[sm], vel = tl2[sl];
@@ -1893,12 +2063,32 @@ __global__ __launch_bounds__(128) void k_fz_entropy(FzArgs a, const uint32_t *wo
                             so = (eox & 0xFFFF) + rd(nbo);
                         }
                         sum_ll += ll; sum_ml += ml;
-                        if (left < 0 || ofb > 28 || sum_ll + sum_ml > BLOCK_MAX) { err = left < 0 ? E_CORRUPT : E_UNSUP; break; }
-                        if (lane == 0) recs[i] = (unsigned long long)ll | ((unsigned long long)ml << 17) | ((unsigned long long)ov << 35);
+                        if (left < 0 || ofb > 27 || sum_ll + sum_ml > BLOCK_MAX) { err = left < 0 ? E_CORRUPT : E_UNSUP; if (lane == 0 && left >= 0) S.why = 3; break; }
+                        // repeat offsets (RFC 8878 3.1.1.5), against the symbolic incoming history
+                        uint32_t o;
+                        if (ov > 3) { o = ov - 3; r2 = r1; r1 = r0; r0 = o; }
+                        else {
+                            const uint32_t idx = ov - 1 + (ll == 0 ? 1u : 0u);
+                            if (idx == 0) o = r0;
+                            else {
+                                if (idx < 3) o = idx == 1 ? r1 : r2;
+                                else if (r0 & FZ_SYM) {  // incoming entry minus one more
+                                    o = r0 + 1;
+                                    if ((o & 0x3FFFFFFu) == 0x3FFFFFFu) { err = E_UNSUP; if (lane == 0) S.why = 3; break; }
+                                } else {
+                                    o = r0 - 1;
+                                    if (o == 0) { err = E_CORRUPT; break; }
+                                }
+                                if (idx > 1) r2 = r1;
+                                r1 = r0; r0 = o;
+                            }
+                        }
+                        if (lane == 0) recs[i] = (unsigned long long)ll | ((unsigned long long)ml << 17) | ((unsigned long long)o << 35);
                     }
                     if (!err && left != 0) err = E_CORRUPT;
                     if (lane == 0) {
                         S.sum_ll = sum_ll; S.sum_ml = sum_ml;
+                        S.rep_out[0] = r0; S.rep_out[1] = r1; S.rep_out[2] = r2;
                         if (err) atomicMin(&S.err, err);
                     }
                 }
@@ -1912,13 +2102,15 @@ __global__ __launch_bounds__(128) void k_fz_entropy(FzArgs a, const uint32_t *wo
             FzItem it;
             it.src = pos; it.out = S.lit_len + S.sum_ml; it.nseq = S.nseq; it.lit_len = S.lit_len;
             it.seq_off = S.seq_off; it.lit_off = S.lit_off; it.lit_kind = S.lit_kind; it.err = err;
+            it.rep[0] = S.rep_out[0]; it.rep[1] = S.rep_out[1]; it.rep[2] = S.rep_out[2]; it.pad = 0;
             a.items[slot] = it;
-            if (err) atomicAdd(&a.pool_used[3], 1ull);  // statistics: blocks left to the serial decoder
+            if (err) { atomicAdd(&a.pool_used[3], 1ull); atomicAdd(&a.pool_used[4 + (S.why & 3)], 1ull); }  // statistics: blocks left to the serial decoder, and why
         }
         __syncthreads();
     }
 }
 
+template <bool PROF>
 __global__ __launch_bounds__(64) void k_fz_exec(FzArgs a) {
     __shared__ __attribute__((aligned(16))) uint8_t W[WIN_HIST + WIN_CAP + 64];
     const uint32_t c = blockIdx.x, lane = threadIdx.x;
@@ -1943,6 +2135,12 @@ __global__ __launch_bounds__(64) void k_fz_exec(FzArgs a) {
     uint32_t win_n = 0, hist_n = 0, r0 = 1, r1 = 4, r2 = 8;
     bool dirty = false;
     int err = 0;
+    ExecProf prof;
+    unsigned long long p_groups = 0, p_seqs = 0, p_big = 0, p_flush = 0, p_hist = 0, p_rep = 0;
+    unsigned long long c_rec = 0, c_rep = 0, c_big = 0, c_flush = 0, c_hist = 0, c_tail = 0, t_mark = 0;
+    const unsigned long long t_begin = PROF ? __builtin_amdgcn_s_memtime() : 0;
+#define FZ_T0() do { if (PROF) t_mark = __builtin_amdgcn_s_memtime(); } while (0)
+#define FZ_T1(acc) do { if (PROF) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); const unsigned long long n_ = __builtin_amdgcn_s_memtime(); acc += n_ - t_mark; t_mark = n_; } } while (0)
     for (uint32_t k = 0; k < nb && !err; k++) {
         const FzItem it = a.items[base + k];
         const uint32_t nseq = uni(it.nseq), lit_len = uni(it.lit_len), kind = uni(it.lit_kind);
@@ -1955,42 +2153,27 @@ __global__ __launch_bounds__(64) void k_fz_exec(FzArgs a) {
         for (uint32_t g0 = 0; g0 < nseq && !err; g0 += 64) {
             const uint32_t cnt = nseq - g0 < 64 ? nseq - g0 : 64;
             const bool on = lane < cnt;
+            FZ_T0();
             const unsigned long long rec = on ? recs[g0 + lane] : 0ull;
+            FZ_T1(c_rec);
+            if (PROF) { p_groups++; p_seqs += cnt; }
             const uint32_t ll0 = (uint32_t)rec & 0x1FFFFu, ml0 = (uint32_t)(rec >> 17) & 0x3FFFFu;
             const uint32_t ov = on ? (uint32_t)(rec >> 35) : 4u;
-            uint32_t offset = ov - 3;
-            // repeat offsets: only a group that contains one walks its sequences in order (scalar unit)
-            if (__ballot(on && ov <= 3) != 0ull || cnt < 3) {
-                for (uint32_t j = 0; j < cnt; j++) {
-                    const uint32_t ovj = uni(__shfl(ov, j)), llj = uni(__shfl(ll0, j));
-                    uint32_t o;
-                    if (ovj > 3) { o = ovj - 3; r2 = r1; r1 = r0; r0 = o; }
-                    else {
-                        const uint32_t idx = ovj - 1 + (llj == 0 ? 1 : 0);
-                        if (idx == 0) o = r0;
-                        else {
-                            o = idx == 1 ? r1 : (idx == 2 ? r2 : r0 - 1);
-                            if (o == 0) { err = E_CORRUPT; break; }
-                            if (idx > 1) r2 = r1;
-                            r1 = r0; r0 = o;
-                        }
-                    }
-                    if (lane == j) offset = o;
-                }
-                if (err) break;
-            } else {
-                r0 = uni(__shfl(offset, cnt - 1)); r1 = uni(__shfl(offset, cnt - 2)); r2 = uni(__shfl(offset, cnt - 3));
+            // offsets come resolved from the entropy phase, up to the history this block started with
+            uint32_t offset = ov;
+            if (ov & FZ_SYM) {
+                const uint32_t kk = (ov >> 26) & 3, dd = ov & 0x3FFFFFFu;
+                const uint32_t in = kk == 0 ? r0 : (kk == 1 ? r1 : r2);
+                offset = in > dd ? in - dd : 0u;
             }
+            if (__ballot(on && offset == 0) != 0ull) { err = E_CORRUPT; break; }
             {
                 uint32_t linc = ll0, pinc = ll0 + ml0;
-#pragma unroll
-                for (int d = 1; d < 64; d <<= 1) {
-                    const uint32_t y = __shfl_up(linc, d), z = __shfl_up(pinc, d);
-                    if (lane >= (uint32_t)d) { linc += y; pinc += z; }
-                }
+linc = wave_incl_scan(linc); pinc = wave_incl_scan(pinc);
                 const bool bad = on && ((uint64_t)offset > opos + win_n + pinc - ml0 || lpos + linc > lit_len);
                 if (__ballot(bad) != 0ull) { err = E_CORRUPT; break; }
             }
+            FZ_T1(c_rep);
             // ---- execute the group (the narrow serial decoder's window scheme, one wave) ----
             uint32_t si = 0;
             while (si < cnt) {
@@ -2003,6 +2186,8 @@ __global__ __launch_bounds__(64) void k_fz_exec(FzArgs a) {
                 const uint32_t nv = cnt - si;
                 const uint32_t ncand = bigm ? (uint32_t)__ffsll((long long)bigm) - 1 : nv;
                 if (ncand == 0) {
+                    FZ_T0();
+                    if (PROF) p_big++;
                     // one long sequence, straight to HBM (the window is emptied first)
                     if (win_n) {
                         (void)win_flush(W, out, opos, win_n, hist_n, lane, false);
@@ -2010,7 +2195,7 @@ __global__ __launch_bounds__(64) void k_fz_exec(FzArgs a) {
                         win_n = 0;
                     }
                     hist_n = 0;
-                    const uint32_t llx = uni(__shfl(ll, 0)), mlx = uni(__shfl(ml, 0)), offx = uni(__shfl(off, 0));
+                    const uint32_t llx = rdlane_u(ll, 0), mlx = rdlane_u(ml, 0), offx = rdlane_u(off, 0);
                     if (llx) {
                         if (rle_lits) coop_fill(out + opos, rle_byte, llx, lane, 64);
                         else coop_copy(out + opos, lit_ptr + lpos, llx, lane, 64);
@@ -2021,37 +2206,54 @@ __global__ __launch_bounds__(64) void k_fz_exec(FzArgs a) {
                     opos += mlx;
                     dirty = true;
                     si++;
+                    FZ_T1(c_big);
                     continue;
                 }
                 uint32_t end = lane < ncand ? tot : 0, lend = lane < ncand ? ll : 0;
-#pragma unroll
-                for (int d = 1; d < 64; d <<= 1) {
-                    const uint32_t y = __shfl_up(end, d), z = __shfl_up(lend, d);
-                    if (lane >= (uint32_t)d) { end += y; lend += z; }
-                }
+                end = wave_incl_scan(end); lend = wave_incl_scan(lend);
                 uint32_t fit = (uint32_t)__popcll(__ballot(lane < ncand && end <= WIN_CAP - win_n));
                 if (fit == 0) {  // chunk full: stream it out, keep the newest bytes as history
+                    FZ_T0();
+                    if (PROF) p_flush++;
                     (void)win_flush(W, out, opos, win_n, hist_n, lane, true);
                     hist_n = hist_n + win_n < WIN_HIST ? hist_n + win_n : WIN_HIST;
                     opos += win_n;
                     win_n = 0;
                     fit = (uint32_t)__popcll(__ballot(lane < ncand && end <= WIN_CAP));
+                    FZ_T1(c_flush);
                 }
                 if (dirty) { wave_mem_sync(); dirty = false; }
                 const uint32_t want_h = opos < WIN_HIST ? (uint32_t)opos : WIN_HIST;
                 if (win_n == 0 && hist_n < want_h) {  // history lost to a direct copy: read the newest output back
+                    FZ_T0();
+                    if (PROF) p_hist++;
                     coop_copy(W + WIN_HIST - want_h, out + opos - want_h, want_h, lane, 64);
                     hist_n = want_h;
+                    FZ_T1(c_hist);
                 }
                 win_exec_group(W, out, opos, hist_n, lane, lane < fit, WIN_HIST + win_n + (end - tot), ll, ml, off,
-                               lit_ptr + lpos + (lend - ll), rle_lits, rle_byte);
-                win_n += __shfl(end, fit - 1);
-                lpos += __shfl(lend, fit - 1);
+                               lit_ptr + lpos + (lend - ll), rle_lits, rle_byte, PROF ? &prof : nullptr);
+                win_n += rdlane_u(end, fit - 1);
+                lpos += rdlane_u(lend, fit - 1);
                 si += fit;
             }
         }
         if (err) break;
+        {   // the history this block leaves
+            uint32_t nr[3];
+#pragma unroll
+            for (int i = 0; i < 3; i++) {
+                const uint32_t x = uni(it.rep[i]);
+                if (x & FZ_SYM) {
+                    const uint32_t kk = (x >> 26) & 3, dd = x & 0x3FFFFFFu;
+                    const uint32_t in = kk == 0 ? r0 : (kk == 1 ? r1 : r2);
+                    nr[i] = in > dd ? in - dd : 0u;
+                } else nr[i] = x;
+            }
+            r0 = nr[0]; r1 = nr[1]; r2 = nr[2];
+        }
         // literals left after the last sequence, then the window goes out (history stays for the next block)
+        FZ_T0();
         const uint32_t rest = lit_len - lpos;
         if (opos + win_n + rest > fcs) { err = E_CORRUPT; break; }
         const bool in_win = rest <= WIN_CAP - win_n;
@@ -2071,7 +2273,15 @@ __global__ __launch_bounds__(64) void k_fz_exec(FzArgs a) {
         opos += win_n + rest;
         win_n = 0;
         hist_n = in_win ? h : 0;
+        FZ_T1(c_tail);
     }
+    if (PROF && a.dbg && lane == 0) {
+        const unsigned long long vals[17] = {1, p_groups, p_seqs, p_big, prof.rounds, p_flush, p_hist, p_rep,
+                                             __builtin_amdgcn_s_memtime() - t_begin, c_rec, c_rep, c_big, c_flush, c_hist, prof.t_lits, prof.t_match, c_tail};
+        for (int i = 0; i < 17; i++) atomicAdd(&a.dbg[i], vals[i]);
+    }
+#undef FZ_T0
+#undef FZ_T1
     if (!err && opos == fcs && lane == 0) {
         a.row_flag[row] = 0;  // k_finish_blocks turns this into status 2 (hash me)
         atomicAdd(&a.pool_used[2], 1ull);  // statistics: frames decoded by this path
@@ -2086,7 +2296,8 @@ void launch_fz_entropy(const FzArgs &a, int cus, const uint32_t *work, const uin
     hipLaunchKernelGGL(k_fz_entropy, dim3(grid), dim3(128), 0, s, a, work, work_count);
 }
 void launch_fz_exec(const FzArgs &a, hipStream_t s) {
-    hipLaunchKernelGGL(k_fz_exec, dim3(a.n_cand), dim3(64), 0, s, a);
+    if (a.dbg) hipLaunchKernelGGL(k_fz_exec<true>, dim3(a.n_cand), dim3(64), 0, s, a);
+    else hipLaunchKernelGGL(k_fz_exec<false>, dim3(a.n_cand), dim3(64), 0, s, a);
 }
 
 int decode_grid_size(int device) {

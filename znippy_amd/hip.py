@@ -178,9 +178,10 @@ class RowTable:
 
     def foreign_stats(self):
         """Last run's two-phase path for foreign multi-block frames: pool use, frames it decoded, blocks it gave up."""
-        st = (C.c_uint64 * 4)()
+        st = (C.c_uint64 * 8)()
         self.ctx._chk(self.ctx.L.znippy_rows_foreign_stats(self.ctx.h, self.h, st), "znippy_rows_foreign_stats")
-        return dict(lit_pool_bytes=int(st[0]), seq_pool_records=int(st[1]), frames=int(st[2]), blocks_given_up=int(st[3]))
+        return dict(lit_pool_bytes=int(st[0]), seq_pool_records=int(st[1]), frames=int(st[2]), blocks_given_up=int(st[3]),
+                    given_up_error=int(st[4]), given_up_table_far=int(st[5]), given_up_pool=int(st[6]), given_up_range=int(st[7]))
 
     def decode_verify(self, d_blobs, d_out, blob_base=0, out_cap=None, blob_cap=None):
         self.decode_verify_async(d_blobs, d_out, blob_base, out_cap, blob_cap)
