@@ -399,7 +399,7 @@ static int ensure_decoder(znippy_ctx *ctx) {
 // finds the pool empty simply stays with the serial decoder.  Both are capped (a 100 GB archive does not get 250 GB
 // of scratch): what does not fit is decoded serially.
 static int ensure_fz_pools(znippy_ctx *ctx, uint64_t content_bytes, uint32_t items) {
-    constexpr uint64_t CAP = 48ull << 30;
+    constexpr uint64_t CAP = 16ull << 30;
     const uint64_t lit = std::min<uint64_t>(content_bytes + 80ull * items + 4096, CAP);
     const uint64_t seq = std::min<uint64_t>(content_bytes * 3 / 2 + 4096, CAP) / 8;
     if (lit > ctx->fz_lit_cap) {
@@ -959,6 +959,17 @@ int znippy_decode_verify_rows_async(znippy_ctx *ctx, znippy_rows *r, const void 
         a.out = (uint8_t *)d_out; a.out_cap = out_cap;
         a.status = r->status; a.n_rows = r->n; a.cursor = r->cursor;
         a.lit_scratch = ctx->lit_scratch;
+        if (ctx->sw.ddbg) {  // diagnostic: phase shares of the previous general-decoder launch
+            static unsigned long long *dbg = nullptr;
+            if (!dbg) { (void)hipMalloc(&dbg, 64); (void)hipMemset(dbg, 0, 64); }
+            unsigned long long h[8];
+            (void)hipStreamSynchronize(s);
+            (void)hipMemcpy(h, dbg, 64, hipMemcpyDeviceToHost);
+            if (h[0]) fprintf(stderr, "[znippy ddbg] general decoder frames=%llu  kcycles per frame: header+literals=%.1f seq-tables=%.1f first-batch=%.1f decode+execute=%.1f tail=%.1f\n", h[0],
+                              h[1] / 1e3 / h[0], h[2] / 1e3 / h[0], h[3] / 1e3 / h[0], h[4] / 1e3 / h[0], h[5] / 1e3 / h[0]);
+            (void)hipMemset(dbg, 0, 64);
+            a.dbg = dbg;
+        }
         ktime_begin(ctx, "zstd_decode_general");
         launch_decode(a, std::min<int>(ctx->decode_grid, (int)r->n_compressed), r->wide_rows, s);
         ktime_end(ctx);
