@@ -57,6 +57,12 @@ int znippy_compress_stream(const char *output, int no_skip, int device, znippy_s
  * page-locked staging); full staging slots are encoded while the caller keeps sending. */
 int znippy_stream_send(znippy_stream *s, const char *relative_path, const void *data, size_t len,
                        int pkg_type, const char *repo);
+/* The same for n entries in one call (a caller that already holds its entries packed — the reference's reader stage
+ * hands StreamCompressor whole batches, stream_packer.rs:L146-206 — or a binding whose per-call cost matters):
+ * entry i has the path paths[path_off[i] .. path_off[i+1]) (no terminator) and the bytes data[data_off[i] .. data_off[i+1]);
+ * pkg_type may be NULL (= None for all), repo NULL = None for all.  Stops at the first error. */
+int znippy_stream_send_packed(znippy_stream *s, uint64_t n, const char *paths, const uint64_t *path_off,
+                              const void *data, const uint64_t *data_off, const int32_t *pkg_type, const char *repo);
 /* Drains the pipeline, writes the metadata layer of `<output>.znippy`, fills the report and frees the handle. */
 int znippy_stream_finish(znippy_stream *s, znippy_compression_report *report);
 

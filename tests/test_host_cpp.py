@@ -179,6 +179,38 @@ def test_cpp_compress_stream_roundtrip_and_cross_read(tmp_path):
 
 
 @gpu
+def test_cpp_stream_send_packed_writes_the_same_archive(tmp_path):
+    """n entries in ONE call (znippy_stream_send_packed) = the archive n send() calls write, byte for byte; offsets
+    that decrease are an error code."""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from znippy_amd import host
+    from znippy_amd.stream_packer import ArchiveEntry
+    datas = [gen.pseudo_text(3000 + 977 * i, seed=i) if i % 5 else b"" for i in range(60)] + [gen.binary(9 * 1024 * 1024 + 17)]
+    names = [f"d{i % 4}/f{i:03}.txt" for i in range(60)] + ["big/blob.bin"]
+    a = host.compress_stream(tmp_path / "one.tmp", False)
+    for nm, d in zip(names, datas):
+        a.send(ArchiveEntry(nm, d))
+    ra = a.finish()
+    b = host.compress_stream(tmp_path / "packed.tmp", False)
+    offs = np.concatenate([[0], np.cumsum([len(d) for d in datas])]).astype(np.uint64)
+    b.send_packed(names[:20], b"".join(datas), offs[:21])
+    b.send_packed(names[20:], b"".join(datas), offs[20:])
+    rb = b.finish()
+    assert ra == rb
+    assert (tmp_path / "one.znippy").read_bytes() == (tmp_path / "packed.znippy").read_bytes()
+    v = host.decompress_archive(tmp_path / "packed.znippy", True, tmp_path / "out")
+    assert (v.corrupt_files, v.total_files) == (0, len(names))
+    for nm, d in zip(names, datas):
+        assert (tmp_path / "out" / nm).read_bytes() == d
+    c = host.compress_stream(tmp_path / "bad.tmp", False)
+    with pytest.raises(Exception):
+        c.send_packed(["x", "y"], b"abcdef", np.array([0, 4, 2], np.uint64))
+    c.finish()
+
+
+@gpu
 def test_cpp_reads_python_written_archive_and_random_access(tmp_path):
     import torch
     if not torch.cuda.is_available():

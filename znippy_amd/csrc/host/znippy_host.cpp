@@ -652,6 +652,22 @@ static int znippy_stream_send_impl(znippy_stream *s, const char *relative_path, 
     return ZNIPPY_OK;
 }
 
+static int znippy_stream_send_packed_impl(znippy_stream *s, uint64_t n, const char *paths, const uint64_t *path_off, const void *data,
+                                          const uint64_t *data_off, const int32_t *pkg_type, const char *repo) {
+    if (!s || (n && (!paths || !path_off || !data_off))) return fail(ZNIPPY_E_INVAL, "null argument");
+    std::string path;
+    for (uint64_t i = 0; i < n; i++) {
+        if (path_off[i + 1] < path_off[i] || data_off[i + 1] < data_off[i]) return fail(ZNIPPY_E_INVAL, "offsets must not decrease");
+        path.assign(paths + path_off[i], paths + path_off[i + 1]);
+        const uint64_t len = data_off[i + 1] - data_off[i];
+        if (len && !data) return fail(ZNIPPY_E_INVAL, "null data");
+        const int rc = znippy_stream_send_impl(s, path.c_str(), len ? (const uint8_t *)data + data_off[i] : nullptr, (size_t)len,
+                                               pkg_type ? (int)pkg_type[i] : -1, repo);
+        if (rc) return rc;
+    }
+    return ZNIPPY_OK;
+}
+
 static int znippy_stream_finish_impl(znippy_stream *sp, znippy_compression_report *report) {
     if (!sp) return fail(ZNIPPY_E_INVAL, "null stream");
     std::unique_ptr<znippy_stream> s(sp);
@@ -1293,6 +1309,11 @@ int znippy_compress_stream(const char *output, int no_skip, int device, znippy_s
 
 int znippy_stream_send(znippy_stream *s, const char *relative_path, const void *data, size_t len, int pkg_type, const char *repo) {
     return guarded([&] { return znippy_stream_send_impl(s, relative_path, data, len, pkg_type, repo); });
+}
+
+int znippy_stream_send_packed(znippy_stream *s, uint64_t n, const char *paths, const uint64_t *path_off, const void *data,
+                              const uint64_t *data_off, const int32_t *pkg_type, const char *repo) {
+    return guarded([&] { return znippy_stream_send_packed_impl(s, n, paths, path_off, data, data_off, pkg_type, repo); });
 }
 
 int znippy_stream_finish(znippy_stream *sp, znippy_compression_report *report) {

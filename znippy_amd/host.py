@@ -27,7 +27,7 @@ class _ME(C.Structure):
 
 
 HOST_EXPORTS = [
-    "znippy_host_last_error", "znippy_compress_stream", "znippy_stream_send", "znippy_stream_finish",
+    "znippy_host_last_error", "znippy_compress_stream", "znippy_stream_send", "znippy_stream_send_packed", "znippy_stream_finish",
     "znippy_compress_dir", "znippy_decompress_archive", "znippy_archive_open", "znippy_archive_file_count", "znippy_archive_file_size",
     "znippy_archive_extract_file", "znippy_archive_extract_file_verified", "znippy_archive_close", "znippy_index_open", "znippy_index_rows",
     "znippy_index_manifest_len", "znippy_index_manifest_entry", "znippy_index_row", "znippy_index_metadata",
@@ -44,6 +44,7 @@ def lib():
         L.znippy_host_last_error.restype = C.c_char_p
         L.znippy_compress_stream.argtypes = [C.c_char_p, C.c_int, C.c_int, C.POINTER(vp)]
         L.znippy_stream_send.argtypes = [vp, C.c_char_p, vp, C.c_size_t, C.c_int, C.c_char_p]
+        L.znippy_stream_send_packed.argtypes = [vp, C.c_uint64, vp, vp, vp, vp, vp, C.c_char_p]
         L.znippy_stream_finish.argtypes = [vp, C.POINTER(_CR)]
         L.znippy_compress_dir.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.c_char_p, C.c_int, C.POINTER(_CR)]
         L.znippy_decompress_archive.argtypes = [C.c_char_p, C.c_int, C.c_char_p, C.c_int, C.c_uint32, C.c_uint32,
@@ -101,6 +102,25 @@ class StreamCompressor:
         _chk(lib().znippy_stream_send(self.h, entry.relative_path.encode(), data, len(data),
                                       -1 if entry.pkg_type is None else int(entry.pkg_type),
                                       None if entry.repo is None else entry.repo.encode()), "stream_send")
+
+    def send_packed(self, paths, data, data_off, pkg_type=None, repo=None):
+        """n entries in one call: `paths` a list of str, `data` one contiguous buffer (bytes / numpy uint8), `data_off`
+        n + 1 offsets into it.  The per-entry work (chunking, the one copy into staging) is the same as send()'s; what goes
+        away is n trips through the binding."""
+        import numpy as np
+        enc = [p.encode() for p in paths]
+        n = len(enc)
+        poff = np.zeros(n + 1, np.uint64)
+        np.cumsum([len(p) for p in enc], out=poff[1:])
+        pblob = b"".join(enc)
+        doff = np.ascontiguousarray(np.asarray(data_off, dtype=np.uint64))
+        assert doff.size == n + 1
+        buf = np.frombuffer(data, dtype=np.uint8) if not isinstance(data, np.ndarray) else np.ascontiguousarray(data, dtype=np.uint8)
+        assert int(doff[-1]) <= buf.size
+        pk = None if pkg_type is None else np.ascontiguousarray(np.asarray(pkg_type, dtype=np.int32))
+        _chk(lib().znippy_stream_send_packed(self.h, n, pblob, poff.ctypes.data_as(vp), buf.ctypes.data_as(vp), doff.ctypes.data_as(vp),
+                                             None if pk is None else pk.ctypes.data_as(vp),
+                                             None if repo is None else repo.encode()), "stream_send_packed")
 
     def finish(self) -> ix.CompressionReport:
         r = _CR()
