@@ -148,3 +148,13 @@ def test_two_phase_matches_serial_bytes(gpu_ctx, oracle):
     assert c1 == c2 and (s1 == s2).all() and (o1 == o2).all()
     assert o1.tobytes() == data
     assert "zstd_foreign_entropy" in kt1 and "zstd_foreign_entropy" not in kt2
+
+
+def test_mutated_real_text_frames_agree_with_oracle(gpu_ctx, oracle):
+    """Real-text multi-block frames at level 19 (Treeless literals, Repeat_Mode tables, repeat offsets across blocks),
+    damaged anywhere: the oracle's verdict is the GPU's, accepted mutants decode to the oracle's bytes, and nothing is
+    ever reported verified with different bytes (the harness of test_gpu_fuzz.py)."""
+    from test_gpu_fuzz import _run as fuzz_run
+    data = _py_corpus(1 << 20)
+    bases = [(data[:400_000], 19), (data[400_000:400_000 + 262_145], 19), (data[700_000:1_000_000], 3)]
+    fuzz_run(gpu_ctx, oracle, bases, 60, 4242, 10, 60)
