@@ -199,3 +199,21 @@ def test_skippable_frames_in_front_of_a_frame(gpu_ctx, oracle):
     from znippy_amd._lib import ZnippyError
     with pytest.raises(ZnippyError):
         hip.get_decompressed_size(struct.pack("<II", 0x184D2A50, 500) + frame[:20])   # skippable frame runs past the input
+
+
+def test_tables_outliving_their_context_are_closed_with_it():
+    """A table collected after Context.close() used to call its destroy entry point with a freed context."""
+    import gc
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from znippy_amd import hip
+    ctx = hip.Context(0)
+    rt = hip.RowTable(ctx, np.zeros(1, np.uint64), np.array([4], np.uint64), np.array([4], np.uint64), np.zeros(1, np.uint64),
+                      np.zeros(1, np.uint8), np.zeros((1, 32), np.uint8))
+    rd = hip.RoundTable(ctx, np.zeros(1, np.uint64), np.array([4], np.uint64))
+    ctx.close()
+    assert rt.h is None and rd.h is None
+    del rt, rd
+    gc.collect()
+    ctx.close()  # idempotent

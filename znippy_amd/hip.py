@@ -2,6 +2,7 @@
 tensors (PyTorch-ROCm is only the allocator/stream provider); every compute call goes through
 libznippy_hip.so."""
 import ctypes as C
+import weakref
 
 import numpy as np
 
@@ -46,9 +47,12 @@ class Context:
             raise ZnippyError(rc, "znippy_ctx_create")
         self.h = h
         self.device = int(device)
+        self._tables = weakref.WeakSet()  # row / round tables created on this context: they die before it does
 
     def close(self):
         if getattr(self, "h", None):
+            for t in list(getattr(self, "_tables", ())):  # a table destroyed after its context is a use-after-free in C
+                t.close()
             self.L.znippy_ctx_destroy(self.h)
             self.h = None
 
@@ -140,6 +144,7 @@ class RowTable:
                                           np_ptr(us), np_ptr(oo), np_ptr(ck) if ck is not None else None,
                                           row_begin, row_end, C.byref(h)), "znippy_rows_create")
         self.h = h
+        ctx._tables.add(self)
         self.row_begin, self.row_end = row_begin, row_end
         self.n = row_end - row_begin
         self._corrupt, self._k1 = _pinned((max(self.n, 1),), np.uint64)
@@ -147,7 +152,8 @@ class RowTable:
 
     def close(self):
         if getattr(self, "h", None):
-            self.ctx.L.znippy_rows_destroy(self.h)
+            if getattr(self.ctx, "h", None):
+                self.ctx.L.znippy_rows_destroy(self.h)
             self.h = None
 
     __del__ = close
@@ -207,10 +213,12 @@ class RoundTable:
         ctx._chk(ctx.L.znippy_rounds_create(ctx.h, np_ptr(so), np_ptr(ln), np_ptr(sk) if sk is not None else None,
                                             self.n, C.byref(h)), "znippy_rounds_create")
         self.h = h
+        ctx._tables.add(self)
 
     def close(self):
         if getattr(self, "h", None):
-            self.ctx.L.znippy_rounds_destroy(self.h)
+            if getattr(self.ctx, "h", None):
+                self.ctx.L.znippy_rounds_destroy(self.h)
             self.h = None
 
     __del__ = close
