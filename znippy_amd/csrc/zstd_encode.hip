@@ -537,6 +537,7 @@ __global__ __launch_bounds__(64) void k_zstd_encode(EncodeArgs a) {
         uint32_t anchor = PRE;  // first byte not yet covered by a sequence
         uint32_t emitted = PRE; // wide variant: literal bytes [anchor, emitted) are already written
         uint32_t base = 0, misses = 0;
+        bool gave_up = false;  // wide variant: incompressible block recognised early
         const uint32_t scan_end = nq >= 8 ? nq - 7 : 0;  // positions with >= 8 bytes ahead
         if constexpr (HASH_LOG == 13) {
             // Wide variant: every lane probes its position AND extends its own candidate (up to LMAX bytes), then the
@@ -590,6 +591,10 @@ __global__ __launch_bounds__(64) void k_zstd_encode(EncodeArgs a) {
                 if (!hitm) {
                     if (misses < 2) store_tail();  // a run of misses is incompressible data: leave it to one bulk copy later
                     misses++;
+                    // 96 windows in a row (21 KiB of the block sampled, 64 positions each) without one 4-byte repeat, and no
+                    // sequence so far: the block is incompressible data (BASELINE's random.bin).  Stop searching — every
+                    // further window is another dependent memory round trip — and let the block go out raw.
+                    if (nseq == 0 && misses >= 96) { gave_up = true; break; }
                     base += 64 * (1 + (misses >> 4 > 7 ? 7 : misses >> 4));  // accelerate through incompressible data
                     continue;
                 }
@@ -747,7 +752,7 @@ __global__ __launch_bounds__(64) void k_zstd_encode(EncodeArgs a) {
         // trailing literals (the wide variant has written most of them already)
         {
             const uint32_t e0 = (HASH_LOG == 13 && emitted > anchor) ? emitted : anchor;
-            if (e0 < nq) wave_copy(lits + lit_total + (e0 - anchor), inb + e0, nq - e0, lane);
+            if (e0 < nq && !gave_up) wave_copy(lits + lit_total + (e0 - anchor), inb + e0, nq - e0, lane);  // (a block given up on goes out raw, straight from the input)
         }
         lit_total += nq - anchor;
         __syncthreads();  // sequences + literal bytes of all lanes are visible to lane 0
@@ -755,7 +760,7 @@ __global__ __launch_bounds__(64) void k_zstd_encode(EncodeArgs a) {
         ESTAMP(2);
         // ---- entropy stage: literals (Huffman in the wide variant when it pays), headers, sequences bitstream ----
         uint32_t lit_sec = 0;  // bytes of the literals section at blk + 3
-        if (HASH_LOG == 13 && lit_total >= HUF_MIN_LITS)
+        if (HASH_LOG == 13 && lit_total >= HUF_MIN_LITS && !gave_up)
             lit_sec = huf_literals(S, lits, lit_total, lits + ((lit_total + 3) & ~3u), blk + 3, lane);
         ESTAMP(3);
         bool raw = nseq == 0 && lit_sec == 0;
