@@ -1130,6 +1130,10 @@ struct alignas(16) RolesShared {
     uint32_t next_iter;                  // the loaders' iteration counter (an iteration = one group of four slots)
     uint32_t cnt[R_SLOTS / R_GROUP];     // hashed slots of the group's current use
     uint32_t gen[R_SLOTS / R_GROUP];     // completed uses of the group (a loader refills it when gen == its next use)
+    // per hasher wave: the 60 leaf chaining values of the tile it hashed LAST (6 rows x 10 leaves), folded in place by
+    // lanes 60..63 while the wave's next tile is hashed (roles_hash_6x10)
+    __attribute__((aligned(16))) uint32_t tree[R_WAVES - R_LOADERS][64 * 8];
+    uint32_t sched[64];  // tree_op_6x10 tabulated: left node | right node << 8 | valid << 16 | root << 17
 };
 
 // One recognised row written by the whole wave from its window (R_LOADER_EMITS; lane = byte / 16-byte piece).
@@ -1285,10 +1289,146 @@ __device__ __forceinline__ void roles_loader(const FusedArgs &a, RolesShared &S)
     atomicAdd(&S.finished, lane == 0 ? 1u : 0u);
 }
 
+// ---- parent trees without passes of their own ------------------------------------------------------------------
+// A tile of BASELINE's shape is 6 rows x 10 leaves = 60 busy lanes per compress pass, and its 54 parent nodes used to
+// cost the workgroup 1.5 more passes per tile (folded four tiles at a time by whoever finished the group).  Here the
+// four idle lanes of every leaf pass compute parent nodes — of the tile this wave hashed BEFORE the current one, whose
+// leaf CVs wait in the wave's private node array: 16 passes x 4 lanes = 64 slots for 54 nodes, level by level
+// (10 leaves: 5 + 2 + 1 + 1 per row), every node written over its left child.  Node operation n of the schedule:
+//   n in [ 0,30)  level 1   row n/5, pair j = n%5:   (10 row + 2j, + 1)
+//   n in [32,44)  level 2   row (n-32)/2, j:         (10 row + 4j, + 2)      [the fifth level-1 node is carried]
+//   n in [44,50)  level 3   row n-44:                (10 row, + 4)
+//   n in [52,58)  root      row n-52:                (10 row, + 8)  -> the row's digest
+// Pass b runs operations 4b .. 4b+3, so a level starts a full pass after the previous one ended.
+__device__ __forceinline__ bool tree_op_6x10(uint32_t n, uint32_t &l, uint32_t &r, bool &root) {
+    root = false;
+    if (n < 30) { const uint32_t row = n / 5, j = n - 5 * row; l = row * 10 + 2 * j; r = l + 1; return true; }
+    if (n >= 32 && n < 44) { const uint32_t m = n - 32, row = m >> 1, j = m & 1; l = row * 10 + 4 * j; r = l + 2; return true; }
+    if (n >= 44 && n < 50) { l = (n - 44) * 10; r = l + 4; return true; }
+    if (n >= 52 && n < 58) { l = (n - 52) * 10; r = l + 8; root = true; return true; }
+    l = r = 0;
+    return false;
+}
+
+// The leaf pass of a 6 x 10 tile staged in `slot` (windows extended by the caller), rows stored from the message
+// registers; lanes 60..63 fold the previous tile's tree (have_prev) in `tree` and write its digests.
+__device__ __forceinline__ void roles_hash_6x10(const FusedArgs &a, RolesShared &S, uint32_t slot, uint32_t *tree, bool have_prev,
+                                                uint32_t prev_first, uint32_t cv[8]) {
+    typedef __attribute__((address_space(3))) uint32_t lds32;
+    const uint32_t lane = threadIdx.x & 63;
+    const bool leaf = lane < 60;
+    const uint32_t row = leaf ? lane / 10 : 0, kk = leaf ? lane - 10 * row : 0, ps = lane - 60;
+    const uint8_t *const Y = S.slots[slot] + S.dy[slot][row];
+    const uint32_t yB = S.dB[slot][row], yoff = S.doff[slot][row], yL0 = yB + yoff;
+    uint32_t p = kk << 10;
+    const uint32_t p1 = p > yL0 ? p : ((yL0 >> 6) + 1) << 6;  // first block read through the period
+    uint32_t r = (p1 - yB) % yoff;
+    const uint32_t step64 = 64 % yoff;
+    uint8_t *const dst = a.h.srcB + S.oo[slot][row] + p;
+    const bool store = !(a.dbg & 16);
+    b3::set_iv(cv);
+    uint4 n0 = make_uint4(0, 0, 0, 0), n1 = n0, n2 = n0, n3 = n0;
+    auto fetch = [&]() {
+        const uint8_t *q = Y + p;
+        if (p > yL0) {
+            q = Y + yB + r;
+            r += step64;
+            if (r >= yoff) r -= yoff;
+        }
+        const lds_u4 *q3 = (const lds_u4 *)q;
+        const u4v a0 = q3[0], a1 = q3[1], a2 = q3[2], a3 = q3[3];
+        n0 = make_uint4(a0.x, a0.y, a0.z, a0.w); n1 = make_uint4(a1.x, a1.y, a1.z, a1.w);
+        n2 = make_uint4(a2.x, a2.y, a2.z, a2.w); n3 = make_uint4(a3.x, a3.y, a3.z, a3.w);
+        p += 64;
+    };
+    if (leaf) fetch();
+#pragma unroll 1
+    for (uint32_t b = 0; b < 16; b++) {
+        uint32_t m[16];
+        uint32_t cnt = kk, flags = (b == 0 ? b3::CHUNK_START : 0u) | (b == 15 ? b3::CHUNK_END : 0u);
+        uint32_t outn = 0;
+        bool op = false, root = false;
+        if (leaf) {
+            m[0] = n0.x; m[1] = n0.y; m[2] = n0.z; m[3] = n0.w; m[4] = n1.x; m[5] = n1.y; m[6] = n1.z; m[7] = n1.w;
+            m[8] = n2.x; m[9] = n2.y; m[10] = n2.z; m[11] = n2.w; m[12] = n3.x; m[13] = n3.y; m[14] = n3.z; m[15] = n3.w;
+            if (b < 15) fetch();
+            if (store) {
+                uint8_t *d = dst + b * 64;
+                st16(d, make_uint4(m[0], m[1], m[2], m[3]));
+                st16(d + 16, make_uint4(m[4], m[5], m[6], m[7]));
+                st16(d + 32, make_uint4(m[8], m[9], m[10], m[11]));
+                st16(d + 48, make_uint4(m[12], m[13], m[14], m[15]));
+            }
+        } else {
+            const uint32_t e = S.sched[4 * b + ps];
+            const uint32_t l = e & 0xFF, rr = (e >> 8) & 0xFF;
+            op = (e >> 16 & 1) && have_prev;
+            root = e >> 17 & 1;
+            const lds_u4a *L = (const lds_u4a *)(tree + l * 8), *R = (const lds_u4a *)(tree + rr * 8);
+            const u4v l0 = L[0], l1 = L[1], r0 = R[0], r1 = R[1];
+            m[0] = l0.x; m[1] = l0.y; m[2] = l0.z; m[3] = l0.w; m[4] = l1.x; m[5] = l1.y; m[6] = l1.z; m[7] = l1.w;
+            m[8] = r0.x; m[9] = r0.y; m[10] = r0.z; m[11] = r0.w; m[12] = r1.x; m[13] = r1.y; m[14] = r1.z; m[15] = r1.w;
+            b3::set_iv(cv);
+            cnt = 0;
+            flags = b3::PARENT | (root ? b3::ROOT : 0u);
+            outn = l;
+        }
+        b3::compress(cv, m, cnt, 0, 64, flags);
+        if (!leaf && op) {
+            if (root) {
+                uint4 *o = reinterpret_cast<uint4 *>(a.h.digests + (size_t)(prev_first + outn / 10) * 8);
+                o[0] = make_uint4(cv[0], cv[1], cv[2], cv[3]);
+                o[1] = make_uint4(cv[4], cv[5], cv[6], cv[7]);
+            } else {
+                lds_u4a *o = (lds_u4a *)(tree + outn * 8);
+                o[0] = u4v{cv[0], cv[1], cv[2], cv[3]};
+                o[1] = u4v{cv[4], cv[5], cv[6], cv[7]};
+            }
+        }
+    }
+    (void)sizeof(lds32);
+}
+
+// The tree of the last tile a wave hashed, with nobody's leaf pass to ride on: four level steps, all lanes.
+__device__ __forceinline__ void roles_flush_tree_6x10(const FusedArgs &a, uint32_t *tree, uint32_t prev_first) {
+    const uint32_t lane = threadIdx.x & 63;
+#pragma unroll 1
+    for (uint32_t lv = 0; lv < 4; lv++) {
+        const uint32_t base = lv == 0 ? 0u : (lv == 1 ? 32u : (lv == 2 ? 44u : 52u));
+        const uint32_t cntl = lv == 0 ? 30u : (lv == 1 ? 12u : 6u);
+        uint32_t l = 0, rr = 0;
+        bool root = false;
+        const bool on = lane < cntl && tree_op_6x10(base + lane, l, rr, root);
+        uint32_t cv[8], L[8], R[8];
+        const lds_u4a *pl = (const lds_u4a *)(tree + l * 8), *pr = (const lds_u4a *)(tree + rr * 8);
+        const u4v l0 = pl[0], l1 = pl[1], r0 = pr[0], r1 = pr[1];
+        L[0] = l0.x; L[1] = l0.y; L[2] = l0.z; L[3] = l0.w; L[4] = l1.x; L[5] = l1.y; L[6] = l1.z; L[7] = l1.w;
+        R[0] = r0.x; R[1] = r0.y; R[2] = r0.z; R[3] = r0.w; R[4] = r1.x; R[5] = r1.y; R[6] = r1.z; R[7] = r1.w;
+        b3::parent(cv, L, R, root);
+        __builtin_amdgcn_wave_barrier();  // every lane has read its children (a node only ever replaces its own left child)
+        if (on) {
+            if (root) {
+                uint4 *o = reinterpret_cast<uint4 *>(a.h.digests + (size_t)(prev_first + l / 10) * 8);
+                o[0] = make_uint4(cv[0], cv[1], cv[2], cv[3]);
+                o[1] = make_uint4(cv[4], cv[5], cv[6], cv[7]);
+            } else {
+                lds_u4a *o = (lds_u4a *)(tree + l * 8);
+                o[0] = u4v{cv[0], cv[1], cv[2], cv[3]};
+                o[1] = u4v{cv[4], cv[5], cv[6], cv[7]};
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 __device__ __forceinline__ void roles_hasher(const FusedArgs &a, RolesShared &S) {
     const uint32_t lane = threadIdx.x & 63;
     HashArgs h = a.h;
     h.pass = PASS_ALL;
+    uint32_t *const tree = S.tree[(threadIdx.x >> 6) - R_LOADERS];
+    bool have_prev = false;       // `tree` holds the leaf CVs of a 6 x 10 tile whose parents are still to be computed
+    uint32_t prev_first = 0;      // ... its first row
+    const bool inline_tree = !(a.dbg & 524288);
     for (;;) {
         const uint32_t take = uni(atomicAdd(&S.take, lane == 0 ? 1u : 0u));  // every lane executes it: see roles_loader
         bool go = false;
@@ -1298,7 +1438,10 @@ __device__ __forceinline__ void roles_hasher(const FusedArgs &a, RolesShared &S)
             if (f == R_LOADERS) break;               // nothing more will be published
             __builtin_amdgcn_s_sleep(2);
         }
-        if (!go) return;
+        if (!go) {
+            if (have_prev) roles_flush_tree_6x10(a, tree, prev_first);
+            return;
+        }
         asm volatile("" ::: "memory");
         const uint32_t slot = take & (R_SLOTS - 1), grp = slot / R_GROUP;
         const uint32_t nu = lds_ld(&S.nunits[slot]);
@@ -1321,6 +1464,21 @@ __device__ __forceinline__ void roles_hasher(const FusedArgs &a, RolesShared &S)
                 for (uint32_t q = 0; q < WROWS; q++)
                     if (q < nu) S.slots[slot][S.dy[slot][q] + S.dB[slot][q] + S.doff[slot][q] + lane] = bytes[q];
             }
+            // BASELINE's tile shape: the previous tile's parent tree rides in the four idle lanes of this tile's passes
+            const bool shape610 = inline_tree && !R_LOADER_EMITS && nu == 6 && t.n_leaves == 60 && !(a.dbg & 8192) &&
+                                  __ballot(lane < 6 && S.len[slot][lu] != 10240u) == 0ull;
+            if (shape610) {
+                uint32_t cv[8];
+                roles_hash_6x10(a, S, slot, tree, have_prev, prev_first, cv);
+                if (lane < 60) {  // the previous tree is done (its last node ran in pass 14): this tile's leaves take its place
+                    lds_u4a *o = (lds_u4a *)(tree + lane * 8);
+                    o[0] = u4v{cv[0], cv[1], cv[2], cv[3]};
+                    o[1] = u4v{cv[4], cv[5], cv[6], cv[7]};
+                }
+                have_prev = true;
+                prev_first = t.first_unit;
+                if (lane < WROWS) S.tn[slot][lane] = 0u;  // nothing left for the group's fold
+            } else {
             // the rows are stored by the lanes that hash them (their message registers) unless the loader wrote them
             LdsSrc ls{S.slots[slot], S.dy[slot], S.dB[slot], S.doff[slot], WROWS, nullptr,
                       lane < nu ? (uint64_t)S.len[slot][lu] : 0ull, 0ull, S.oo[slot][lu], 1u,
@@ -1342,6 +1500,7 @@ __device__ __forceinline__ void roles_hasher(const FusedArgs &a, RolesShared &S)
             if (lane < WROWS) {
                 S.tn[slot][lane] = (lane < nu && act) ? lo.u_cnt : 0u;
                 S.toff[slot][lane] = (slot % R_GROUP) * R_SLOT_NODES + lo.u_head;
+            }
             }
         } else if (lane < WROWS) {
             S.tn[slot][lane] = 0u;
@@ -1380,6 +1539,12 @@ __global__ __launch_bounds__(R_WAVES * 64) void k_fused_roles(FusedArgs a) {
     RolesShared &S = *reinterpret_cast<RolesShared *>(s_roles_raw);
     if (threadIdx.x == 0) { S.ready = 0; S.take = 0; S.finished = 0; S.next_iter = 0; }
     if (threadIdx.x < R_SLOTS / R_GROUP) { S.cnt[threadIdx.x] = 0; S.gen[threadIdx.x] = 0; }
+    if (threadIdx.x >= 64 && threadIdx.x < 128) {
+        uint32_t l, r;
+        bool root;
+        const bool ok = tree_op_6x10(threadIdx.x - 64, l, r, root);
+        S.sched[threadIdx.x - 64] = l | (r << 8) | (ok ? 1u << 16 : 0u) | (root ? 1u << 17 : 0u);
+    }
     __syncthreads();
     const bool clk = (a.dbg & 32768) && a.dbg_buf && blockIdx.x == 7 && threadIdx.x == 64 * R_LOADERS;
     const unsigned long long c0 = clk ? __builtin_amdgcn_s_memtime() : 0, r0 = clk ? __builtin_amdgcn_s_memrealtime() : 0;
