@@ -1,4 +1,5 @@
-"""Real-data check (not a BASELINE config): source text + shared objects found in the image, one Round per file
+"""(Lives under tests/ because it times the oracle's CPU loops beside the GPU path; not collected by pytest.)
+Real-data check (not a BASELINE config): source text + shared objects found in the image, one Round per file
 (8 MiB slices), GPU encoder ratio/time vs libzstd, GPU decode+verify time on both kinds of frames."""
 import os, sys, time, glob
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -4,15 +4,15 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch, gen
-from oracle import oracle as O
+import workloads
 from znippy_amd import hip
 n, sz = int(os.environ.get("N", 100000)), 10240
 ctx = hip.Context(0)
 chunk = gen.text(sz)
-frame = np.frombuffer(O.libzstd_compress(chunk, 19), dtype=np.uint8)
+frame = np.frombuffer(workloads.libzstd_compress(chunk, 19), dtype=np.uint8)
 fl = len(frame)
 d_blobs = torch.from_numpy(np.concatenate([np.tile(frame, n), np.zeros(64, np.uint8)])).cuda()
-want = np.frombuffer(O.blake3(chunk), dtype=np.uint8)
+want = np.frombuffer(ctx.blake3(chunk), dtype=np.uint8)
 ck = np.tile(want, (n, 1))
 rt = hip.RowTable(ctx, np.arange(n, dtype=np.uint64) * fl, np.full(n, fl, np.uint64), np.full(n, sz, np.uint64),
                   np.arange(n, dtype=np.uint64) * sz, None, ck)
