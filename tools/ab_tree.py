@@ -16,8 +16,12 @@ fl = len(frame)
 d_blobs = torch.from_numpy(np.concatenate([np.tile(frame, n), np.zeros(64, np.uint8)])).cuda()
 d_out = torch.zeros(n * sz + 64, dtype=torch.uint8, device="cuda")
 ctxs, tabs = [], []
+from znippy_amd import _lib, _build
 for d in (dA, dB):
     os.environ["ZNIPPY_DBG"] = d
+    if d is dB and os.environ.get("ZN_LIB_B"):  # second side from another build of the library (compile-time variants)
+        _lib._lib = None
+        _build.SO = os.path.abspath(os.environ["ZN_LIB_B"])
     c = hip.Context(0)
     ck = np.tile(np.frombuffer(c.blake3(chunk), dtype=np.uint8), (n, 1))
     ctxs.append(c)
