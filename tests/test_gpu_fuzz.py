@@ -130,3 +130,39 @@ def test_every_bit_of_block_heads_in_big_frames(gpu_ctx, oracle):
     header + first block) and of the tail of multi-block frames of periodic and raw data."""
     bases = [(_periodic(45, 3 * 128 * 1024, 4), 3), (gen.incompressible(8, 2 * 128 * 1024 + 5000), 1)]
     _run(gpu_ctx, oracle, bases, 96, 6, 20, 100, mutants=_all_bit_flips)
+
+
+def test_mutant_table_is_decoded_the_same_every_time(gpu_ctx, oracle):
+    """The exhaustive single-bit table (role-split kernel + its left-over list + general decoder in one run) ten times
+    over: the digests, statuses and counters of every run equal the first one's.  (A wrong digest for one valid row in
+    ~30 % of runs is how a race in the left-over path showed; a single run of the parity test above can miss it.)"""
+    import torch
+    from znippy_amd import hip
+    bases = [(gen.text(10240), 19), (gen.text(10240), 1), (_periodic(200, 20480, 2), 19), (gen.binary(10240), 3)]
+    rng = np.random.default_rng(5)
+    frames, sizes, originals = [], [], []
+    for data, lvl in bases:
+        for base in (oracle.libzstd_compress(data, lvl), gpu_ctx.compress(data)):
+            frames.append(base); sizes.append(len(data)); originals.append(data)
+            for m in _all_bit_flips(base, rng, 400):
+                frames.append(m); sizes.append(len(data)); originals.append(data)
+    n = len(frames)
+    bs = np.array([len(f) for f in frames], dtype=np.uint64)
+    bo = np.concatenate([[0], np.cumsum(bs)[:-1]]).astype(np.uint64)
+    us = np.array(sizes, dtype=np.uint64)
+    oo = np.concatenate([[0], np.cumsum(us)[:-1]]).astype(np.uint64)
+    ck = np.stack([np.frombuffer(oracle.blake3(d), dtype=np.uint8) for d in originals])
+    d_blobs = torch.from_numpy(np.frombuffer(b"".join(frames) + bytes(64), dtype=np.uint8).copy()).cuda()
+    d_out = torch.zeros(int(us.sum()) + 64, dtype=torch.uint8, device="cuda")
+    rt = hip.RowTable(gpu_ctx, bo, bs, us, oo, None, ck)
+    first = None
+    for rep in range(10):
+        counters, corrupt, status = rt.decode_verify(d_blobs, d_out)
+        got = (dict(counters), sorted(int(x) for x in corrupt), status.copy(), rt.digests()[status >= 0].copy())
+        if first is None:
+            first = got
+            assert n > 4000
+        else:
+            assert got[0] == first[0], (rep, got[0], first[0])
+            assert got[1] == first[1], (rep, sorted(set(got[1]) ^ set(first[1]))[:8])
+            assert (got[2] == first[2]).all() and (got[3] == first[3]).all(), rep
