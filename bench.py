@@ -172,18 +172,23 @@ def main():
             self.rows, self.table_ms = make_rows(a)
             self.pending = 0
             self.last = None
+            self.bad_steps = 0  # steps whose counters were not "every byte verified" (checked on the host, off the GPU's path)
+
+        def _take(self, c):
+            self.last = c
+            if c["corrupt_rows"] or c["decode_errors"] or c["verified_bytes"] != my_bytes:
+                self.bad_steps += 1
+            reduce_counters(c)
 
         def step(self):  # queue run k+1, then read run k
             self.rows.decode_verify_async(self.a["d_blobs"], d_out)
             if self.pending:
-                self.last = self.rows.results_lagged(1)
-                reduce_counters(self.last)
+                self._take(self.rows.results_lagged(1))
             self.pending = 1
 
         def drain(self):
             if self.pending:
-                self.last = self.rows.results_lagged(0)
-                reduce_counters(self.last)
+                self._take(self.rows.results_lagged(0))
                 self.pending = 0
 
     class WriteLeg:
@@ -252,6 +257,8 @@ def main():
     if dt_own is None:
         dt_own, k_own = dt_read, k_read
     dt_write, k_write = timed(WriteLeg(), args.steps, args.warmup)
+    for k, leg in legs.items():  # every step of every read leg (warmup, timed, kernel-time collection) verified every byte
+        assert leg.bad_steps == 0, f"{leg.bad_steps} steps of the {k} read leg did not verify"
 
     total_bytes = total_in * world if args.scaling == "weak" else total_in
     mbps = lambda dt: total_bytes / 2**20 / (dt / args.steps)
