@@ -158,3 +158,35 @@ def test_mutated_real_text_frames_agree_with_oracle(gpu_ctx, oracle):
     data = _py_corpus(1 << 20)
     bases = [(data[:400_000], 19), (data[400_000:400_000 + 262_145], 19), (data[700_000:1_000_000], 3)]
     fuzz_run(gpu_ctx, oracle, bases, 60, 4242, 10, 60)
+
+
+def test_checksummed_and_small_window_frames(gpu_ctx, oracle):
+    """Multi-block frames with a content-checksum trailer stay with the serial decoder (it verifies XXH64); a damaged
+    trailer is a per-row checksum error, as with libzstd.  A small window log (matches never reach further back than
+    128 KiB) goes through the two-phase path like any other frame."""
+    import torch
+    from znippy_amd import hip
+    data = _py_corpus(1 << 20)
+    e = [data[:500_000], data[500_000:900_000], data[200_000:700_000]]
+    frames = [workloads.libzstd_compress_adv(e[0], 19, checksum=True), workloads.libzstd_compress_adv(e[1], 3, checksum=True),
+              workloads.libzstd_compress_adv(e[2], 19, window_log=17)]
+    bad = bytearray(frames[1]); bad[-1] ^= 0x40            # the trailer itself
+    frames.append(bytes(bad)); e.append(e[1])
+    for f, d in zip(frames[:3], e[:3]):
+        assert oracle.zstd_decompress(f) == d
+    bs = np.array([len(f) for f in frames], np.uint64)
+    bo = np.concatenate([[0], np.cumsum(bs)[:-1]]).astype(np.uint64)
+    us = np.array([len(d) for d in e], np.uint64)
+    oo = np.concatenate([[0], np.cumsum(us)[:-1]]).astype(np.uint64)
+    ck = np.stack([np.frombuffer(oracle.blake3(d), dtype=np.uint8) for d in e])
+    d_blobs = torch.from_numpy(np.frombuffer(b"".join(frames) + bytes(64), dtype=np.uint8).copy()).cuda()
+    d_out = torch.zeros(int(us.sum()) + 64, dtype=torch.uint8, device="cuda")
+    rt = hip.RowTable(gpu_ctx, bo, bs, us, oo, None, ck)
+    c, corrupt, status = rt.decode_verify(d_blobs, d_out)
+    st = rt.foreign_stats()
+    assert list(status[:3]) == [0, 0, 0] and status[3] == -7, status      # ZNIPPY_E_CHECKSUM
+    assert c["decode_errors"] == 1 and c["corrupt_rows"] == 0
+    out = d_out.cpu().numpy()
+    for i in range(3):
+        assert out[int(oo[i]):int(oo[i] + us[i])].tobytes() == e[i]
+    assert st["frames"] == 1, st                                          # only the checksum-less frame took the two-phase path

@@ -76,3 +76,33 @@ def libzstd_compress(data, level=19) -> bytes:
     if z.ZSTD_isError(r):
         raise RuntimeError("ZSTD_compress failed")
     return out.raw[:r]
+
+
+def libzstd_compress_adv(data, level=19, checksum=False, window_log=0) -> bytes:
+    """libzstd's advanced API (ZSTD_compress2): a frame with a content checksum trailer and/or a given window log."""
+    import ctypes as C
+    z = C.CDLL("libzstd.so.1")
+    z.ZSTD_createCCtx.restype = C.c_void_p
+    z.ZSTD_freeCCtx.argtypes = [C.c_void_p]
+    z.ZSTD_CCtx_setParameter.restype = C.c_size_t
+    z.ZSTD_CCtx_setParameter.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    z.ZSTD_compressBound.restype = C.c_size_t
+    z.ZSTD_compressBound.argtypes = [C.c_size_t]
+    z.ZSTD_compress2.restype = C.c_size_t
+    z.ZSTD_compress2.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
+    z.ZSTD_isError.restype = C.c_uint
+    z.ZSTD_isError.argtypes = [C.c_size_t]
+    cctx = z.ZSTD_createCCtx()
+    try:
+        for prm, val in ((100, level), (201, 1 if checksum else 0)) + (((101, window_log),) if window_log else ()):
+            if z.ZSTD_isError(z.ZSTD_CCtx_setParameter(cctx, prm, val)):
+                raise RuntimeError(f"ZSTD_CCtx_setParameter({prm}, {val}) failed")
+        raw = bytes(data)
+        cap = z.ZSTD_compressBound(len(raw))
+        out = C.create_string_buffer(cap)
+        r = z.ZSTD_compress2(cctx, out, cap, raw, len(raw))
+        if z.ZSTD_isError(r):
+            raise RuntimeError("ZSTD_compress2 failed")
+        return out.raw[:r]
+    finally:
+        z.ZSTD_freeCCtx(cctx)
