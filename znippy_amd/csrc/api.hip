@@ -67,6 +67,7 @@ struct znippy_ctx {
     // kernel timing
     std::vector<KTime> ktimes;
     int n_ktimes = 0;
+    std::vector<hipEvent_t> event_pool;  // disable-timing events handed back by destroyed tables
     bool ktime_open = false;
     // page-locked host buffers handed back by destroyed tables: locking pages costs ~1 ms per 4 MB, more than a
     // whole C2 encode pass, so a table takes its result mirror from here when one is big enough
@@ -132,6 +133,22 @@ static void pinned_give(znippy_ctx *ctx, void *p, size_t cap) {
         ctx->pinned_pool.emplace_back(cap, p);
         ctx->pinned_pool_bytes += cap;
     } else (void)hipHostFree(p);
+}
+// Events of tables (two or four each) come from a per-context free list: creating one costs ~0.1 ms.
+static hipEvent_t event_take(znippy_ctx *ctx) {
+    if (!ctx->event_pool.empty()) {
+        hipEvent_t e = ctx->event_pool.back();
+        ctx->event_pool.pop_back();
+        return e;
+    }
+    hipEvent_t e = nullptr;
+    if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;
+    return e;
+}
+static void event_give(znippy_ctx *ctx, hipEvent_t e) {
+    if (!e) return;
+    if (ctx->event_pool.size() < 64) ctx->event_pool.push_back(e);
+    else (void)hipEventDestroy(e);
 }
 
 // Device memory of the tables (index columns, plans, per-run scratch) comes from a per-context pool: a table is
@@ -278,6 +295,7 @@ struct znippy_rows {
     // pinned mirror of the counters, filled by the run's own D2H copy.  Two slots + one event each: run k uses slot
     // k & 1, so the counters of run k can be read while run k + 1 is already executing (znippy_rows_results_lagged)
     uint64_t *h_counters = nullptr;
+    size_t h_counters_cap = 0;
     hipEvent_t ev_done[2] = {nullptr, nullptr};
     uint64_t run_seq = 0;  // async runs queued so far
     // Host copies of the columns a run is validated against (one pass per distinct (blob_base, blob_cap, out_cap)):
@@ -487,6 +505,7 @@ void znippy_ctx_destroy(znippy_ctx *ctx) {
     if (ctx->copy) { (void)hipStreamSynchronize(ctx->copy); (void)hipStreamDestroy(ctx->copy); }
     for (auto &e : ctx->pinned_pool) (void)hipHostFree(e.second);
     for (auto &e : ctx->dev_pool) (void)hipFree(e.second);
+    for (hipEvent_t e : ctx->event_pool) (void)hipEventDestroy(e);
     if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
     if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
@@ -601,9 +620,11 @@ void znippy_rows_destroy(znippy_rows *r) {
                     r->bt_tile, r->bt_item, r->tile_done, r->item_done, r->todo, r->status_init, r->slow_list};
     for (void *p : ptrs)
         tfree(r->ctx, p);
-    if (r->h_counters) (void)hipHostFree(r->h_counters);
-    for (hipEvent_t e : r->ev_done)
-        if (e) (void)hipEventDestroy(e);
+    if (r->h_counters) {
+        (void)hipStreamSynchronize(r->ctx->stream);  // a queued run may still copy into the slot
+        pinned_give(r->ctx, r->h_counters, r->h_counters_cap);
+    }
+    for (hipEvent_t e : r->ev_done) event_give(r->ctx, e);
     free_plan(r->ctx, r->plan);
     delete r;
 }
@@ -653,9 +674,8 @@ int znippy_rows_create(znippy_ctx *ctx, const uint64_t *blob_offset, const uint6
     r->ctl_bytes = znippy_rows::CTL_HEAD + std::max<size_t>(4 * (size_t)n, 16);
     if (tmalloc(ctx, &r->ctl, r->ctl_bytes) != hipSuccess ||
         tmalloc(ctx, &r->digests, std::max<size_t>(32 * (size_t)n, 32)) != hipSuccess ||
-        hipHostMalloc(&r->h_counters, 128) != hipSuccess ||
-        hipEventCreateWithFlags(&r->ev_done[0], hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&r->ev_done[1], hipEventDisableTiming) != hipSuccess ||
+        !(r->h_counters = (uint64_t *)pinned_take(ctx, 128, &r->h_counters_cap)) ||
+        !(r->ev_done[0] = event_take(ctx)) || !(r->ev_done[1] = event_take(ctx)) ||
         tmalloc(ctx, &r->corrupt, 8 * (size_t)r->corrupt_cap) != hipSuccess) {
         znippy_rows_destroy(r);
         return ZNIPPY_E_NOMEM;
@@ -1118,8 +1138,8 @@ void znippy_rounds_destroy(znippy_rounds *r) {
     if (r->ctx->copy) (void)hipStreamSynchronize(r->ctx->copy);  // a result copy may still be reading a slab
     for (int k = 0; k < 2; k++) {
         pinned_give(r->ctx, r->h_res_m[k], r->h_res_cap_m[k]);
-        if (r->ev_enc[k]) (void)hipEventDestroy(r->ev_enc[k]);
-        if (r->ev_res[k]) (void)hipEventDestroy(r->ev_res[k]);
+        event_give(r->ctx, r->ev_enc[k]);
+        event_give(r->ctx, r->ev_res[k]);
     }
     void *ptrs[] = {r->src_off, r->len, r->skip, r->res_m[0], r->res_m[1], r->items, r->piece_len, r->piece_len_init,
                     r->piece_start, r->local_excl, r->block_tot, r->first_item, r->stored, r->order_small, r->order_wide, r->retry_list, r->retry_count};
@@ -1159,8 +1179,7 @@ int znippy_rounds_create(znippy_ctx *ctx, const uint64_t *src_offset, const uint
     for (int k = 0; k < 2; k++)
         if (tmalloc(ctx, &r->res_m[k], r->res_bytes) != hipSuccess ||
             !(r->h_res_m[k] = (uint8_t *)pinned_take(ctx, r->res_bytes, &r->h_res_cap_m[k])) ||
-            hipEventCreateWithFlags(&r->ev_enc[k], hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&r->ev_res[k], hipEventDisableTiming) != hipSuccess) {
+            !(r->ev_enc[k] = event_take(ctx)) || !(r->ev_res[k] = event_take(ctx))) {
             znippy_rounds_destroy(r);
             return ZNIPPY_E_NOMEM;
         }
