@@ -1380,10 +1380,12 @@ extern "C" int znippy_encode_hash_rounds_async(znippy_ctx *ctx, znippy_rounds *r
     const unsigned slot = (unsigned)(r->run_seq & 1);
     rounds_select(r, slot);
     if (r->run_seq >= 2) HIPCHK(ctx, hipStreamWaitEvent(s, r->ev_res[slot], 0));  // the slab's previous results have left
-    HIPCHK(ctx, hipEventRecord(ctx->ev_fork, s));
     HIPCHK(ctx, hipMemsetAsync(r->res, 0, 16 + 16 * (size_t)r->n, s));  // total, overflow, blob_offset, blob_size
-    HIPCHK(ctx, hipMemsetAsync(ctx->cursor, 0, 64, s));
-    HIPCHK(ctx, hipMemsetAsync(r->retry_count, 0, 4, s));
+    HIPCHK(ctx, hipMemsetAsync(ctx->cursor, 0, 64, s));  // work cursors + (last word) the count of blocks handed to the wide variant
+    // The fork comes AFTER the clears.  The hash kernel on the auxiliary stream starts at the fork and fills the chip; a
+    // clear issued behind it is one tiny fill kernel that then waits ~100 us for its turn (kernel trace of the C2 write
+    // step: two of them, 88 + 125 us, between the previous run's gather and this run's encoder).
+    HIPCHK(ctx, hipEventRecord(ctx->ev_fork, s));
     EncodeArgs a{};
     a.items = r->items;
     a.src = (const uint8_t *)d_src; a.src_off = r->src_off; a.len = r->len;
@@ -1408,11 +1410,11 @@ extern "C" int znippy_encode_hash_rounds_async(znippy_ctx *ctx, znippy_rounds *r
         a.cursor = ctx->cursor + (wide ? 8 : 0);
         const int g = wide ? ctx->encode_grid : ctx->encode_grid_small;
         a.batch = std::max<uint32_t>(1, std::min<uint32_t>(16, a.n_items / (uint32_t)(g * 2)));
-        if (!wide) { a.retry_list = r->retry_list; a.retry_count = r->retry_count; }
+        if (!wide) { a.retry_list = r->retry_list; a.retry_count = ctx->cursor + 15; }
         launch_encode(a, std::min<int>(g, (int)a.n_items), !wide, s);
     }
     if (r->n_small) {  // second wide launch: whatever the small variant handed over (count on the device)
-        a.order = r->retry_list; a.n_items = r->n_small; a.n_items_dev = r->retry_count;
+        a.order = r->retry_list; a.n_items = r->n_small; a.n_items_dev = ctx->cursor + 15;
         a.retry_list = nullptr; a.retry_count = nullptr;
         a.cursor = ctx->cursor + 12;
         a.batch = 1;
