@@ -135,3 +135,37 @@ def test_roles_kernel_respects_host_verdicts_and_out_cap(gpu_ctx_roles, oracle):
         else:
             assert (row == 0xCD).all()
     assert (host[total:] == 0xCD).all()
+
+
+def test_mixed_row_shapes_decode_the_same_every_time(gpu_ctx_roles, oracle):
+    """Rows of several whole-leaf sizes in random order (6 x 10-leaf tiles between tiles of other shapes: the parent trees
+    in the idle lanes, the group fold, the left-over list and the wave-exit flush all in one table), five runs: every
+    digest equals the oracle's, every run equals the first."""
+    import torch
+    from znippy_amd import hip
+    rng = np.random.default_rng(77)
+    sizes = [10240, 10240, 10240, 20480, 4096, 8192, 10240, 1024, 30720]
+    chunks = {s: gen.text(s) for s in set(sizes)}
+    frames = {s: gpu_ctx_roles.compress(chunks[s]) for s in set(sizes)}
+    want = {s: np.frombuffer(oracle.blake3(chunks[s]), dtype=np.uint8) for s in set(sizes)}
+    # runs of equal rows (so that whole tiles of one shape occur) separated by random single rows
+    order = []
+    while len(order) < 20000:
+        s = sizes[int(rng.integers(0, len(sizes)))]
+        order += [s] * int(rng.integers(1, 40))
+    order = order[:20000]
+    us = np.array(order, np.uint64)
+    bs = np.array([len(frames[s]) for s in order], np.uint64)
+    bo = np.concatenate([[0], np.cumsum(bs)[:-1]]).astype(np.uint64)
+    oo = np.concatenate([[0], np.cumsum(us)[:-1]]).astype(np.uint64)
+    ck = np.stack([want[s] for s in order])
+    d_blobs = torch.from_numpy(np.frombuffer(b"".join(frames[s] for s in order) + bytes(64), dtype=np.uint8).copy()).cuda()
+    d_out = torch.zeros(int(us.sum()) + 64, dtype=torch.uint8, device="cuda")
+    rt = hip.RowTable(gpu_ctx_roles, bo, bs, us, oo, None, ck)
+    ref = torch.from_numpy(np.frombuffer(b"".join(chunks[s] for s in order), dtype=np.uint8).copy()).cuda()
+    for rep in range(5):
+        d_out.zero_()
+        c, corrupt, status = rt.decode_verify(d_blobs, d_out)
+        assert c["corrupt_rows"] == 0 and c["decode_errors"] == 0 and c["verified_bytes"] == int(us.sum()), (rep, c, corrupt[:8])
+        assert (rt.digests() == ck).all(), rep
+        assert torch.equal(d_out[:int(us.sum())], ref), rep
