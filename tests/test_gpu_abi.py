@@ -217,3 +217,36 @@ def test_tables_outliving_their_context_are_closed_with_it():
     del rt, rd
     gc.collect()
     ctx.close()  # idempotent
+
+
+@pytest.mark.parametrize("tiles", [
+    ("......", "......", "......", "v.v..."), ("v.v...", "......", "......", "......"), ("vv....", "vvvvvv", "v.....", "vv.v.v"),
+    ("......", "..v..v", "......", "......"), ("v.v.v.", "v.v.v.", "v.v.v.", "v.v.v."), ("vvvvvv", "......", ".v.v.v", "......")])
+def test_valid_rows_between_undecodable_ones_keep_their_digests(gpu_ctx, oracle, tiles):
+    """Tiles of six 10 KiB rows in which valid ('v') and undecodable ('.') rows alternate: the parent fold works on a
+    table of the workgroup's HASHED units, compacted per tile; a unit that is not hashed between two that are pushed an
+    inactive entry into the compacted table and the last hashed unit out of it — and when that entry was the table's
+    last, the table still looked well-formed: the left-out row's digest was never written and a valid row came back
+    corrupt.  Four tiles = one workgroup of the small-row kernel."""
+    import torch
+    from znippy_amd import hip
+    data = gen.text(10240)
+    good = gpu_ctx.compress(data)
+    bad = bytearray(good); bad[0] ^= 0xFF                       # magic number: every decoder refuses it
+    pattern = "".join(tiles)
+    rows = [(good if ch == "v" else bytes(bad)) for ch in pattern]
+    n = len(rows)
+    bs = np.array([len(f) for f in rows], np.uint64)
+    bo = np.concatenate([[0], np.cumsum(bs)[:-1]]).astype(np.uint64)
+    us = np.full(n, len(data), np.uint64)
+    oo = np.arange(n, dtype=np.uint64) * len(data)
+    ck = np.tile(np.frombuffer(oracle.blake3(data), dtype=np.uint8), (n, 1))
+    d_blobs = torch.from_numpy(np.frombuffer(b"".join(rows) + bytes(64), dtype=np.uint8).copy()).cuda()
+    d_out = torch.zeros(n * len(data) + 64, dtype=torch.uint8, device="cuda")
+    rt = hip.RowTable(gpu_ctx, bo, bs, us, oo, None, ck)
+    c, corrupt, status = rt.decode_verify(d_blobs, d_out)
+    valid = np.array([ch == "v" for ch in pattern])
+    assert (status[valid] == 0).all() and (status[~valid] < 0).all(), status
+    assert c["corrupt_rows"] == 0, [int(x) for x in corrupt]
+    assert c["decode_errors"] == int((~valid).sum()) and c["verified_bytes"] == int(valid.sum()) * len(data)
+    assert (rt.digests()[valid] == ck[valid]).all()

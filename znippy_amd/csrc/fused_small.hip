@@ -1057,11 +1057,7 @@ __global__ __launch_bounds__(256, 5) void k_fused_small(FusedArgs a) {
             if (__ballot(fq.tb_n != 0) != 0ull) {
                 FoldQueue<4> fd = fq.dense16();
                 uint32_t U = 0;
-                // (list mode = the tiles k_fused_roles left over, workgroups loop: the generic fold.  With the uniform one
-                // here, 3 runs in 10 of the exhaustive single-bit-mutant table (tests/test_gpu_fuzz.py) came back with ONE
-                // wrong digest — a valid row among invalid ones, bytes right; never in plan mode, never with the generic
-                // fold, never in the role kernel's own group fold.  Cause not found; the left-over path is not the fast path.)
-                const uint32_t n = ((a.dbg & 262144) || a.tile_list) ? 0u : fd.uniform(&U);
+                const uint32_t n = (a.dbg & 262144) ? 0u : fd.uniform(&U);
                 if (n) fd.fold_uniform_and_write(s_nodes, a.h, n, U);  // every row of the four tiles has the same length
                 else fq.fold_and_write(s_nodes, a.h);
             }

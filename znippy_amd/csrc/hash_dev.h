@@ -729,7 +729,12 @@ struct FoldQueue {
         const uint64_t has = __ballot(lane < n_tab && tb_n != 0), same = __ballot(lane < n_tab && tb_n == n0);
         const uint32_t U = (uint32_t)__popcll(has);
         *units = U;
-        if (n0 < 2 || has != same || U == 0 || has != (U == 64 ? ~0ull : ((1ull << U) - 1))) return 0;
+        // U != n_tab: dense16() took the first c entries of a 16-entry group where the group's c active ones were not its
+        // first c (a unit that is not hashed between two that are) — one of the table's entries is then an inactive unit
+        // and an ACTIVE one was left out.  When that entry happened to be the table's last, the remaining test (the
+        // non-zero entries are lanes [0, U)) passed and the left-out unit's digest was never written: a valid row among
+        // invalid ones reported corrupt, in whichever runs the left-over list happened to group the tiles that way.
+        if (n0 < 2 || has != same || U == 0 || U != n_tab || has != (U == 64 ? ~0ull : ((1ull << U) - 1))) return 0;
         return n0;
     }
     __device__ __forceinline__ void fold_uniform_and_write(uint32_t *nodes, const HashArgs &a, uint32_t n, uint32_t U) {
