@@ -368,3 +368,53 @@ def test_stored_big_rows_every_output_alignment(gpu_ctx, oracle):
     for o, d in zip(out_off, rows):
         want[o:o + len(d)] = np.frombuffer(d, dtype=np.uint8)
     assert np.array_equal(out, want)
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_random_archives_every_path_every_time(gpu_ctx, gpu_ctx_roles, oracle, seed):
+    """Randomised archives — whole-leaf and ragged rows, text / binary / word-soup / incompressible / empty, stored and
+    compressed, runs of equal rows and single ones, a few big rows, ~1 in 40 rows damaged — through the default context and
+    through one that sends every table to the role-split kernel first, three runs each: counters, verdicts, bytes and
+    digests equal the oracle's read loop every time."""
+    rng = np.random.default_rng(1000 + seed)
+    entries, skip = [], []
+    while len(entries) < 2500:
+        kind = int(rng.integers(0, 8))
+        run = int(rng.integers(1, 30)) if rng.random() < 0.5 else 1
+        n = int(rng.choice([0, 1, 1023, 1024, 1025, 4096, 10240, 10240, 10240, 20480, 30720, 65536, int(rng.integers(2, 50000))]))
+        if kind <= 1: e = gen.text(n)
+        elif kind == 2: e = gen.binary(n)
+        elif kind == 3: e = gen.pseudo_text(min(n, 20000), seed=len(entries))
+        elif kind == 4: e = gen.incompressible(len(entries), min(n, 30000))
+        elif kind == 5: e = bytes(n)
+        else: e = gen.text(n)
+        for _ in range(run):
+            entries.append(e)
+            skip.append(1 if kind == 4 and len(entries) % 3 == 0 else 0)
+    for big, sk in ((gen.text(700_000), 0), (gen.incompressible(9, 400_000), 1), (gen.pseudo_text(300_000, seed=5), 0)):
+        at = int(rng.integers(0, len(entries)))
+        entries.insert(at, big); skip.insert(at, sk)
+    arch = _build_archive(oracle, entries, level=3, skip=skip)
+    n = len(entries)
+    blobs = arch["blobs"].copy()
+    for i in rng.choice(n, size=n // 40, replace=False):       # damage: one byte somewhere in the row's blob
+        if arch["blob_size"][i] > 0:
+            at = int(arch["blob_offset"][i]) + int(rng.integers(0, int(arch["blob_size"][i])))
+            blobs[at] ^= 1 << int(rng.integers(0, 8))
+    arch["blobs"] = blobs
+    bitmap = np.packbits(arch["compressed"].astype(bool), bitorder="little")
+    want_out = np.zeros(int(arch["usize"].sum()), dtype=np.uint8)
+    want, want_corrupt = oracle.decompress_rows(arch["blobs"], arch["blob_offset"], arch["blob_size"], arch["usize"],
+                                                arch["out_off"], bitmap, arch["checksum"], 0, n, out=want_out)
+    for ctx in (gpu_ctx, gpu_ctx_roles):
+        for rep in range(3):
+            counters, corrupt, status, out, rt = _run_gpu(ctx, arch, pad_blobs=3)
+            assert counters == want, (rep, counters, want)
+            assert sorted(int(x) for x in corrupt) == sorted(int(x) for x in want_corrupt), rep
+            okrows = status >= 0
+            assert int((~okrows).sum()) == want["decode_errors"]
+            for i in np.nonzero(okrows)[0][:: max(1, n // 400)]:    # bytes of a sample of the decoded rows (all digests below)
+                a, b = int(arch["out_off"][i]), int(arch["out_off"][i] + arch["usize"][i])
+                assert np.array_equal(out[a:b], want_out[a:b]), (rep, int(i))
+            good = okrows.copy(); good[[int(x) for x in want_corrupt]] = False
+            assert np.array_equal(rt.digests()[good], arch["checksum"][good]), rep
