@@ -245,3 +245,55 @@ def test_store_path_tables_blob_is_the_input(gpu_ctx, oracle, sizes):
         assert np.array_equal(d_blob.cpu().numpy()[:len(src)], src)
         for i, d in enumerate(data):
             assert bytes(enc["checksum"][i]) == oracle.blake3(d)
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_random_round_tables_encode_decode_and_repeat(gpu_ctx, oracle, seed):
+    """Randomised Round tables (every kind of content, block-boundary sizes, runs of equal rounds, some on the store path):
+    every frame decodes with libzstd to its input, every digest is the oracle's, a second run writes the same blob region,
+    and this library's read side gets every byte back."""
+    import torch
+    from znippy_amd import hip
+    rng = np.random.default_rng(seed)
+    entries, skip = [], []
+    while len(entries) < 500:
+        kind = int(rng.integers(0, 7))
+        run = int(rng.integers(1, 12)) if rng.random() < 0.4 else 1
+        n = int(rng.choice([0, 1, 63, 1024, 4096, 10240, 10240, 16384, 16385, 20480, 131072, 131073, int(rng.integers(2, 300000))]))
+        if kind <= 1: e = gen.text(n)
+        elif kind == 2: e = gen.binary(n)
+        elif kind == 3: e = gen.pseudo_text(min(n, 60000), seed=len(entries) + seed * 1000)
+        elif kind == 4: e = gen.incompressible(len(entries) + seed, min(n, 200000))
+        elif kind == 5: e = bytes(n)
+        else: e = (gen.pseudo_text(min(n, 30000) // 2 + 1, seed=seed) + gen.incompressible(seed, min(n, 30000) // 2))[:n]
+        for _ in range(run):
+            entries.append(e); skip.append(1 if kind == 4 and len(entries) % 4 == 0 else 0)
+    lens = np.array([len(e) for e in entries], np.uint64)
+    offs = np.concatenate([[0], np.cumsum(lens)[:-1]]).astype(np.uint64)
+    total = int(lens.sum())
+    d_src = torch.from_numpy(np.frombuffer(b"".join(entries) + bytes(64), np.uint8).copy()).cuda()
+    rt = hip.RoundTable(gpu_ctx, offs, lens, np.array(skip, np.uint8))
+    d_blob = torch.zeros(rt.blob_bound() + 64, dtype=torch.uint8, device="cuda")
+    first = None
+    for rep in range(2):
+        d_blob.zero_()
+        enc = rt.encode_hash(d_src, d_blob)
+        hb = d_blob.cpu().numpy()
+        got = (enc["blob_offset"].copy(), enc["blob_size"].copy(), enc["checksum"].copy(), hb[:int(enc["blob_bytes"])].copy())
+        if first is None:
+            first = got
+            for i, e in enumerate(entries):
+                f = hb[int(enc["blob_offset"][i]):int(enc["blob_offset"][i] + enc["blob_size"][i])].tobytes()
+                assert enc["checksum"][i].tobytes() == oracle.blake3(e), i
+                if enc["compressed"][i]:
+                    assert oracle.libzstd_decompress(f, max(len(e), 1)) == e, (i, len(e))
+                else:
+                    assert f == e, i
+        else:
+            assert all((a == b).all() for a, b in zip(got, first)), "the second run wrote something else"
+    rows = hip.RowTable(gpu_ctx, enc["blob_offset"], enc["blob_size"], lens, offs,
+                        np.packbits(enc["compressed"].astype(bool), bitorder="little"), enc["checksum"])
+    d_out = torch.zeros(total + 64, dtype=torch.uint8, device="cuda")
+    c, corrupt, st = rows.decode_verify(d_blob, d_out)
+    assert c["corrupt_rows"] == 0 and c["decode_errors"] == 0 and c["verified_bytes"] == total
+    assert torch.equal(d_out[:total], d_src[:total])
