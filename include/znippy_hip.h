@@ -48,6 +48,13 @@ typedef struct znippy_rounds znippy_rounds; /* write side: a batch of Rounds, de
  * `hip_stream` may be NULL (the context then owns a non-blocking stream). */
 int znippy_ctx_create(int device, void *hip_stream, znippy_ctx **out);
 void znippy_ctx_destroy(znippy_ctx *ctx);
+/* CompressCtx::new(compression_level) (znippy-common/src/codec.rs:L16-28): the effort of every later encode call of
+ * this context.  1..22; a new context starts at 19 (CONFIG.compression_level, common_config.rs:L37).  Two tiers:
+ * levels 1-3 use the fast block matcher (one probe per position, raw literals beyond 128 symbols, predefined
+ * sequence tables), levels 4-22 the higher effort one (4-way buckets, lazy choice, in-block repeat offsets,
+ * per-block entropy tables).  Frames of both tiers are plain RFC 8878.  znippy_ctx_level returns the level. */
+int znippy_ctx_set_level(znippy_ctx *ctx, int level);
+int znippy_ctx_level(const znippy_ctx *ctx);
 const char *znippy_last_error(const znippy_ctx *ctx);
 /* Block until everything queued on the context's stream has finished. */
 int znippy_ctx_sync(znippy_ctx *ctx);

@@ -21,6 +21,20 @@ CASES = [("text", 10240), ("binary", 10240), ("random_lcg", 10240), ("pseudo_tex
          ("text", 131073), ("zeros", 131072 * 2)]
 
 
+@pytest.fixture(scope="module", params=[1, 19], ids=["level1", "level19"])
+def gpu_ctx(request):
+    """Every test of this file runs on both effort tiers of the encoder (znippy_ctx_set_level: 1-3 fast, 4-22 high)."""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from znippy_amd import hip
+    ctx = hip.Context(0)
+    ctx.set_level(request.param)
+    assert ctx.level == request.param
+    yield ctx
+    ctx.close()
+
+
 def _gen(name, n):
     return bytes(n) if name == "zeros" else getattr(gen, name)(n)
 

@@ -43,7 +43,7 @@ EXPORTS = [
     "znippy_decode_verify_rows_async", "znippy_rows_results", "znippy_rows_digests",
     "znippy_rounds_create", "znippy_rounds_destroy", "znippy_rounds_blob_bound",
     "znippy_encode_hash_rounds", "znippy_encode_hash_rounds_async", "znippy_rounds_results",
-    "znippy_rounds_results_view", "znippy_rows_results_lagged", "znippy_rows_set_blob_cap", "znippy_rounds_results_lagged", "znippy_rounds_set_store_incompressible", "znippy_hash_rounds", "znippy_last_kernel_times", "znippy_measure_blake3_pass_ns", "znippy_last_shader_ghz", "znippy_ctx_set_kernel_timing", "znippy_rows_foreign_stats",
+    "znippy_rounds_results_view", "znippy_rows_results_lagged", "znippy_rows_set_blob_cap", "znippy_rounds_results_lagged", "znippy_rounds_set_store_incompressible", "znippy_hash_rounds", "znippy_last_kernel_times", "znippy_measure_blake3_pass_ns", "znippy_last_shader_ghz", "znippy_ctx_set_kernel_timing", "znippy_rows_foreign_stats", "znippy_ctx_set_level", "znippy_ctx_level",
 ]
 
 
@@ -106,6 +106,8 @@ def lib():
     L.znippy_measure_blake3_pass_ns.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]
     L.znippy_last_shader_ghz.argtypes = [vp, C.POINTER(C.c_float)]
     L.znippy_ctx_set_kernel_timing.argtypes = [vp, C.c_int]
+    L.znippy_ctx_set_level.argtypes = [vp, C.c_int]
+    L.znippy_ctx_level.argtypes = [vp]
     L.znippy_rows_foreign_stats.argtypes = [vp, vp, C.POINTER(C.c_uint64)]
     _lib = L
     return L

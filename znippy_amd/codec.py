@@ -6,8 +6,8 @@ Same names, argument meaning and error behaviour as the reference:
   .compress_into(input, out)    codec.rs:L43-55   out: bytearray, resized to the bytes written
   decompress_frame(frame)       codec.rs:L58-62
   decompress_into(frame, out)   codec.rs:L67-78
-Errors raise ZnippyError (the reference returns anyhow::Error).  The compression level is
-recorded but the GPU encoder has a single effort setting.
+Errors raise ZnippyError (the reference returns anyhow::Error).  The compression level selects the
+encoder's effort tier (znippy_ctx_set_level: 1-3 fast, 4-22 higher effort).
 """
 from . import hip
 from ._lib import ZnippyError  # noqa: F401
@@ -28,10 +28,18 @@ class CompressCtx:
         self.level = compression_level
         self.ctx = ctx or default_context()
 
+    def _apply_level(self):
+        if not 1 <= int(self.level) <= 22:
+            raise ZnippyError(-1, f"compression level {self.level} outside 1..22")
+        if self.ctx.level != self.level:  # the HIP context may be shared between CompressCtx objects
+            self.ctx.set_level(self.level)
+
     def compress(self, data) -> bytes:
+        self._apply_level()
         return self.ctx.compress(bytes(data))
 
     def compress_into(self, data, out: bytearray) -> int:
+        self._apply_level()
         b = self.ctx.compress(bytes(data))
         out[:] = b
         return len(b)

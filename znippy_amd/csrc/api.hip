@@ -50,6 +50,7 @@ struct znippy_ctx {
     size_t shim_in_cap = 0, shim_out_cap = 0;
     // encoder scratch (grow-only) + tables
     int encode_grid = 0, encode_grid_small = 0;
+    int level = 19;  // CompressCtx::new(compression_level), codec.rs:L16-28; CONFIG.compression_level is 19 (common_config.rs:L37)
     uint8_t *enc_prov = nullptr;
     size_t enc_prov_cap = 0;
     uint32_t *enc_seq = nullptr;
@@ -104,6 +105,7 @@ static void read_switches(znippy_ctx *ctx) {
     ctx->sw.nohash = on("ZNIPPY_NOHASH");
     ctx->sw.no_roles = on("ZNIPPY_NO_ROLES");
     ctx->sw.no_fz = on("ZNIPPY_NO_FZ");
+    if (const char *lv = getenv("ZNIPPY_LEVEL")) { const int v = atoi(lv); if (v >= 1 && v <= 22) ctx->level = v; }  // initial level of every context (tests, A/B runs)
     ctx->sw.fz_only = on("ZNIPPY_FZ_ONLY");  // test hook: no serial fallback behind the two-phase path (what it leaves shows up as corrupt rows)
     if (const char *e = getenv("ZNIPPY_ROLES_MIN")) ctx->sw.roles_min = (unsigned)atoi(e);
     if (const char *e = getenv("ZNIPPY_KTIME")) ctx->sw.ktime = atoi(e);
@@ -539,6 +541,14 @@ int znippy_rows_foreign_stats(znippy_ctx *ctx, znippy_rows *r, uint64_t stats[8]
     HIPCHK(ctx, hipMemcpy(stats, r->ctl + 192, 64, hipMemcpyDeviceToHost));
     return ZNIPPY_OK;
 }
+
+int znippy_ctx_set_level(znippy_ctx *ctx, int level) {
+    if (!ctx || level < 1 || level > 22) return ZNIPPY_E_INVAL;
+    ctx->level = level;
+    return ZNIPPY_OK;
+}
+
+int znippy_ctx_level(const znippy_ctx *ctx) { return ctx ? ctx->level : ZNIPPY_E_INVAL; }
 
 int znippy_ctx_set_kernel_timing(znippy_ctx *ctx, int level) {
     if (!ctx || level < 0 || level > 2) return ZNIPPY_E_INVAL;
@@ -1411,14 +1421,14 @@ extern "C" int znippy_encode_hash_rounds_async(znippy_ctx *ctx, znippy_rounds *r
         const int g = wide ? ctx->encode_grid : ctx->encode_grid_small;
         a.batch = std::max<uint32_t>(1, std::min<uint32_t>(16, a.n_items / (uint32_t)(g * 2)));
         if (!wide) { a.retry_list = r->retry_list; a.retry_count = ctx->cursor + 15; }
-        launch_encode(a, std::min<int>(g, (int)a.n_items), !wide, s);
+        launch_encode(a, std::min<int>(g, (int)a.n_items), !wide, ctx->level >= HIGH_TIER_LEVEL, s);
     }
     if (r->n_small) {  // second wide launch: whatever the small variant handed over (count on the device)
         a.order = r->retry_list; a.n_items = r->n_small; a.n_items_dev = ctx->cursor + 15;
         a.retry_list = nullptr; a.retry_count = nullptr;
         a.cursor = ctx->cursor + 12;
         a.batch = 1;
-        launch_encode(a, std::min<int>(ctx->encode_grid, (int)r->n_small), false, s);
+        launch_encode(a, std::min<int>(ctx->encode_grid, (int)r->n_small), false, ctx->level >= HIGH_TIER_LEVEL, s);
     }
     ktime_end(ctx);
     // checksum over the ORIGINAL bytes (stream_packer.rs:L219): VALU-bound, submitted to the

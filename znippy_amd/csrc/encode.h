@@ -72,7 +72,8 @@ struct GatherArgs {
     int skip_stored_copy;   // store-heavy tables: the hash kernel copies the stored rounds while it hashes them
 };
 
-void launch_encode(const EncodeArgs &a, int grid, bool small_blocks, hipStream_t s);
+void launch_encode(const EncodeArgs &a, int grid, bool small_blocks, bool high, hipStream_t s);
+constexpr int HIGH_TIER_LEVEL = 4;  // compression levels from here up use the higher effort tier of the wide encoder
 void launch_piece_scan(const uint32_t *piece_len, uint32_t n, uint64_t *local_excl, uint64_t *block_tot, hipStream_t s);
 void launch_gather(const GatherArgs &g, hipStream_t s);
 void launch_store_decide(const uint32_t *first_item, const EncItem *items, const uint64_t *len, const uint8_t *skip,

@@ -858,7 +858,7 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES == 4 ? 4 : 1) void k_zstd_decod
             S.out_pos = o0; S.win_n = 0; S.hist_n = 0;
             S.blk_base = o0;
             S.huf_valid = 0; S.valid[0] = S.valid[1] = S.valid[2] = 0;
-            S.rep[0] = 1; S.rep[1] = 4; S.rep[2] = 8;
+            S.rep[0] = 0; S.rep[1] = 0; S.rep[2] = 0;  // the history the block before leaves is not known here: 0 = undefined
             S.has_cksum = 0;
             S.content_size = fcs;
             S.src_pos = item_src;
@@ -1151,7 +1151,6 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES == 4 ? 4 : 1) void k_zstd_decod
                     uint32_t lits = 0;
                     const uint32_t lit_room = lit_room_in;
                     const uint64_t abs0 = abs0_in;  // bytes a match may reach back over
-                    const bool no_rep = a.block_mode != 0;  // a repeat offset would depend on the block before
                     const uint64_t out_end = uni64(S.out_end);
                     const uint2 *const tl2 = reinterpret_cast<const uint2 *>(tl), *const to2 = reinterpret_cast<const uint2 *>(to),
                                 *const tm2 = reinterpret_cast<const uint2 *>(tm);
@@ -1197,16 +1196,18 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES == 4 ? 4 : 1) void k_zstd_decod
                         const uint32_t ov = on ? S.seq_off[buf][g0 + lane] : 4;
                         uint32_t offset = ov - 3;
                         if (__ballot(on && ov <= 3) != 0ull || cnt < 3) {
-                            if (no_rep && __ballot(on && ov <= 3) != 0ull) { err = E_CORRUPT; break; }
+                            // A block item starts with an undefined history (all 0): a repeat code is good once the block's
+                            // own sequences have defined the entry it names (this build's higher effort tier writes such
+                            // blocks); one that reaches an undefined entry depends on the block before — the serial pass decides.
                             for (uint32_t j = 0; j < cnt; j++) {  // in order, on the scalar unit
                                 const uint32_t ovj = rdlane_u(ov, j), llj = rdlane_u(ll, j);
                                 uint32_t o;
                                 if (ovj > 3) { o = ovj - 3; r2 = r1; r1 = r0; r0 = o; }
                                 else {
                                     const uint32_t idx = ovj - 1 + (llj == 0 ? 1 : 0);
-                                    if (idx == 0) o = r0;
+                                    if (idx == 0) { o = r0; if (o == 0) { err = E_CORRUPT; break; } }
                                     else {
-                                        o = idx == 1 ? r1 : (idx == 2 ? r2 : r0 - 1);
+                                        o = idx == 1 ? r1 : (idx == 2 ? r2 : (r0 ? r0 - 1 : 0));
                                         if (o == 0) { err = E_CORRUPT; break; }
                                         if (idx > 1) r2 = r1;
                                         r1 = r0; r0 = o;

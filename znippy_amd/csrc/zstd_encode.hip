@@ -142,8 +142,10 @@ __device__ __forceinline__ uint32_t rdlane(uint32_t v, uint32_t l) { return (uin
 //   * each lane then assembles its sequence's <= 75 bits, an exclusive scan places them, and the lanes OR
 //     them into a small LDS window that is streamed out one dword per lane.
 // seqs[3*i..] = {ll, ml-3, offset}; returns the end of the bitstream (after the closing 1 bit).
+// ov_bias: what turns seqs[3*i+2] into the coded offset value (3 when the entry is a plain offset, 0 when the
+// matcher already stored the offset value with its repeat codes).
 template <class SH>
-__device__ __noinline__ uint8_t *encode_sequences(SH &S, const uint32_t *seqs, uint32_t nseq, uint8_t *p, uint32_t lane) {
+__device__ __noinline__ uint8_t *encode_sequences(SH &S, const uint32_t *seqs, uint32_t nseq, uint8_t *p, uint32_t lane, uint32_t ov_bias) {
     // bit window: 64 sequences x <= 75 bits + carry; lives in the hash table, which is dead once the block's matches are found
     uint32_t *const ebits = reinterpret_cast<uint32_t *>(S.table);
     const uint32_t st_ll = S.tabs.ll_state[lane & 63], st_ml = S.tabs.ml_state[lane & 63], st_of = S.tabs.of_state[lane & 31];
@@ -154,7 +156,7 @@ __device__ __noinline__ uint8_t *encode_sequences(SH &S, const uint32_t *seqs, u
         const uint32_t cnt = nseq - e0 < 64 ? nseq - e0 : 64;
         const bool on = lane < cnt;
         const uint32_t i = nseq - 1 - (e0 + (on ? lane : 0));  // encoding order: last sequence first
-        const uint32_t ll = seqs[3 * i], mlb = seqs[3 * i + 1], ov = seqs[3 * i + 2] + 3;
+        const uint32_t ll = seqs[3 * i], mlb = seqs[3 * i + 1], ov = seqs[3 * i + 2] + ov_bias;
         const uint32_t lc = ll < 64 ? c_ll_code[ll] : (uint32_t)hib(ll) + 19;
         const uint32_t mc = mlb < 128 ? c_ml_code[mlb] : (uint32_t)hib(mlb) + 36;
         const uint32_t oc = (uint32_t)hib(ov);
@@ -450,7 +452,9 @@ __device__ __forceinline__ uint32_t huf_literals(SH &S, const uint8_t *lits, uin
 
 // One wave encodes one block item pulled from the atomic cursor.  HASH_LOG 11 (4 KiB table, more
 // resident waves) serves batches of small rounds, 13 serves 128 KiB blocks.
-template <uint32_t HASH_LOG>
+// HIGH (with HASH_LOG 13 only) is the higher effort tier (levels >= HIGH_TIER_LEVEL): 4-way buckets, one-step lazy
+// choice, a cost gate on short far matches, in-block repeat offsets.
+template <uint32_t HASH_LOG, bool HIGH = false>
 __global__ __launch_bounds__(64) void k_zstd_encode(EncodeArgs a) {
     constexpr uint32_t HASH_SIZE = 1u << HASH_LOG;
     __shared__ __attribute__((aligned(16))) EncShared<HASH_LOG> S;
@@ -539,7 +543,172 @@ __global__ __launch_bounds__(64) void k_zstd_encode(EncodeArgs a) {
         uint32_t base = 0, misses = 0;
         bool gave_up = false;  // wide variant: incompressible block recognised early
         const uint32_t scan_end = nq >= 8 ? nq - 7 : 0;  // positions with >= 8 bytes ahead
-        if constexpr (HASH_LOG == 13) {
+        if constexpr (HIGH) {
+            // Higher effort tier of the wide variant.  Same shape (every lane probes its position and extends its own
+            // candidates, the window's matches are then picked left to right), with what tools/enc_model.c showed to pay:
+            //   * 2^11 buckets x 4 ways in the same 16 KiB (one 8-byte LDS word per bucket, newest first): associativity
+            //     beats table size on text and binaries alike;
+            //   * a candidate at the repeat offset of the window's start, preferred when it is within a byte of the best;
+            //   * a gate on short far matches (4 bytes beyond 2 KiB, 5 beyond 32 KiB cost more than their literals);
+            //   * one-step lazy choice (the next position's match wins when it is two bytes longer);
+            //   * offsets equal to one of the block's last three go out as repeat codes.  The history starts unknown
+            //     (0): blocks are encoded independently, so a code is only used once this block has defined its entry.
+            constexpr uint32_t LMAX = 64;
+            uint2 *const B = reinterpret_cast<uint2 *>(S.table);
+            uint32_t r0 = 0, r1 = 0, r2 = 0;
+            while (base < scan_end && nseq < max_seq) {
+                const uint32_t pos = base + lane;
+                uint32_t cand = 0, mlen = 0, v = 0;
+                auto store_tail = [&]() {  // this window's bytes that no match of the window covers
+                    const uint32_t wend = base + 64 < nq ? base + 64 : nq;
+                    if (emitted < base) {  // a stretch skipped while accelerating through incompressible data
+                        wave_copy(lits + lit_total + (emitted - anchor), inb + emitted, base - emitted, lane);
+                        emitted = base;
+                    }
+                    if (emitted < wend) {
+                        if (pos >= emitted && pos < wend) lits[lit_total + (pos - anchor)] = pos < scan_end ? (uint8_t)v : inb[pos];
+                        emitted = wend;
+                    }
+                };
+                auto extend = [&](uint32_t c) -> uint32_t {  // bytes (>= 4, <= LMAX) that pos and c have in common
+                    const uint32_t lim = nq - pos < LMAX ? nq - pos : LMAX;
+                    uint32_t k = 4;
+                    bool open = true;
+                    while (open && k + 8 <= lim) {
+                        uint64_t x, y;
+                        __builtin_memcpy(&x, inb + pos + k, 8);
+                        __builtin_memcpy(&y, inb + c + k, 8);
+                        const uint64_t d = x ^ y;
+                        if (d) { k += (uint32_t)(__ffsll((long long)d) - 1) >> 3; open = false; }
+                        else k += 8;
+                    }
+                    while (open && k < lim && inb[pos + k] == inb[c + k]) k++;
+                    return k;
+                };
+                const uint32_t r0w = r0;
+                if (pos < scan_end) {
+                    v = ld32(inb + pos);
+                    const uint32_t h = hash4<11>(v);
+                    const uint2 b = B[h];
+                    B[h] = make_uint2((b.x << 16) | (pos & 0xFFFFu), (b.y << 16) | (b.x >> 16));
+                    uint32_t c[4] = {b.x & 0xFFFFu, b.x >> 16, b.y & 0xFFFFu, b.y >> 16};
+                    uint32_t cv[4];
+#pragma unroll
+                    for (int w = 0; w < 4; w++) {
+                        const bool have = c[w] != 0xFFFFu;
+                        c[w] |= pos & ~0xFFFFu;
+                        if (c[w] >= pos) c[w] -= 0x10000u;  // wraps to a huge value when there is no earlier half
+                        if (!have || c[w] >= pos) c[w] = 0xFFFFFFFFu;
+                        cv[w] = c[w] != 0xFFFFFFFFu ? ld32(inb + c[w]) : ~v;
+                    }
+#pragma unroll
+                    for (int w = 0; w < 4; w++)
+                        if (cv[w] == v && c[w] != 0xFFFFFFFFu) {
+                            const uint32_t k = extend(c[w]);
+                            if (k > mlen) { mlen = k; cand = c[w]; }  // ties stay with the newer (closer) one
+                        }
+                    if (mlen) {
+                        const uint32_t off = pos - cand;
+                        if ((mlen == 4 && off > 2048u) || (mlen == 5 && off > 32768u)) mlen = 0;
+                    }
+                    if (r0w && pos >= r0w && ld32(inb + pos - r0w) == v) {
+                        const uint32_t k = extend(pos - r0w);
+                        if (k + 1 >= mlen) { mlen = k; cand = pos - r0w; }
+                    }
+                }
+                const uint64_t hitm = __ballot(mlen != 0);
+                if (!hitm) {
+                    if (misses < 2) store_tail();
+                    misses++;
+                    if (nseq == 0 && misses >= 96) { gave_up = true; break; }
+                    base += 64 * (1 + (misses >> 4 > 7 ? 7 : misses >> 4));
+                    continue;
+                }
+                misses = 0;
+                while (nseq < max_seq) {
+                    const uint32_t skip = anchor > base ? anchor - base : 0;
+                    const uint64_t m = skip >= 64 ? 0ull : (hitm >> skip) << skip;
+                    if (!m) break;
+                    uint32_t win = (uint32_t)__ffsll((long long)m) - 1;
+                    uint32_t ml = rdlane(mlen, win);
+                    if (win < 63 && ((m >> (win + 1)) & 1) && base + win - rdlane(cand, win) != r0) {
+                        const uint32_t ml1 = rdlane(mlen, win + 1);
+                        if (ml1 > ml + 1) { win++; ml = ml1; }
+                    }
+                    const uint32_t mpos = base + win, mcand = rdlane(cand, win);
+                    if (ml >= LMAX) {
+                        for (;;) {  // cooperative extension: 16 bytes per lane per piece, 4 pieces (4 KiB) in flight per step
+                            uint32_t good[4];
+#pragma unroll
+                            for (int q = 0; q < 4; q++) {
+                                const uint32_t o = ml + q * 1024 + lane * 16;
+                                uint32_t g = 0;
+                                if (mpos + o + 16 <= nq) {
+                                    uint4 x = ld128(inb + mpos + o), y = ld128(inb + mcand + o);
+                                    const uint32_t d0 = x.x ^ y.x, d1 = x.y ^ y.y, d2 = x.z ^ y.z, d3 = x.w ^ y.w;
+                                    g = 16;
+                                    if (d0 | d1 | d2 | d3) {
+                                        if (d0) g = (__ffs(d0) - 1) >> 3;
+                                        else if (d1) g = 4 + ((__ffs(d1) - 1) >> 3);
+                                        else if (d2) g = 8 + ((__ffs(d2) - 1) >> 3);
+                                        else g = 12 + ((__ffs(d3) - 1) >> 3);
+                                    }
+                                } else {
+                                    while (g < 16 && mpos + o + g < nq && inb[mpos + o + g] == inb[mcand + o + g]) g++;
+                                }
+                                good[q] = g;
+                            }
+                            bool done = false;
+#pragma unroll
+                            for (int q = 0; q < 4; q++) {
+                                if (done) break;
+                                const uint64_t partial = __ballot(good[q] != 16);
+                                if (partial) {
+                                    const uint32_t fl = __ffsll((unsigned long long)partial) - 1;
+                                    ml += fl * 16 + __shfl(good[q], fl);
+                                    done = true;
+                                } else {
+                                    ml += 1024;
+                                }
+                            }
+                            if (done) break;
+                        }
+                    }
+                    const uint32_t ll = mpos - anchor, off = mpos - mcand;
+                    if (emitted < mpos) {
+                        if (emitted < base) {
+                            wave_copy(lits + lit_total + (emitted - anchor), inb + emitted, base - emitted, lane);
+                            emitted = base;
+                        }
+                        if (pos >= emitted && pos < mpos) lits[lit_total + (pos - anchor)] = (uint8_t)v;
+                    }
+                    // offset value (RFC 8878 3.1.1.3.2.1.1 / 3.1.1.5): 1..3 name the history, shifted by one when ll == 0
+                    uint32_t ov = off + 3;
+                    if (ll) {
+                        if (off == r0) ov = 1;
+                        else if (off == r1) { ov = 2; r1 = r0; r0 = off; }
+                        else if (off == r2) { ov = 3; r2 = r1; r1 = r0; r0 = off; }
+                        else { r2 = r1; r1 = r0; r0 = off; }
+                    } else {
+                        if (off == r1) { ov = 1; r1 = r0; r0 = off; }
+                        else if (off == r2) { ov = 2; r2 = r1; r1 = r0; r0 = off; }
+                        else if (r0 > 1 && off == r0 - 1) { ov = 3; r2 = r1; r1 = r0; r0 = off; }
+                        else { r2 = r1; r1 = r0; r0 = off; }
+                    }
+                    if (lane == 0) {
+                        seqs[3 * nseq] = ll;
+                        seqs[3 * nseq + 1] = ml - 3;
+                        seqs[3 * nseq + 2] = ov;
+                    }
+                    lit_total += ll;
+                    nseq++;
+                    anchor = mpos + ml;
+                    emitted = anchor;
+                }
+                store_tail();
+                base = anchor > base + 64 ? anchor : base + 64;
+            }
+        } else if constexpr (HASH_LOG == 13) {
             // Wide variant: every lane probes its position AND extends its own candidate (up to LMAX bytes), then the
             // window's matches are picked left to right — several sequences per 64 positions on real data instead
             // of one.  Only a match that runs past LMAX is extended cooperatively (periodic data: 4 KiB per step).
@@ -786,7 +955,7 @@ __global__ __launch_bounds__(64) void k_zstd_encode(EncodeArgs a) {
             if (nseq == 0) p += 1;  // a block of literals only: the sequences section is the single count byte
             else
             // wide variant (128 KiB blocks, thousands of sequences): wave-parallel bitstream; small variant: serial writer
-            if (HASH_LOG == 13 && nseq > 8) p = encode_sequences(S, seqs, nseq, p + hl + 1, lane);
+            if (HASH_LOG == 13 && nseq > 8) p = encode_sequences(S, seqs, nseq, p + hl + 1, lane, HIGH ? 0u : 3u);
             else {
                 // a handful of sequences (periodic data: one or two per block): the serial writer costs fewer
                 // issue slots than a wave-wide pass, and those slots belong to the hash kernel running alongside
@@ -795,7 +964,7 @@ __global__ __launch_bounds__(64) void k_zstd_encode(EncodeArgs a) {
                     BitW b{p + hl + 1, 0, 0};
                     CState sl, so, sm;
                     for (int32_t i = (int32_t)nseq - 1; i >= 0; i--) {
-                        const uint32_t ll = seqs[3 * i], mlb = seqs[3 * i + 1], ov = seqs[3 * i + 2] + 3;
+                        const uint32_t ll = seqs[3 * i], mlb = seqs[3 * i + 1], ov = seqs[3 * i + 2] + (HIGH ? 0u : 3u);
                         const uint32_t lc = ll < 64 ? c_ll_code[ll] : (uint32_t)hib(ll) + 19;
                         const uint32_t mc = mlb < 128 ? c_ml_code[mlb] : (uint32_t)hib(mlb) + 36;
                         const uint32_t oc = (uint32_t)hib(ov);
@@ -904,9 +1073,10 @@ __global__ __launch_bounds__(256) void k_gather(GatherArgs g) {
     }
 }
 
-void launch_encode(const EncodeArgs &a, int grid, bool small_blocks, hipStream_t s) {
+void launch_encode(const EncodeArgs &a, int grid, bool small_blocks, bool high, hipStream_t s) {
     if (!a.n_items) return;
     if (small_blocks) hipLaunchKernelGGL(k_zstd_encode<11>, dim3(grid), dim3(64), 0, s, a);
+    else if (high) hipLaunchKernelGGL((k_zstd_encode<13, true>), dim3(grid), dim3(64), 0, s, a);
     else hipLaunchKernelGGL(k_zstd_encode<13>, dim3(grid), dim3(64), 0, s, a);
 }
 

@@ -71,6 +71,14 @@ class Context:
         n = self.L.znippy_last_kernel_times(self.h, names, ms, 16)
         return [(names[i].decode(), float(ms[i])) for i in range(n)]
 
+    def set_level(self, level):
+        """CompressCtx::new(compression_level), codec.rs:L16-28: levels 1-3 fast tier, 4-22 higher effort tier."""
+        self._chk(self.L.znippy_ctx_set_level(self.h, int(level)), "znippy_ctx_set_level")
+
+    @property
+    def level(self):
+        return int(self.L.znippy_ctx_level(self.h))
+
     def set_kernel_timing(self, level):
         """2 = HIP events around every kernel (default), 1 = around the dominant read kernels only, 0 = none."""
         self._chk(self.L.znippy_ctx_set_kernel_timing(self.h, int(level)), "znippy_ctx_set_kernel_timing")
