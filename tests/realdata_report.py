@@ -8,26 +8,7 @@ import numpy as np, torch
 from oracle import oracle as O
 from znippy_amd import hip
 
-def corpus(kind, cap):
-    pats = {"text": ["/usr/lib/python3.10/**/*.py", "/usr/lib/python3/dist-packages/**/*.py", "/opt/rocm/include/**/*.h*"],
-            "binary": ["/opt/rocm/lib/*.so*", "/usr/lib/x86_64-linux-gnu/*.so*"]}[kind]
-    out, tot = [], 0
-    for pat in pats:
-        for f in sorted(glob.glob(pat, recursive=True)):
-            if os.path.islink(f) or not os.path.isfile(f):
-                continue
-            try:
-                b = open(f, "rb").read()
-            except OSError:
-                continue
-            if not b:
-                continue
-            for o in range(0, len(b), 8 << 20):
-                out.append(b[o:o + (8 << 20)])
-                tot += len(out[-1])
-            if tot >= cap:
-                return out
-    return out
+from workloads import image_corpus as corpus
 
 def run(kind, cap):
     ents = corpus(kind, cap)

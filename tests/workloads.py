@@ -78,6 +78,22 @@ def libzstd_compress(data, level=19) -> bytes:
     return out.raw[:r]
 
 
+def libzstd_decompress(frame, cap) -> bytes:
+    """The system's libzstd decoding one frame (ctypes, no oracle involved): an outside judge of the encoder's frames."""
+    import ctypes as C
+    z = C.CDLL("libzstd.so.1")
+    z.ZSTD_decompress.restype = C.c_size_t
+    z.ZSTD_decompress.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
+    z.ZSTD_isError.restype = C.c_uint
+    z.ZSTD_isError.argtypes = [C.c_size_t]
+    out = C.create_string_buffer(max(int(cap), 1))
+    raw = bytes(frame)
+    r = z.ZSTD_decompress(out, max(int(cap), 1), raw, len(raw))
+    if z.ZSTD_isError(r):
+        raise RuntimeError("ZSTD_decompress failed")
+    return out.raw[:r]
+
+
 def libzstd_compress_adv(data, level=19, checksum=False, window_log=0) -> bytes:
     """libzstd's advanced API (ZSTD_compress2): a frame with a content checksum trailer and/or a given window log."""
     import ctypes as C
@@ -106,3 +122,28 @@ def libzstd_compress_adv(data, level=19, checksum=False, window_log=0) -> bytes:
         return out.raw[:r]
     finally:
         z.ZSTD_freeCCtx(cctx)
+
+
+def image_corpus(kind, cap):
+    """Real files found in the image (not a BASELINE config): kind "text" = Python / C++ sources, "binary" = shared
+    objects; cut into rounds of at most 8 MiB, up to cap bytes."""
+    import glob, os
+    pats = {"text": ["/usr/lib/python3.10/**/*.py", "/usr/lib/python3/dist-packages/**/*.py", "/opt/rocm/include/**/*.h*"],
+            "binary": ["/opt/rocm/lib/*.so*", "/usr/lib/x86_64-linux-gnu/*.so*"]}[kind]
+    out, tot = [], 0
+    for pat in pats:
+        for f in sorted(glob.glob(pat, recursive=True)):
+            if os.path.islink(f) or not os.path.isfile(f):
+                continue
+            try:
+                b = open(f, "rb").read()
+            except OSError:
+                continue
+            if not b:
+                continue
+            for o in range(0, len(b), 8 << 20):
+                out.append(b[o:o + (8 << 20)])
+                tot += len(out[-1])
+            if tot >= cap:
+                return out
+    return out

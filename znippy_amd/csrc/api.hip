@@ -1401,6 +1401,7 @@ extern "C" int znippy_encode_hash_rounds_async(znippy_ctx *ctx, znippy_rounds *r
     a.src = (const uint8_t *)d_src; a.src_off = r->src_off; a.len = r->len;
     a.prov = ctx->enc_prov; a.seq_scratch = ctx->enc_seq;
     a.piece_len = r->piece_len; a.piece_start = r->piece_start; a.tabs = ctx->enc_tabs;
+    a.tail_mark = ctx->level >= HIGH_TIER_LEVEL;
     if (ctx->sw.edbg) {  // diagnostic: phase shares of the previous run's wide-variant blocks
         static unsigned long long *dbg = nullptr;
         if (!dbg) { (void)hipMalloc(&dbg, 64); (void)hipMemset(dbg, 0, 64); }
@@ -1578,8 +1579,9 @@ extern "C" int znippy_compress(znippy_ctx *ctx, const void *src, size_t n, void 
 }
 
 extern "C" size_t znippy_compress_bound(size_t n) {
-    // every 128 KiB block can fall back to a raw block (3-byte header) + frame header
-    return n + 3 * (n / BLOCK_BYTES + 1) + 16;
+    // every 128 KiB block can fall back to a raw block (3-byte header) + frame header (<= 13) + the empty closing block
+    // the higher effort tier puts behind frames of several blocks
+    return n + 3 * (n / BLOCK_BYTES + 1) + 19;
 }
 
 extern "C" int znippy_rounds_set_store_incompressible(znippy_rounds *r, int on) {

@@ -54,6 +54,7 @@ struct EncodeArgs {
     uint32_t *piece_len;
     uint64_t *piece_start;  // offset in prov where the finished piece begins
     const EncTables *tabs;
+    int tail_mark;  // higher effort tier: frames of several blocks end with an empty raw block (zstd_encode.hip)
 };
 
 struct GatherArgs {

@@ -1515,9 +1515,17 @@ __global__ __launch_bounds__(64) void k_scan_blocks(BlockScanArgs a) {
     // so lane i guesses "header i blocks ahead = pos + i * (size of the previous block)": when the guess holds the
     // wave walks 64 headers per round trip, when it does not (real data) it advances by one, as before.
     uint32_t k = 0;
-    bool last = false;
+    bool last = false, style_first = true, tail_mark = false;
     uint64_t stride = 0;  // 3 + payload bytes of the previous block (0: no guess yet)
     while (ok && !last) {
+        if (k == nb) {
+            // all expected blocks seen and none was the last: the encoder's higher effort tier closes such a frame with an
+            // empty raw last block — its statement that every block stands on its own (zstd_encode.hip, tail_mark)
+            tail_mark = pos + 3 == n && src[pos] == 1 && src[pos + 1] == 0 && src[pos + 2] == 0;
+            if (tail_mark) pos += 3;
+            else ok = false;
+            break;
+        }
         const uint64_t p_i = pos + (uint64_t)lane * stride;
         const bool valid = (lane == 0 || stride != 0) && k + lane < nb && p_i + 3 <= n;
         uint32_t bh = 0;
@@ -1562,7 +1570,7 @@ __global__ __launch_bounds__(64) void k_scan_blocks(BlockScanArgs a) {
                         const uint32_t hl = s0 == 0 ? 0 : (s0 < 128 ? 1 : (s0 < 255 ? 2 : 3));
                         if (hl && (q + hl >= bend || src[q + hl] != 0)) style = false;  // modes byte: all Predefined
                     } else style = false;
-                    if (!style) { ok = false; break; }
+                    style_first = style;  // not this encoder's plain style: only the closing mark can vouch for the frame
             }
         }
         if (mine) a.item_src[base + k + lane] = (uint32_t)p_i;
@@ -1572,7 +1580,7 @@ __global__ __launch_bounds__(64) void k_scan_blocks(BlockScanArgs a) {
         last = __shfl(lst ? 1u : 0u, lastl) != 0;
         k += taken;
     }
-    ok = ok && k == nb && pos == n;  // the expected number of blocks, nothing behind the last one
+    ok = ok && k == nb && pos == n && (style_first || tail_mark);  // the expected number of blocks, nothing behind the last one
     if (!ok)
         for (uint32_t i = lane; i < nb; i += 64) a.item_src[base + i] = 0xFFFFFFFFu;
     if (lane == 0) a.row_flag[row] = ok ? 0u : 1u;

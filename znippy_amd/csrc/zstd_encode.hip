@@ -250,6 +250,274 @@ __device__ __noinline__ uint8_t *encode_sequences(SH &S, const uint32_t *seqs, u
     return p + ((bitpos + 18 + 7) >> 3);
 }
 
+// Sequences section with per-block FSE tables (RFC 8878 3.1.1.3.2.1: Compression_Modes FSE_Compressed / RLE), the
+// higher effort tier's counterpart of encode_sequences.  tools/enc_model.c puts the predefined distributions at 12 % of
+// the whole output on real text: they price this matcher's offsets (codes 8..16) at 5 bits each.  The wave
+//   * counts the three code alphabets (LDS atomics) and normalises each to 2^tl (tl 6..8 by sequence count; every
+//     present symbol >= 1, the remainder to the most frequent one) — lane = symbol;
+//   * writes the table description with one field per lane: what a symbol's field looks like depends only on the
+//     counts before it (an exclusive scan), and a run of absent symbols is its first member's field plus repeat flags;
+//   * builds the encoding tables: symbol rows from the scan; the state table by walking the spread table 64 cells at a
+//     time (cell -> flat occurrence index through the inverse of the spread step -> symbol by binary search in the
+//     cumulative counts -> rank inside the symbol by ballots);
+//   * runs the same batch loop as encode_sequences with the state tables in LDS.
+// The hash table is dead by now and holds all of it.  p = the Compression_Modes byte; returns the section's end.
+template <class SH>
+__device__ __noinline__ uint8_t *encode_sequences_custom(SH &S, const uint32_t *seqs, uint32_t nseq, uint8_t *p, uint32_t lane) {
+    uint32_t *const W = reinterpret_cast<uint32_t *>(S.table);
+    uint32_t *const ebits = W, *const hist = W + 256;                 // bit window (256 words), 3 x 64 counts (LL, ML, OF)
+    FseSymTT *const tt = reinterpret_cast<FseSymTT *>(W + 448);       // 3 x 64 symbol rows
+    uint16_t *const stt = reinterpret_cast<uint16_t *>(W + 832);      // 3 x 256 states
+    uint32_t *const cum = W + 1216, *const cur = W + 1280, *const hbits = W + 1344;  // 64, 64, 32 words
+    for (uint32_t i = lane; i < 448; i += 64) W[i] = 0;
+    __builtin_amdgcn_wave_barrier();
+    for (uint32_t i = lane; i < nseq; i += 64) {
+        const uint32_t ll = seqs[3 * i], mlb = seqs[3 * i + 1], ov = seqs[3 * i + 2];
+        const uint32_t lc = ll < 64 ? c_ll_code[ll] : (uint32_t)hib(ll) + 19;
+        const uint32_t mc = mlb < 128 ? c_ml_code[mlb] : (uint32_t)hib(mlb) + 36;
+        atomicAdd(&hist[lc], 1u); atomicAdd(&hist[64 + mc], 1u); atomicAdd(&hist[128 + (uint32_t)hib(ov)], 1u);
+    }
+    __builtin_amdgcn_wave_barrier();
+    auto wsum = [&](uint32_t v) -> uint32_t {
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
+        return v;
+    };
+    auto wmax = [&](uint32_t v) -> uint32_t {
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) { const uint32_t o = __shfl_xor(v, d); v = o > v ? o : v; }
+        return v;
+    };
+    uint32_t tl = (uint32_t)hib(nseq) - 2;
+    tl = tl < 6 ? 6 : (tl > 8 ? 8 : tl);
+    const uint32_t ts = 1u << tl, step = (ts >> 1) + (ts >> 3) + 3;
+    uint32_t inv = step;  // inverse of the (odd) spread step modulo 2^tl: Newton, 3 -> 6 -> 12 correct bits
+    inv *= 2u - step * inv; inv *= 2u - step * inv;
+    const uint64_t below = lane ? (~0ull >> (64 - lane)) : 0ull;
+    uint32_t lg[3] = {0, 0, 0}, modes = 0;  // table log per kind (0 = RLE), kinds: 0 LL, 1 ML, 2 OF
+    uint8_t *q = p + 1;
+    for (uint32_t t = 0; t < 3; t++) {  // section order: LL, OF, ML
+        const uint32_t k = t == 0 ? 0u : (t == 1 ? 2u : 1u);
+        const uint32_t c = hist[k * 64 + lane];
+        const uint64_t present = __ballot(c != 0);
+        const uint32_t last = 63u - (uint32_t)__clzll(present);
+        const uint32_t mode_shift = k == 0 ? 6u : (k == 2 ? 4u : 2u);
+        if (__popcll(present) == 1) {  // RLE_Mode: one byte, a table of one state that costs no bits
+            modes |= 1u << mode_shift;
+            if (lane == 0) { *q = (uint8_t)last; tt[k * 64 + last].delta_nb_bits = 0; tt[k * 64 + last].delta_find_state = 0; stt[k * 256] = 0; }
+            q += 1;
+            continue;
+        }
+        modes |= 2u << mode_shift;
+        lg[k] = tl;
+        uint32_t norm = c ? (c * ts + (nseq >> 1)) / nseq : 0;
+        if (c && !norm) norm = 1;
+        const uint32_t sum = wsum(norm);
+        if (sum <= ts) {
+            const uint32_t big = wmax((c << 6) | lane) & 63;
+            if (lane == big) norm += ts - sum;
+        } else {
+            uint32_t excess = sum - ts;
+            while (excess) {  // take it from the largest counts, a quarter of one at a time
+                const uint32_t kb = wmax(norm > 1 ? (norm << 6) | lane : 0u);
+                const uint32_t nb = kb >> 6;
+                uint32_t take = nb >> 2 ? nb >> 2 : 1u;
+                take = take < excess ? take : excess;
+                take = take < nb - 1 ? take : nb - 1;
+                if (lane == (kb & 63)) norm -= take;
+                excess -= take;
+            }
+        }
+        uint32_t incl = norm;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t y = __shfl_up(incl, d);
+            if (lane >= (uint32_t)d) incl += y;
+        }
+        const uint32_t excl = incl - norm;
+        // symbol rows
+        if (norm) {
+            FseSymTT r;
+            if (norm == 1) { r.delta_nb_bits = (tl << 16) - ts; r.delta_find_state = (int32_t)excl - 1; }
+            else {
+                const uint32_t mbo = tl - (uint32_t)hib(norm - 1);
+                r.delta_nb_bits = (mbo << 16) - (norm << mbo);
+                r.delta_find_state = (int32_t)excl - (int32_t)norm;
+            }
+            tt[k * 64 + lane] = r;
+        }
+        cum[lane] = incl;
+        cur[lane] = excl;
+        for (uint32_t i = lane; i < 32; i += 64) hbits[i] = 0;
+        __builtin_amdgcn_wave_barrier();
+        // state table
+        for (uint32_t u0 = 0; u0 < ts; u0 += 64) {
+            const uint32_t u = u0 + lane, kf = (u * inv) & (ts - 1);
+            uint32_t sidx = 0;
+#pragma unroll
+            for (uint32_t st2 = 32; st2; st2 >>= 1)
+                if (cum[sidx + st2 - 1] <= kf) sidx += st2;
+            uint64_t todo = ~0ull;
+            uint32_t slot = 0;
+            while (todo) {
+                const uint32_t l = (uint32_t)__ffsll((long long)todo) - 1, sl = rdlane(sidx, l);
+                const uint64_t same = __ballot(sidx == sl);
+                const uint32_t b0 = cur[sl];
+                if (sidx == sl) slot = b0 + (uint32_t)__popcll(same & below);
+                if (lane == l) cur[sl] = b0 + (uint32_t)__popcll(same);
+                todo &= ~same;
+            }
+            stt[k * 256 + slot] = (uint16_t)(ts + u);
+        }
+        // table description
+        {
+            const uint32_t prevn = __shfl_up(norm, 1);
+            const uint64_t nz = __ballot(norm != 0);
+            uint64_t val = 0;
+            uint32_t nb = 0;
+            const bool zero = norm == 0;
+            if (lane <= last && !(zero && lane && prevn == 0)) {
+                const uint32_t remaining = ts + 1 - excl;
+                const uint32_t thr = 1u << hib(remaining), nbb = (uint32_t)hib(thr) + 1, mx = 2 * thr - 1 - remaining;
+                uint32_t cnt = norm + 1;
+                const bool small = cnt < mx;
+                if (cnt >= thr) cnt += mx;
+                val = cnt;
+                nb = nbb - (small ? 1u : 0u);
+                if (zero) {  // repeat flags: how many more absent symbols follow, 3 per flag, the last flag < 3
+                    const uint32_t next = lane + (uint32_t)__ffsll((long long)(nz >> (lane + 1)));  // lane < last: one exists
+                    const uint32_t more = next - lane - 1, q3 = more / 3, r3 = more % 3;
+                    const uint64_t flags = ((1ull << (2 * q3)) - 1) | ((uint64_t)r3 << (2 * q3));
+                    val |= flags << nb;
+                    nb += 2 * q3 + 2;
+                }
+            }
+            uint32_t inc = nb;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const uint32_t y = __shfl_up(inc, d);
+                if (lane >= (uint32_t)d) inc += y;
+            }
+            const uint32_t bp = 4 + inc - nb;  // the first 4 bits are Accuracy_Log - 5
+            if (lane == 0) atomicOr(&hbits[0], tl - 5);
+            if (nb) {
+                const uint32_t sft = bp & 31, w = bp >> 5;  // nb <= 9 + 36
+                const uint64_t x0 = val << sft;
+                const uint32_t x1 = sft ? (uint32_t)(val >> (64 - sft)) : 0u;
+                if ((uint32_t)x0) atomicOr(&hbits[w], (uint32_t)x0);
+                if ((uint32_t)(x0 >> 32)) atomicOr(&hbits[w + 1], (uint32_t)(x0 >> 32));
+                if (x1) atomicOr(&hbits[w + 2], x1);
+            }
+            const uint32_t total = 4 + rdlane(inc, 63), nbytes = (total + 7) >> 3;
+            __builtin_amdgcn_wave_barrier();
+            for (uint32_t i = lane; i < nbytes; i += 64) q[i] = (uint8_t)(hbits[i >> 2] >> (8 * (i & 3)));
+            q += nbytes;
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (lane == 0) *p = (uint8_t)modes;
+    __builtin_amdgcn_wave_barrier();
+    // ---- bitstream: encode_sequences' batch loop, state tables in LDS ----
+    p = q;
+    const uint16_t *const s_ll = stt, *const s_ml = stt + 256, *const s_of = stt + 512;
+    uint32_t vl = 0, vm = 0, vo = 0;
+    uint32_t bitpos = 0;
+    for (uint32_t e0 = 0; e0 < nseq; e0 += 64) {
+        const uint32_t cnt = nseq - e0 < 64 ? nseq - e0 : 64;
+        const bool on = lane < cnt;
+        const uint32_t i = nseq - 1 - (e0 + (on ? lane : 0));
+        const uint32_t ll = seqs[3 * i], mlb = seqs[3 * i + 1], ov = seqs[3 * i + 2];
+        const uint32_t lc = ll < 64 ? c_ll_code[ll] : (uint32_t)hib(ll) + 19;
+        const uint32_t mc = mlb < 128 ? c_ml_code[mlb] : (uint32_t)hib(mlb) + 36;
+        const uint32_t oc = (uint32_t)hib(ov);
+        const FseSymTT tl_ = tt[lc], tm_ = tt[64 + mc], to_ = tt[128 + oc];
+        uint32_t f_l = 0, f_m = 0, f_o = 0;
+        for (uint32_t j = 0; j < cnt; j++) {
+            const uint32_t dl = rdlane(tl_.delta_nb_bits, j), fl = rdlane((uint32_t)tl_.delta_find_state, j);
+            const uint32_t dm = rdlane(tm_.delta_nb_bits, j), fm = rdlane((uint32_t)tm_.delta_find_state, j);
+            const uint32_t d_o = rdlane(to_.delta_nb_bits, j), fo = rdlane((uint32_t)to_.delta_find_state, j);
+            if (e0 + j == 0) {
+                const uint32_t nbm = (dm + (1u << 15)) >> 16, nbo = (d_o + (1u << 15)) >> 16, nbl = (dl + (1u << 15)) >> 16;
+                const uint32_t xm = s_ml[(uint32_t)((int32_t)(((nbm << 16) - dm) >> nbm) + (int32_t)fm)];
+                const uint32_t xo = s_of[(uint32_t)((int32_t)(((nbo << 16) - d_o) >> nbo) + (int32_t)fo)];
+                const uint32_t xl = s_ll[(uint32_t)((int32_t)(((nbl << 16) - dl) >> nbl) + (int32_t)fl)];
+                vm = suni(xm); vo = suni(xo); vl = suni(xl);
+            } else {
+                const uint32_t nbo = (vo + d_o) >> 16, nbm = (vm + dm) >> 16, nbl = (vl + dl) >> 16;
+                if (lane == j) {
+                    f_o = (vo & ((1u << nbo) - 1)) | (nbo << 16);
+                    f_m = (vm & ((1u << nbm) - 1)) | (nbm << 16);
+                    f_l = (vl & ((1u << nbl) - 1)) | (nbl << 16);
+                }
+                const uint32_t xo = s_of[(uint32_t)((int32_t)(vo >> nbo) + (int32_t)fo)];
+                const uint32_t xm = s_ml[(uint32_t)((int32_t)(vm >> nbm) + (int32_t)fm)];
+                const uint32_t xl = s_ll[(uint32_t)((int32_t)(vl >> nbl) + (int32_t)fl)];
+                vo = suni(xo); vm = suni(xm); vl = suni(xl);
+            }
+        }
+        uint64_t lo = 0, hi = 0;
+        uint32_t T = 0;
+        auto put = [&](uint32_t v, uint32_t nb) {  // nb <= 17, v < 2^nb
+            if (T < 64) {
+                lo |= (uint64_t)v << T;
+                if (T + nb > 64) hi |= (uint64_t)v >> (64 - T);
+            } else hi |= (uint64_t)v << (T - 64);
+            T += nb;
+        };
+        if (on) {
+            put(f_o & 0xFFFF, f_o >> 16);
+            put(f_m & 0xFFFF, f_m >> 16);
+            put(f_l & 0xFFFF, f_l >> 16);
+            put(ll - c_ll_base_e[lc], c_ll_bits_e[lc]);
+            put(mlb + 3 - c_ml_base_e[mc], c_ml_bits_e[mc]);
+            put(ov - (1u << oc), oc);
+        }
+        uint32_t inc = T;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t y = __shfl_up(inc, d);
+            if (lane >= (uint32_t)d) inc += y;
+        }
+        const uint32_t pos = bitpos + inc - T;
+        if (T) {
+            const uint32_t sft = pos & 31, w = pos >> 5;
+            const uint64_t x0 = lo << sft, x1 = (hi << sft) | (sft ? lo >> (64 - sft) : 0ull);
+            const uint32_t w0 = (uint32_t)x0, w1 = (uint32_t)(x0 >> 32), w2 = (uint32_t)x1, w3 = (uint32_t)(x1 >> 32);
+            if (w0) atomicOr(&ebits[w], w0);
+            if (w1) atomicOr(&ebits[w + 1], w1);
+            if (w2) atomicOr(&ebits[w + 2], w2);
+            if (w3) atomicOr(&ebits[w + 3], w3);
+        }
+        bitpos = suni(bitpos + __shfl(inc, 63));
+        __builtin_amdgcn_wave_barrier();
+        const uint32_t ndw = bitpos >> 5;
+        uint32_t keep = 0;
+        for (uint32_t k2 = lane; k2 < ndw; k2 += 64) {
+            const uint32_t w = ebits[k2];
+            __builtin_memcpy(p + 4 * k2, &w, 4);
+        }
+        keep = ebits[ndw];
+        __builtin_amdgcn_wave_barrier();
+        for (uint32_t k2 = lane; k2 <= ndw; k2 += 64) ebits[k2] = 0;
+        __builtin_amdgcn_wave_barrier();
+        if (lane == 0) ebits[0] = keep;
+        __builtin_amdgcn_wave_barrier();
+        p += 4 * ndw;
+        bitpos &= 31;
+    }
+    const uint32_t fin = lg[1] + lg[2] + lg[0] + 1;  // final states (ML, OF, LL) and the closing bit
+    if (lane == 0) {
+        uint64_t acc = ebits[0];
+        uint32_t nb = bitpos;
+        acc |= (uint64_t)(vm & ((1u << lg[1]) - 1)) << nb; nb += lg[1];
+        acc |= (uint64_t)(vo & ((1u << lg[2]) - 1)) << nb; nb += lg[2];
+        acc |= (uint64_t)(vl & ((1u << lg[0]) - 1)) << nb; nb += lg[0];
+        acc |= 1ull << nb; nb += 1;
+        for (uint32_t k2 = 0; k2 * 8 < nb; k2++) p[k2] = (uint8_t)(acc >> (8 * k2));
+    }
+    return p + ((bitpos + fin + 7) >> 3);
+}
+
 // Huffman-coded literals section (RFC 8878 §4.2.1) for the wide variant, built by the whole wave:
 //   histogram (LDS atomics) -> code lengths <= 11 (Shannon lengths, then greedy repair until the Kraft sum is
 //   exactly 1: lengthen the rarest symbols while over-subscribed, shorten the most frequent ones that fit the gap)
@@ -260,6 +528,7 @@ __device__ __noinline__ uint8_t *encode_sequences(SH &S, const uint32_t *seqs, u
 // size of the section written at `dst` (header included), or 0 to keep raw literals: alphabet beyond 128 symbols
 // (would need FSE-compressed weights), a single symbol, or no gain.
 constexpr uint32_t HUF_MIN_LITS = 256, HUF_MAX_BITS = 11;
+constexpr uint32_t CUSTOM_FSE_MIN_SEQ = 128;  // below this the three table descriptions cost more than they save
 template <class SH>
 __device__ __forceinline__ uint32_t huf_literals(SH &S, const uint8_t *lits, uint32_t n, uint8_t *tmp, uint8_t *dst, uint32_t lane) {
     uint32_t *const T = reinterpret_cast<uint32_t *>(S.table);  // the hash table is dead: hist | codes | bit window
@@ -955,7 +1224,8 @@ __global__ __launch_bounds__(64) void k_zstd_encode(EncodeArgs a) {
             if (nseq == 0) p += 1;  // a block of literals only: the sequences section is the single count byte
             else
             // wide variant (128 KiB blocks, thousands of sequences): wave-parallel bitstream; small variant: serial writer
-            if (HASH_LOG == 13 && nseq > 8) p = encode_sequences(S, seqs, nseq, p + hl + 1, lane, HIGH ? 0u : 3u);
+            if (HIGH && nseq >= CUSTOM_FSE_MIN_SEQ) p = encode_sequences_custom(S, seqs, nseq, p + hl, lane);  // writes the modes byte itself
+            else if (HASH_LOG == 13 && nseq > 8) p = encode_sequences(S, seqs, nseq, p + hl + 1, lane, HIGH ? 0u : 3u);
             else {
                 // a handful of sequences (periodic data: one or two per block): the serial writer costs fewer
                 // issue slots than a wave-wide pass, and those slots belong to the hash kernel running alongside
@@ -992,18 +1262,25 @@ __global__ __launch_bounds__(64) void k_zstd_encode(EncodeArgs a) {
             if (csize >= n) raw = true;
         }
         ESTAMP(4);
+        // Higher effort tier, frames of several blocks: the frame ends with an EMPTY raw block (3 bytes, legal anywhere in
+        // a frame) behind the last real one.  It tells this build's block scan that every block of the frame stands on its
+        // own (k_block_scan: a first block with per-block entropy tables looks like any foreign frame otherwise, and a
+        // foreign frame's blocks are not worth trying one by one).  To every other decoder it is a block of no bytes.
+        const bool tail_mark = a.tail_mark && last && it.n_blocks > 1;  // (a short last block is encoded by the small variant)
         if (lane == 0) {
             uint32_t piece_len = 0, hdr_len = 0;
+            const uint32_t last_bit = last && !tail_mark ? 1u : 0u;
             if (!raw) {
-                const uint32_t bh = (last ? 1u : 0u) | (2u << 1) | (csize << 3);
+                const uint32_t bh = last_bit | (2u << 1) | (csize << 3);
                 blk[0] = (uint8_t)bh; blk[1] = (uint8_t)(bh >> 8); blk[2] = (uint8_t)(bh >> 16);
                 piece_len = 3 + csize;
             }
             if (raw) {
-                const uint32_t bh = (last ? 1u : 0u) | (0u << 1) | (n << 3);
+                const uint32_t bh = last_bit | (0u << 1) | (n << 3);
                 blk[0] = (uint8_t)bh; blk[1] = (uint8_t)(bh >> 8); blk[2] = (uint8_t)(bh >> 16);
                 piece_len = 3 + n;
             }
+            if (tail_mark) piece_len += 3;
             if (it.block == 0) {  // frame header in front of block 0: magic, FHD (single segment), FCS
                 uint8_t h[16];
                 uint32_t k = 0;
@@ -1021,6 +1298,10 @@ __global__ __launch_bounds__(64) void k_zstd_encode(EncodeArgs a) {
         }
         __syncthreads();
         if (s_raw) wave_copy(blk + 3, in, n, lane);  // raw block: the input bytes after the header
+        if (tail_mark && lane == 0) {
+            uint8_t *const t = blk + 3 + (s_raw ? n : csize);
+            t[0] = 1; t[1] = 0; t[2] = 0;  // Last_Block, Raw_Block, Block_Size 0
+        }
     }
 }
 
