@@ -250,34 +250,13 @@ __device__ __noinline__ uint8_t *encode_sequences(SH &S, const uint32_t *seqs, u
     return p + ((bitpos + 18 + 7) >> 3);
 }
 
-// Sequences section with per-block FSE tables (RFC 8878 3.1.1.3.2.1: Compression_Modes FSE_Compressed / RLE), the
-// higher effort tier's counterpart of encode_sequences.  tools/enc_model.c puts the predefined distributions at 12 % of
-// the whole output on real text: they price this matcher's offsets (codes 8..16) at 5 bits each.  The wave
-//   * counts the three code alphabets (LDS atomics) and normalises each to 2^tl (tl 6..8 by sequence count; every
-//     present symbol >= 1, the remainder to the most frequent one) — lane = symbol;
-//   * writes the table description with one field per lane: what a symbol's field looks like depends only on the
-//     counts before it (an exclusive scan), and a run of absent symbols is its first member's field plus repeat flags;
-//   * builds the encoding tables: symbol rows from the scan; the state table by walking the spread table 64 cells at a
-//     time (cell -> flat occurrence index through the inverse of the spread step -> symbol by binary search in the
-//     cumulative counts -> rank inside the symbol by ballots);
-//   * runs the same batch loop as encode_sequences with the state tables in LDS.
-// The hash table is dead by now and holds all of it.  p = the Compression_Modes byte; returns the section's end.
-template <class SH>
-__device__ __noinline__ uint8_t *encode_sequences_custom(SH &S, const uint32_t *seqs, uint32_t nseq, uint8_t *p, uint32_t lane) {
-    uint32_t *const W = reinterpret_cast<uint32_t *>(S.table);
-    uint32_t *const ebits = W, *const hist = W + 256;                 // bit window (256 words), 3 x 64 counts (LL, ML, OF)
-    FseSymTT *const tt = reinterpret_cast<FseSymTT *>(W + 448);       // 3 x 64 symbol rows
-    uint16_t *const stt = reinterpret_cast<uint16_t *>(W + 832);      // 3 x 256 states
-    uint32_t *const cum = W + 1216, *const cur = W + 1280, *const hbits = W + 1344;  // 64, 64, 32 words
-    for (uint32_t i = lane; i < 448; i += 64) W[i] = 0;
-    __builtin_amdgcn_wave_barrier();
-    for (uint32_t i = lane; i < nseq; i += 64) {
-        const uint32_t ll = seqs[3 * i], mlb = seqs[3 * i + 1], ov = seqs[3 * i + 2];
-        const uint32_t lc = ll < 64 ? c_ll_code[ll] : (uint32_t)hib(ll) + 19;
-        const uint32_t mc = mlb < 128 ? c_ml_code[mlb] : (uint32_t)hib(mlb) + 36;
-        atomicAdd(&hist[lc], 1u); atomicAdd(&hist[64 + mc], 1u); atomicAdd(&hist[128 + (uint32_t)hib(ov)], 1u);
-    }
-    __builtin_amdgcn_wave_barrier();
+// One FSE table from a histogram, by the wave (lane = symbol, alphabets of at most 64 symbols).  c = the symbol's count
+// (0 = absent; at least two symbols present), total = the sum of the counts, tl = Accuracy_Log (5..8).  Normalises the
+// counts to 2^tl (every present symbol >= 1, the remainder to the most frequent one), writes the table description
+// (RFC 8878 4.1.1) to q and returns its size, and leaves the encoder's tables: symbol rows in tt[0..64), the 2^tl states
+// in stt.  cum, cur (64 words each) and hbits (32 words) are LDS scratch.
+__device__ __noinline__ uint32_t fse_build(uint32_t c, uint32_t total, uint32_t tl, FseSymTT *tt, uint16_t *stt, uint32_t *cum, uint32_t *cur,
+                                           uint32_t *hbits, uint8_t *q, uint32_t lane) {
     auto wsum = [&](uint32_t v) -> uint32_t {
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
@@ -288,28 +267,15 @@ __device__ __noinline__ uint8_t *encode_sequences_custom(SH &S, const uint32_t *
         for (int d = 32; d >= 1; d >>= 1) { const uint32_t o = __shfl_xor(v, d); v = o > v ? o : v; }
         return v;
     };
-    uint32_t tl = (uint32_t)hib(nseq) - 2;
-    tl = tl < 6 ? 6 : (tl > 8 ? 8 : tl);
     const uint32_t ts = 1u << tl, step = (ts >> 1) + (ts >> 3) + 3;
     uint32_t inv = step;  // inverse of the (odd) spread step modulo 2^tl: Newton, 3 -> 6 -> 12 correct bits
     inv *= 2u - step * inv; inv *= 2u - step * inv;
     const uint64_t below = lane ? (~0ull >> (64 - lane)) : 0ull;
-    uint32_t lg[3] = {0, 0, 0}, modes = 0;  // table log per kind (0 = RLE), kinds: 0 LL, 1 ML, 2 OF
-    uint8_t *q = p + 1;
-    for (uint32_t t = 0; t < 3; t++) {  // section order: LL, OF, ML
-        const uint32_t k = t == 0 ? 0u : (t == 1 ? 2u : 1u);
-        const uint32_t c = hist[k * 64 + lane];
-        const uint64_t present = __ballot(c != 0);
-        const uint32_t last = 63u - (uint32_t)__clzll(present);
-        const uint32_t mode_shift = k == 0 ? 6u : (k == 2 ? 4u : 2u);
-        if (__popcll(present) == 1) {  // RLE_Mode: one byte, a table of one state that costs no bits
-            modes |= 1u << mode_shift;
-            if (lane == 0) { *q = (uint8_t)last; tt[k * 64 + last].delta_nb_bits = 0; tt[k * 64 + last].delta_find_state = 0; stt[k * 256] = 0; }
-            q += 1;
-            continue;
-        }
-        modes |= 2u << mode_shift;
-        lg[k] = tl;
+    const uint64_t present = __ballot(c != 0);
+    const uint32_t last = 63u - (uint32_t)__clzll(present);
+    const uint32_t nseq = total;
+    uint32_t nbytes_out = 0;
+    {
         uint32_t norm = c ? (c * ts + (nseq >> 1)) / nseq : 0;
         if (c && !norm) norm = 1;
         const uint32_t sum = wsum(norm);
@@ -344,7 +310,7 @@ __device__ __noinline__ uint8_t *encode_sequences_custom(SH &S, const uint32_t *
                 r.delta_nb_bits = (mbo << 16) - (norm << mbo);
                 r.delta_find_state = (int32_t)excl - (int32_t)norm;
             }
-            tt[k * 64 + lane] = r;
+            tt[lane] = r;
         }
         cum[lane] = incl;
         cur[lane] = excl;
@@ -367,7 +333,7 @@ __device__ __noinline__ uint8_t *encode_sequences_custom(SH &S, const uint32_t *
                 if (lane == l) cur[sl] = b0 + (uint32_t)__popcll(same);
                 todo &= ~same;
             }
-            stt[k * 256 + slot] = (uint16_t)(ts + u);
+            stt[slot] = (uint16_t)(ts + u);
         }
         // table description
         {
@@ -408,11 +374,63 @@ __device__ __noinline__ uint8_t *encode_sequences_custom(SH &S, const uint32_t *
                 if ((uint32_t)(x0 >> 32)) atomicOr(&hbits[w + 1], (uint32_t)(x0 >> 32));
                 if (x1) atomicOr(&hbits[w + 2], x1);
             }
-            const uint32_t total = 4 + rdlane(inc, 63), nbytes = (total + 7) >> 3;
+            const uint32_t tbits = 4 + rdlane(inc, 63), nbytes = (tbits + 7) >> 3;
             __builtin_amdgcn_wave_barrier();
             for (uint32_t i = lane; i < nbytes; i += 64) q[i] = (uint8_t)(hbits[i >> 2] >> (8 * (i & 3)));
-            q += nbytes;
+            nbytes_out = nbytes;
         }
+    }
+    __builtin_amdgcn_wave_barrier();
+    return nbytes_out;
+}
+
+// Sequences section with per-block FSE tables (RFC 8878 3.1.1.3.2.1: Compression_Modes FSE_Compressed / RLE), the
+// higher effort tier's counterpart of encode_sequences.  tools/enc_model.c puts the predefined distributions at 12 % of
+// the whole output on real text: they price this matcher's offsets (codes 8..16) at 5 bits each.  The wave
+//   * counts the three code alphabets (LDS atomics) and normalises each to 2^tl (tl 6..8 by sequence count; every
+//     present symbol >= 1, the remainder to the most frequent one) — lane = symbol;
+//   * writes the table description with one field per lane: what a symbol's field looks like depends only on the
+//     counts before it (an exclusive scan), and a run of absent symbols is its first member's field plus repeat flags;
+//   * builds the encoding tables: symbol rows from the scan; the state table by walking the spread table 64 cells at a
+//     time (cell -> flat occurrence index through the inverse of the spread step -> symbol by binary search in the
+//     cumulative counts -> rank inside the symbol by ballots);
+//   * runs the same batch loop as encode_sequences with the state tables in LDS.
+// The hash table is dead by now and holds all of it.  p = the Compression_Modes byte; returns the section's end.
+template <class SH>
+__device__ __noinline__ uint8_t *encode_sequences_custom(SH &S, const uint32_t *seqs, uint32_t nseq, uint8_t *p, uint32_t lane) {
+    uint32_t *const W = reinterpret_cast<uint32_t *>(S.table);
+    uint32_t *const ebits = W, *const hist = W + 256;                 // bit window (256 words), 3 x 64 counts (LL, ML, OF)
+    FseSymTT *const tt = reinterpret_cast<FseSymTT *>(W + 448);       // 3 x 64 symbol rows
+    uint16_t *const stt = reinterpret_cast<uint16_t *>(W + 832);      // 3 x 256 states
+    uint32_t *const cum = W + 1216, *const cur = W + 1280, *const hbits = W + 1344;  // 64, 64, 32 words
+    for (uint32_t i = lane; i < 448; i += 64) W[i] = 0;
+    __builtin_amdgcn_wave_barrier();
+    for (uint32_t i = lane; i < nseq; i += 64) {
+        const uint32_t ll = seqs[3 * i], mlb = seqs[3 * i + 1], ov = seqs[3 * i + 2];
+        const uint32_t lc = ll < 64 ? c_ll_code[ll] : (uint32_t)hib(ll) + 19;
+        const uint32_t mc = mlb < 128 ? c_ml_code[mlb] : (uint32_t)hib(mlb) + 36;
+        atomicAdd(&hist[lc], 1u); atomicAdd(&hist[64 + mc], 1u); atomicAdd(&hist[128 + (uint32_t)hib(ov)], 1u);
+    }
+    __builtin_amdgcn_wave_barrier();
+    uint32_t tl = (uint32_t)hib(nseq) - 2;
+    tl = tl < 6 ? 6 : (tl > 8 ? 8 : tl);
+    uint32_t lg[3] = {0, 0, 0}, modes = 0;  // table log per kind (0 = RLE), kinds: 0 LL, 1 ML, 2 OF
+    uint8_t *q = p + 1;
+    for (uint32_t t = 0; t < 3; t++) {  // section order: LL, OF, ML
+        const uint32_t k = t == 0 ? 0u : (t == 1 ? 2u : 1u);
+        const uint32_t c = hist[k * 64 + lane];
+        const uint64_t present = __ballot(c != 0);
+        const uint32_t last = 63u - (uint32_t)__clzll(present);
+        const uint32_t mode_shift = k == 0 ? 6u : (k == 2 ? 4u : 2u);
+        if (__popcll(present) == 1) {  // RLE_Mode: one byte, a table of one state that costs no bits
+            modes |= 1u << mode_shift;
+            if (lane == 0) { *q = (uint8_t)last; tt[k * 64 + last].delta_nb_bits = 0; tt[k * 64 + last].delta_find_state = 0; stt[k * 256] = 0; }
+            q += 1;
+            continue;
+        }
+        modes |= 2u << mode_shift;
+        lg[k] = tl;
+        q += fse_build(c, nseq, tl, tt + k * 64, stt + k * 256, cum, cur, hbits, q, lane);
         __builtin_amdgcn_wave_barrier();
     }
     if (lane == 0) *p = (uint8_t)modes;
@@ -705,6 +723,259 @@ __device__ __forceinline__ uint32_t huf_literals(SH &S, const uint8_t *lits, uin
             const uint32_t wa = la ? L + 1 - la : 0, wb = lb ? L + 1 - lb : 0;
             dst[hdr + 1 + i] = (uint8_t)((wa << 4) | wb);
         }
+    }
+    uint8_t *d = dst + hdr + tree_bytes;
+    if (nstreams == 4) {
+        if (lane == 0) {
+            d[0] = (uint8_t)ssz[0]; d[1] = (uint8_t)(ssz[0] >> 8);
+            d[2] = (uint8_t)ssz[1]; d[3] = (uint8_t)(ssz[1] >> 8);
+            d[4] = (uint8_t)ssz[2]; d[5] = (uint8_t)(ssz[2] >> 8);
+        }
+        d += 6;
+    }
+    wave_copy(d, tmp, streams_bytes, lane);  // moves down over the raw literals: ranges do not overlap (comp < n)
+    return hdr + comp;
+}
+
+// The higher effort tier's Huffman literals: huf_literals for any alphabet.  A lane owns four symbols (lane, +64,
+// +128, +192); a tree whose highest symbol is beyond 127 cannot be described by direct 4-bit weights and goes out as
+// FSE-compressed weights (RFC 8878 4.2.1.2): the weights of symbols 0 .. last-1 coded with one table of Accuracy_Log 6
+// (fse_build) by two interleaved states, even positions on the first — lane 0 walks the at most 255 weights backwards.
+// Binaries' literals are such alphabets; the fast tier leaves them raw.
+template <class SH>
+__device__ __forceinline__ uint32_t huf_literals_any(SH &S, const uint8_t *lits, uint32_t n, uint8_t *tmp, uint8_t *dst, uint32_t lane) {
+    uint32_t *const T = reinterpret_cast<uint32_t *>(S.table);  // the hash table is dead: hist | codes | bit window | weight coder
+    uint32_t *const hist = T, *const codes = T + 256, *const win = T + 512;
+    FseSymTT *const wtt = reinterpret_cast<FseSymTT *>(T + 640);    // 64 rows
+    uint16_t *const wstt = reinterpret_cast<uint16_t *>(T + 768);   // 64 states (room for 256)
+    uint32_t *const cum = T + 896, *const cur = T + 960, *const hbits = T + 1024, *const whist = T + 1120;
+    uint8_t *const wbuf = reinterpret_cast<uint8_t *>(T + 1056);    // 256 bytes: the compressed weights
+    for (uint32_t i = lane; i < 512 + 128; i += 64) T[i] = 0;
+    if (lane < 16) whist[lane] = 0;
+    __builtin_amdgcn_wave_barrier();
+    for (uint32_t i = lane * 4; i < n; i += 256) {
+        if (i + 4 <= n) {
+            const uint32_t v = ld32(lits + i);
+            atomicAdd(&hist[v & 0xFF], 1u); atomicAdd(&hist[(v >> 8) & 0xFF], 1u);
+            atomicAdd(&hist[(v >> 16) & 0xFF], 1u); atomicAdd(&hist[v >> 24], 1u);
+        } else
+            for (uint32_t k = i; k < n; k++) atomicAdd(&hist[lits[k]], 1u);
+    }
+    __builtin_amdgcn_wave_barrier();
+    uint32_t c[4], l[4];
+    uint64_t pm[4];
+    uint32_t nsym = 0, last = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        c[j] = hist[lane + 64 * j];
+        pm[j] = __ballot(c[j] != 0);
+        nsym += (uint32_t)__popcll(pm[j]);
+        if (pm[j]) last = 64 * j + 63 - (uint32_t)__clzll(pm[j]);
+    }
+    if (nsym < 2) return 0;
+    auto wsum = [&](uint32_t v) -> uint32_t {
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
+        return v;
+    };
+    auto wmin = [&](uint32_t v) -> uint32_t {
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) { const uint32_t o = __shfl_xor(v, d); v = o < v ? o : v; }
+        return v;
+    };
+    auto wmax = [&](uint32_t v) -> uint32_t {
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) { const uint32_t o = __shfl_xor(v, d); v = o > v ? o : v; }
+        return v;
+    };
+    const uint32_t FULL = 1u << HUF_MAX_BITS;
+    auto kraft = [&]() -> uint32_t {
+        uint32_t k = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) k += l[j] ? FULL >> l[j] : 0;
+        return wsum(k);
+    };
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        uint32_t len = 0;
+        if (c[j]) { len = 1; while (len < HUF_MAX_BITS && ((uint64_t)c[j] << len) < n) len++; }
+        l[j] = len;
+    }
+    uint32_t K = kraft();
+    // over-subscribed (only through the 11-bit clamp): lengthen the rarest symbol that still can be
+    for (uint32_t guard = 0; K > FULL && guard < 4096; guard++) {
+        uint32_t key = 0xFFFFFFFFu;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const uint32_t kj = (l[j] && l[j] < HUF_MAX_BITS) ? (c[j] << 8) | (lane + 64 * j) : 0xFFFFFFFFu;
+            key = kj < key ? kj : key;
+        }
+        const uint32_t best = wmin(key);
+        if (best == 0xFFFFFFFFu) return 0;
+        const uint32_t sym = best & 0xFF;
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+            if (sym == lane + 64 * j) l[j]++;
+        K = kraft();
+    }
+    if (K > FULL) return 0;
+    // under-subscribed: shorten the most frequent symbol whose gain still fits the gap
+    for (uint32_t guard = 0; K < FULL && guard < 4096; guard++) {
+        const uint32_t gap = FULL - K;
+        uint32_t key = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const uint32_t kj = (l[j] > 1 && (FULL >> l[j]) <= gap) ? (c[j] << 8) | (lane + 64 * j) : 0;
+            key = kj > key ? kj : key;
+        }
+        const uint32_t best = wmax(key);
+        if (!best) return 0;
+        const uint32_t sym = best & 0xFF;
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+            if (sym == lane + 64 * j && c[j] == best >> 8) l[j]--;
+        K = kraft();
+    }
+    if (K != FULL) return 0;
+    uint32_t lm = 0, pay = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) { lm = l[j] > lm ? l[j] : lm; pay += c[j] * l[j]; }
+    const uint32_t L = wmax(lm);  // table log; weight = L + 1 - length
+    uint32_t w[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) w[j] = l[j] ? L + 1 - l[j] : 0;
+    const uint32_t pay_bits = wsum(pay);
+    const uint32_t nstreams = n < 1024 ? 1u : 4u;
+    if (16 + (nstreams == 4 ? 6u : 0u) + (pay_bits + 7) / 8 + nstreams + 5 + (n >> 6) >= n) return 0;  // not worth a Huffman stage on the decode side
+    // canonical codes: positions in the 2^L table by (weight, symbol) order; code = position >> (weight - 1)
+    uint32_t base = 0, code[4] = {0, 0, 0, 0};
+    const uint64_t below = lane ? (~0ull >> (64 - lane)) : 0ull;
+    for (uint32_t ww = 1; ww <= L; ww++) {
+        uint32_t before = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const uint64_t m = __ballot(w[j] == ww);
+            if (w[j] == ww) code[j] = (base >> (ww - 1)) + before + (uint32_t)__popcll(m & below);
+            before += (uint32_t)__popcll(m);
+        }
+        base += before << (ww - 1);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; j++) codes[lane + 64 * j] = code[j] | (l[j] << 16);
+    // ---- tree description ----
+    uint32_t tree_bytes;
+    const bool direct = last < 128;
+    if (direct) tree_bytes = 1 + (last + 1) / 2;
+    else {
+        // weights of symbols 0 .. last-1 (the last one is implied), FSE-compressed
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+            if (lane + 64 * j < last) atomicAdd(&whist[w[j]], 1u);
+        __builtin_amdgcn_wave_barrier();
+        const uint32_t wc = lane < 16 ? whist[lane] : 0;
+        if (__popcll(__ballot(wc != 0)) < 2) return 0;  // one weight only: no table can say that (and no gain to expect)
+        const uint32_t nc = fse_build(wc, last, 6, wtt, wstt, cum, cur, hbits, wbuf + 1, lane);
+        uint32_t wlen = 0;
+        if (lane == 0) {
+            BitW b{wbuf + 1 + nc, 0, 0};
+            CState s1, s2;
+            bool have1 = false, have2 = false;
+            for (int32_t i = (int32_t)last - 1; i >= 0; i--) {
+                const uint32_t len = codes[i] >> 16, wt = len ? L + 1 - len : 0;
+                if (i & 1) {
+                    if (!have2) { s2.init(wstt, wtt, 6, wt); have2 = true; } else s2.encode(b, wt);
+                } else {
+                    if (!have1) { s1.init(wstt, wtt, 6, wt); have1 = true; } else s1.encode(b, wt);
+                }
+            }
+            s2.flush(b);
+            s1.flush(b);
+            wlen = (uint32_t)(b.close() - (wbuf + 1));
+            wbuf[0] = (uint8_t)wlen;
+        }
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // lane 0's stores into wbuf (possibly FLAT) before the ds reads below
+        wlen = suni(wlen);
+        if (wlen >= 128 || wlen + 1 > 250) return 0;  // the header byte of compressed weights is their size, below 128
+        tree_bytes = 1 + wlen;
+    }
+    __builtin_amdgcn_wave_barrier();
+    // ---- streams into tmp ----
+    const uint32_t seg = (n + 3) / 4;
+    uint32_t ssz[4] = {0, 0, 0, 0};
+    uint8_t *q = tmp;
+    for (uint32_t st = 0; st < nstreams; st++) {
+        const uint32_t a = nstreams == 1 ? 0 : st * seg;
+        const uint32_t b = nstreams == 1 ? n : (st == 3 ? n : a + seg);
+        uint8_t *const q0 = q;
+        uint32_t bitpos = 0;
+        for (uint32_t e0 = 0; e0 < b - a; e0 += 64) {
+            const uint32_t idx = e0 + lane;
+            uint32_t cd = 0, ln = 0;
+            if (idx < b - a) {
+                const uint32_t cw = codes[lits[b - 1 - idx]];  // last symbol first
+                cd = cw & 0xFFFF; ln = cw >> 16;
+            }
+            uint32_t inc = ln;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const uint32_t y = __shfl_up(inc, d);
+                if (lane >= (uint32_t)d) inc += y;
+            }
+            const uint32_t pos = bitpos + inc - ln;
+            if (ln) {
+                const uint64_t x = (uint64_t)cd << (pos & 31);
+                atomicOr(&win[pos >> 5], (uint32_t)x);
+                if (x >> 32) atomicOr(&win[(pos >> 5) + 1], (uint32_t)(x >> 32));
+            }
+            bitpos = suni(bitpos + __shfl(inc, 63));
+            __builtin_amdgcn_wave_barrier();
+            const uint32_t ndw = bitpos >> 5;
+            if (lane < ndw) {
+                const uint32_t wv = win[lane];
+                __builtin_memcpy(q + 4 * lane, &wv, 4);
+            }
+            const uint32_t keep = win[ndw];
+            __builtin_amdgcn_wave_barrier();
+            if (lane <= ndw) win[lane] = 0;
+            __builtin_amdgcn_wave_barrier();
+            if (lane == 0) win[0] = keep;
+            __builtin_amdgcn_wave_barrier();
+            q += 4 * ndw;
+            bitpos &= 31;
+        }
+        const uint32_t tail_bits = bitpos + 1, tail_bytes = (tail_bits + 7) >> 3;
+        if (lane == 0) {
+            const uint64_t acc = (uint64_t)win[0] | (1ull << bitpos);
+            for (uint32_t k = 0; k < tail_bytes; k++) q[k] = (uint8_t)(acc >> (8 * k));
+            win[0] = 0;
+        }
+        __builtin_amdgcn_wave_barrier();
+        q += tail_bytes;
+        ssz[st] = (uint32_t)(q - q0);
+    }
+    const uint32_t streams_bytes = (uint32_t)(q - tmp);
+    const uint32_t comp = tree_bytes + (nstreams == 4 ? 6u : 0u) + streams_bytes;
+    uint32_t sf, hdr;
+    if (nstreams == 1) { sf = 0; hdr = 3; if (comp > 1023) return 0; }
+    else if (n <= 16383 && comp <= 16383) { sf = 2; hdr = 4; }
+    else { sf = 3; hdr = 5; }
+    if (hdr + comp + (n >> 6) >= 3 + n || (nstreams == 4 && (ssz[0] > 65535 || ssz[1] > 65535 || ssz[2] > 65535))) return 0;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the streams in tmp have landed before they are moved
+    if (lane == 0) {
+        const uint32_t nb = sf == 0 ? 10u : (sf == 2 ? 14u : 18u);
+        const uint64_t h = 2ull | ((uint64_t)sf << 2) | ((uint64_t)n << 4) | ((uint64_t)comp << (4 + nb));
+        for (uint32_t k = 0; k < hdr; k++) dst[k] = (uint8_t)(h >> (8 * k));
+        if (direct) dst[hdr] = (uint8_t)(127 + last);  // direct weights for symbols 0 .. last-1, the last one is implied
+    }
+    if (direct) {
+        const uint32_t nbytes = (last + 1) / 2;  // weight nibbles: byte i = weight[2i] << 4 | weight[2i+1]
+        for (uint32_t i = lane; i < nbytes; i += 64) {
+            const uint32_t la = codes[2 * i] >> 16, lb = (2 * i + 1 < last) ? codes[2 * i + 1] >> 16 : 0;
+            const uint32_t wa = la ? L + 1 - la : 0, wb = lb ? L + 1 - lb : 0;
+            dst[hdr + 1 + i] = (uint8_t)((wa << 4) | wb);
+        }
+    } else {
+        for (uint32_t i = lane; i < tree_bytes; i += 64) dst[hdr + i] = wbuf[i];
     }
     uint8_t *d = dst + hdr + tree_bytes;
     if (nstreams == 4) {
@@ -1198,7 +1469,9 @@ __global__ __launch_bounds__(64) void k_zstd_encode(EncodeArgs a) {
         ESTAMP(2);
         // ---- entropy stage: literals (Huffman in the wide variant when it pays), headers, sequences bitstream ----
         uint32_t lit_sec = 0;  // bytes of the literals section at blk + 3
-        if (HASH_LOG == 13 && lit_total >= HUF_MIN_LITS && !gave_up)
+        if (HIGH && lit_total >= HUF_MIN_LITS && !gave_up)
+            lit_sec = huf_literals_any(S, lits, lit_total, lits + ((lit_total + 3) & ~3u), blk + 3, lane);
+        else if (HASH_LOG == 13 && lit_total >= HUF_MIN_LITS && !gave_up)
             lit_sec = huf_literals(S, lits, lit_total, lits + ((lit_total + 3) & ~3u), blk + 3, lane);
         ESTAMP(3);
         bool raw = nseq == 0 && lit_sec == 0;
