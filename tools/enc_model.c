@@ -34,7 +34,7 @@ static double huf_cost_bits(const uint32_t *hist, uint32_t n, int optimal, int *
     for (int i = 0; i < 256; i++) if (hist[i]) { nsym++; maxsym = i; }
     *nsym_out = nsym; *maxsym_out = maxsym;
     if (nsym < 2) return 1e18;
-    if (optimal) {
+    if (optimal == 1) {
         // plain O(n^2) Huffman
         static uint64_t w[512]; static int par[512]; static int alive[512];
         int cnt = 0, idx[256];
@@ -46,6 +46,14 @@ static double huf_cost_bits(const uint32_t *hist, uint32_t n, int optimal, int *
             w[total] = w[a] + w[b]; alive[total] = 1; par[total] = -1; alive[a] = alive[b] = 0; par[a] = par[b] = total; total++;
         }
         for (int i = 0; i < cnt; i++) { int d = 0, k = i; while (par[k] >= 0) { k = par[k]; d++; } len[idx[i]] = d > 11 ? 11 : d; }
+    } else if (optimal == 2) {
+        // rounded Shannon lengths, then repair by cost per unit of Kraft sum: lengthen where count << len is smallest, shorten where it is largest
+        for (int i = 0; i < 256; i++) if (hist[i]) { double l = log2((double)n / hist[i]); int r = (int)(l + 0.5); len[i] = r < 1 ? 1 : (r > 11 ? 11 : r); }
+        long K = 0; for (int i = 0; i < 256; i++) if (len[i]) K += 2048 >> len[i];
+        while (K > 2048) { int best = -1; for (int i = 0; i < 256; i++) if (len[i] && len[i] < 11 && (best < 0 || ((uint64_t)hist[i] << len[i]) < ((uint64_t)hist[best] << len[best]))) best = i; if (best < 0) return 1e18; K -= 2048 >> len[best]; len[best]++; K += 2048 >> len[best]; }
+        while (K < 2048) { long gap = 2048 - K; int best = -1; for (int i = 0; i < 256; i++) if (len[i] > 1 && (2048 >> len[i]) <= gap && (best < 0 || ((uint64_t)hist[i] << len[i]) > ((uint64_t)hist[best] << len[best]))) best = i; if (best < 0) break; K += 2048 >> len[best]; len[best]--; }
+        double bits = 0; for (int i = 0; i < 256; i++) bits += (double)hist[i] * len[i];
+        return bits;
     } else {
         for (int i = 0; i < 256; i++) if (hist[i]) { int l = 1; while (l < 11 && ((uint64_t)hist[i] << l) < n) l++; len[i] = l; }
     }
