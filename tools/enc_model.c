@@ -83,8 +83,8 @@ static double norm_cost(const uint32_t *h, int nsym, uint32_t total, int tl) {
 static double block_cost(const uint8_t *in, uint32_t n, const Opt *o, double *lit_bytes, double *seq_bytes, uint32_t *nseq_out, uint32_t *nrep_out) {
     const uint32_t HS = 1u << o->hash_log;
     static int32_t *tab = NULL; static Seq *seqs = NULL; static uint8_t *lits = NULL;
-    if (!tab) { tab = malloc(sizeof(int32_t) * 4 * (1 << 17)); seqs = malloc(sizeof(Seq) * 70000); lits = malloc(1 << 18); }
-    for (uint32_t i = 0; i < HS * 4; i++) tab[i] = -1;
+    if (!tab) { tab = malloc(sizeof(int32_t) * 8 * (1 << 17)); seqs = malloc(sizeof(Seq) * 70000); lits = malloc(1 << 18); }
+    for (uint32_t i = 0; i < HS * 8; i++) tab[i] = -1;
     uint32_t nseq = 0, nlit = 0, anchor = 0, base = 0, nrep = 0;
     const uint32_t scan_end = n >= 8 ? n - 7 : 0;
     uint32_t rep[3] = {0, 0, 0};  // 0 = unknown at block start (blocks are encoded independently)
@@ -98,7 +98,7 @@ static double block_cost(const uint8_t *in, uint32_t n, const Opt *o, double *li
             const uint32_t h = hsh(in + pos, o);
             uint32_t best = 0, bc = 0;
             for (int w = 0; w < o->ways; w++) {
-                const int32_t c = tab[h * 4 + w];
+                const int32_t c = tab[h * 8 + w];
                 if (c < 0) continue;
                 uint32_t cv; memcpy(&cv, in + c, 4);
                 if (cv != v) continue;
@@ -112,8 +112,8 @@ static double block_cost(const uint8_t *in, uint32_t n, const Opt *o, double *li
             const uint32_t pos = base + l;
             if (pos >= scan_end) continue;
             const uint32_t h = hsh(in + pos, o);
-            for (int w = o->ways - 1; w > 0; w--) tab[h * 4 + w] = tab[h * 4 + w - 1];
-            tab[h * 4] = (int32_t)pos;
+            for (int w = o->ways - 1; w > 0; w--) tab[h * 8 + w] = tab[h * 8 + w - 1];
+            tab[h * 8] = (int32_t)pos;
         }
         // pick left to right
         for (;;) {

@@ -999,7 +999,7 @@ __device__ __forceinline__ uint32_t huf_literals_any(SH &S, const uint8_t *lits,
 
 // One wave encodes one block item pulled from the atomic cursor.  HASH_LOG 11 (4 KiB table, more
 // resident waves) serves batches of small rounds, 13 serves 128 KiB blocks.
-// HIGH (with HASH_LOG 13 only) is the higher effort tier (levels >= HIGH_TIER_LEVEL): 4-way buckets, one-step lazy
+// HIGH (with HASH_LOG 13 only) is the higher effort tier (levels >= HIGH_TIER_LEVEL): 8-way buckets, one-step lazy
 // choice, a cost gate on short far matches, in-block repeat offsets.
 template <uint32_t HASH_LOG, bool HIGH = false>
 __global__ __launch_bounds__(64) void k_zstd_encode(EncodeArgs a) {
@@ -1093,15 +1093,15 @@ __global__ __launch_bounds__(64) void k_zstd_encode(EncodeArgs a) {
         if constexpr (HIGH) {
             // Higher effort tier of the wide variant.  Same shape (every lane probes its position and extends its own
             // candidates, the window's matches are then picked left to right), with what tools/enc_model.c showed to pay:
-            //   * 2^11 buckets x 4 ways in the same 16 KiB (one 8-byte LDS word per bucket, newest first): associativity
-            //     beats table size on text and binaries alike;
+            //   * 2^10 buckets x 8 ways in the same 16 KiB (one 16-byte LDS word per bucket, newest first): associativity
+            //     beats table size on text and binaries alike (2^13 x 1 -> 2^11 x 4 -> 2^10 x 8: 0.297, 0.282, 0.279 in the model);
             //   * a candidate at the repeat offset of the window's start, preferred when it is within a byte of the best;
             //   * a gate on short far matches (4 bytes beyond 2 KiB, 5 beyond 32 KiB cost more than their literals);
             //   * one-step lazy choice (the next position's match wins when it is two bytes longer);
             //   * offsets equal to one of the block's last three go out as repeat codes.  The history starts unknown
             //     (0): blocks are encoded independently, so a code is only used once this block has defined its entry.
             constexpr uint32_t LMAX = 64;
-            uint2 *const B = reinterpret_cast<uint2 *>(S.table);
+            uint4 *const B = reinterpret_cast<uint4 *>(S.table);
             uint32_t r0 = 0, r1 = 0, r2 = 0;
             while (base < scan_end && nseq < max_seq) {
                 const uint32_t pos = base + lane;
@@ -1135,13 +1135,13 @@ __global__ __launch_bounds__(64) void k_zstd_encode(EncodeArgs a) {
                 const uint32_t r0w = r0;
                 if (pos < scan_end) {
                     v = ld32(inb + pos);
-                    const uint32_t h = hash4<11>(v);
-                    const uint2 b = B[h];
-                    B[h] = make_uint2((b.x << 16) | (pos & 0xFFFFu), (b.y << 16) | (b.x >> 16));
-                    uint32_t c[4] = {b.x & 0xFFFFu, b.x >> 16, b.y & 0xFFFFu, b.y >> 16};
-                    uint32_t cv[4];
+                    const uint32_t h = hash4<10>(v);
+                    const uint4 b = B[h];
+                    B[h] = make_uint4((b.x << 16) | (pos & 0xFFFFu), (b.y << 16) | (b.x >> 16), (b.z << 16) | (b.y >> 16), (b.w << 16) | (b.z >> 16));
+                    uint32_t c[8] = {b.x & 0xFFFFu, b.x >> 16, b.y & 0xFFFFu, b.y >> 16, b.z & 0xFFFFu, b.z >> 16, b.w & 0xFFFFu, b.w >> 16};
+                    uint32_t cv[8];
 #pragma unroll
-                    for (int w = 0; w < 4; w++) {
+                    for (int w = 0; w < 8; w++) {
                         const bool have = c[w] != 0xFFFFu;
                         c[w] |= pos & ~0xFFFFu;
                         if (c[w] >= pos) c[w] -= 0x10000u;  // wraps to a huge value when there is no earlier half
@@ -1149,7 +1149,7 @@ __global__ __launch_bounds__(64) void k_zstd_encode(EncodeArgs a) {
                         cv[w] = c[w] != 0xFFFFFFFFu ? ld32(inb + c[w]) : ~v;
                     }
 #pragma unroll
-                    for (int w = 0; w < 4; w++)
+                    for (int w = 0; w < 8; w++)
                         if (cv[w] == v && c[w] != 0xFFFFFFFFu) {
                             const uint32_t k = extend(c[w]);
                             if (k > mlen) { mlen = k; cand = c[w]; }  // ties stay with the newer (closer) one
