@@ -12,6 +12,9 @@ class OracleBackend:
         self.level = level
         self.n_threads = n_threads
 
+    def set_level(self, level):  # the double keeps its own (cheap) libzstd level: host logic does not depend on it
+        pass
+
     def encode_hash(self, staging, off, length, skip):
         if len(off) == 0:
             return dict(blob_offset=np.zeros(0, np.uint64), blob_size=np.zeros(0, np.uint64),

@@ -15,6 +15,10 @@ class HipBackend:
         self.device = torch.cuda.current_device() if device is None else device
         self.ctx = ctx or hip.Context(self.device)
 
+    def set_level(self, level):
+        """CompressCtx::new(compression_level), codec.rs:L16-28."""
+        self.ctx.set_level(level)
+
     def _to_dev(self, a):
         t = self.torch.from_numpy(np.ascontiguousarray(a))
         return t.to(f"cuda:{self.device}", non_blocking=False)

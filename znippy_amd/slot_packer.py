@@ -27,6 +27,7 @@ def compress_dir(input_dir, output, no_skip: bool = False, plugin=None, repo: Op
     from .backend import default_backend
     backend = backend or default_backend()
     config = config or ix.CONFIG
+    backend.set_level(config.compression_level)  # CompressCtx::new(CONFIG.compression_level), stream_packer.rs:L217 / slot_packer.rs:L551
     input_dir = str(input_dir)
     total_dirs = 0
     all_files = []

@@ -133,6 +133,7 @@ def run_pipeline(entries, output, no_skip, backend=None, config=None) -> ix.Comp
     from .sharding import split_rows
     backend = backend or default_backend()
     config = config or ix.CONFIG
+    backend.set_level(config.compression_level)  # CompressCtx::new(CONFIG.compression_level), stream_packer.rs:L217 / slot_packer.rs:L551
     output_path = with_extension(output, "znippy")  # L132
     rounds, (uf, ub, cf, cb) = plan_rounds(entries, no_skip)
     rank, world = 0, 1
