@@ -128,6 +128,10 @@ static double block_cost(const uint8_t *in, uint32_t n, const Opt *o, double *li
                     uint32_t a, b; memcpy(&a, in + pos, 4); memcpy(&b, in + pos - rep[0], 4);
                     if (a == b) { rl = 4; while (pos + rl < n && in[pos + rl] == in[pos - rep[0] + rl]) rl++; }
                 }
+                if (o->rep >= 2) for (int ri = 1; ri < 3; ri++) if (rep[ri] && pos >= rep[ri]) {  // older history entries as ordinary candidates
+                    uint32_t a, b; memcpy(&a, in + pos, 4); memcpy(&b, in + pos - rep[ri], 4);
+                    if (a == b) { uint32_t k = 4; while (pos + k < n && k < 64 && in[pos + k] == in[pos - rep[ri] + k]) k++; if (k + 1 >= mlen[l] && k > rl) { mlen[l] = k; cand[l] = pos - rep[ri]; } }
+                }
                 crep[l] = rl;
                 uint32_t m = mlen[l];
                 if (m && o->gate) {  // cost gate: short far matches lose to literals
@@ -232,7 +236,7 @@ int main(int argc, char **argv) {
         struct stat st;
         if (lstat(g.gl_pathv[f], &st) || !S_ISREG(st.st_mode) || st.st_size == 0) continue;
         FILE *fp = fopen(g.gl_pathv[f], "rb"); if (!fp) continue;
-        uint8_t *b = malloc(st.st_size + 64); size_t got = fread(b, 1, st.st_size, fp); fclose(fp);
+        size_t want = st.st_size; if (tot_in + want > cap) want = (size_t)(cap - tot_in) + 1; uint8_t *b = malloc(want + 64); size_t got = fread(b, 1, want, fp); fclose(fp);
         memset(b + got, 0, 64);
         for (size_t r = 0; r < got; r += 8u << 20) {  // rounds of 8 MiB, blocks of 128 KiB
             const size_t rl = got - r < (8u << 20) ? got - r : (8u << 20);

@@ -1095,7 +1095,7 @@ __global__ __launch_bounds__(64) void k_zstd_encode(EncodeArgs a) {
             // candidates, the window's matches are then picked left to right), with what tools/enc_model.c showed to pay:
             //   * 2^10 buckets x 8 ways in the same 16 KiB (one 16-byte LDS word per bucket, newest first): associativity
             //     beats table size on text and binaries alike (2^13 x 1 -> 2^11 x 4 -> 2^10 x 8: 0.297, 0.282, 0.279 in the model);
-            //   * a candidate at the repeat offset of the window's start, preferred when it is within a byte of the best;
+            //   * candidates at the three repeat offsets of the window's start, preferred when within a byte of the best;
             //   * a gate on short far matches (4 bytes beyond 2 KiB, 5 beyond 32 KiB cost more than their literals);
             //   * one-step lazy choice (the next position's match wins when it is two bytes longer);
             //   * offsets equal to one of the block's last three go out as repeat codes.  The history starts unknown
@@ -1132,7 +1132,7 @@ __global__ __launch_bounds__(64) void k_zstd_encode(EncodeArgs a) {
                     while (open && k < lim && inb[pos + k] == inb[c + k]) k++;
                     return k;
                 };
-                const uint32_t r0w = r0;
+                const uint32_t r0w = r0, r1w = r1, r2w = r2;  // the history at the window's start
                 if (pos < scan_end) {
                     v = ld32(inb + pos);
                     const uint32_t h = hash4<10>(v);
@@ -1158,9 +1158,15 @@ __global__ __launch_bounds__(64) void k_zstd_encode(EncodeArgs a) {
                         const uint32_t off = pos - cand;
                         if ((mlen == 4 && off > 2048u) || (mlen == 5 && off > 32768u)) mlen = 0;
                     }
-                    if (r0w && pos >= r0w && ld32(inb + pos - r0w) == v) {
-                        const uint32_t k = extend(pos - r0w);
-                        if (k + 1 >= mlen) { mlen = k; cand = pos - r0w; }
+                    {   // the three offsets of the history as candidates: a repeat code is worth a byte of match length
+                        uint32_t score = mlen;
+                        const uint32_t rw[3] = {r0w, r1w, r2w};
+#pragma unroll
+                        for (int i = 0; i < 3; i++)
+                            if (rw[i] && pos >= rw[i] && ld32(inb + pos - rw[i]) == v) {
+                                const uint32_t k = extend(pos - rw[i]);
+                                if (k + 1 > score || (i == 0 && k + 1 >= score)) { score = k + 1; mlen = k; cand = pos - rw[i]; }
+                            }
                     }
                     if (mlen && cand >= 8) {  // bytes in front of the match that agree too (up to 8): literals it can take over
                         uint64_t x, y;
