@@ -1401,7 +1401,7 @@ extern "C" int znippy_encode_hash_rounds_async(znippy_ctx *ctx, znippy_rounds *r
     a.src = (const uint8_t *)d_src; a.src_off = r->src_off; a.len = r->len;
     a.prov = ctx->enc_prov; a.seq_scratch = ctx->enc_seq;
     a.piece_len = r->piece_len; a.piece_start = r->piece_start; a.tabs = ctx->enc_tabs;
-    a.tail_mark = ctx->level >= HIGH_TIER_LEVEL;
+    a.tail_mark = a.high = ctx->level >= HIGH_TIER_LEVEL;
     if (ctx->sw.edbg) {  // diagnostic: phase shares of the previous run's wide-variant blocks
         static unsigned long long *dbg = nullptr;
         if (!dbg) { (void)hipMalloc(&dbg, 64); (void)hipMemset(dbg, 0, 64); }

@@ -55,6 +55,7 @@ struct EncodeArgs {
     uint64_t *piece_start;  // offset in prov where the finished piece begins
     const EncTables *tabs;
     int tail_mark;  // higher effort tier: frames of several blocks end with an empty raw block (zstd_encode.hip)
+    int high;       // higher effort tier: the small variant keeps only blocks of the periodic shape
 };
 
 struct GatherArgs {

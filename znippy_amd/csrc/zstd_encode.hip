@@ -1140,9 +1140,10 @@ __global__ __launch_bounds__(64) void k_zstd_encode(EncodeArgs a) {
                     B[h] = make_uint4((b.x << 16) | (pos & 0xFFFFu), (b.y << 16) | (b.x >> 16), (b.z << 16) | (b.y >> 16), (b.w << 16) | (b.z >> 16));
                     uint32_t c[8] = {b.x & 0xFFFFu, b.x >> 16, b.y & 0xFFFFu, b.y >> 16, b.z & 0xFFFFu, b.z >> 16, b.w & 0xFFFFu, b.w >> 16};
                     uint32_t cv[8];
+                    const int nways = misses >= 8 ? 2 : 8;  // eight windows without one repeat: incompressible so far, probe lightly
 #pragma unroll
                     for (int w = 0; w < 8; w++) {
-                        const bool have = c[w] != 0xFFFFu;
+                        const bool have = c[w] != 0xFFFFu && w < nways;
                         c[w] |= pos & ~0xFFFFu;
                         if (c[w] >= pos) c[w] -= 0x10000u;  // wraps to a huge value when there is no earlier half
                         if (!have || c[w] >= pos) c[w] = 0xFFFFFFFFu;
@@ -1477,9 +1478,14 @@ __global__ __launch_bounds__(64) void k_zstd_encode(EncodeArgs a) {
                 base = anchor;
             }
         }
-        if (HASH_LOG == 11 && a.retry_list && nseq >= max_seq && base < scan_end) {
+        if (HASH_LOG == 11 && a.retry_list &&
+            ((nseq >= max_seq && base < scan_end) || (a.high && (nseq > 8 || lit_total + (nq - anchor) >= HUF_MIN_LITS)))) {
             // Sequence budget spent before the end of the block: this is not periodic data.  Hand the block to the
             // wide variant (denser matcher, Huffman literals, parallel bitstream) instead of emitting the rest raw.
+            // The higher effort tier hands over everything that is not the periodic shape this variant is for (a handful
+            // of sequences, few literals): on real text two thirds of the rounds are below 16 KiB and never spend the
+            // budget — one match per window, raw literals — and cost 7 % of the corpus against libzstd -1
+            // (tools/ratio_by_size.py: rounds of 4-16 KiB at 0.57 here, 0.27 there).
             if (lane == 0) a.retry_list[atomicAdd(a.retry_count, 1u)] = item_id;
             continue;
         }
