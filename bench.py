@@ -348,6 +348,7 @@ def main():
                                  "ms_per_step": round(dt_own / args.steps * 1e3, 4),
                                  "blob_bytes_per_gpu": int(own["bs"].sum()),
                                  "kernel_ms": {k: round(v, 4) for k, v in k_own.items()}},
+            "compress_level": int(ctx.level),  # CONFIG.compression_level = 19 unless ZNIPPY_LEVEL says otherwise: the higher effort tier
             "compress_MBps": round(mbps(dt_write), 1),
             "compress_ms_per_step": round(dt_write / args.steps * 1e3, 4),
             "compress_kernel_ms": {k: round(v, 4) for k, v in k_write.items()},
