@@ -108,6 +108,35 @@ def _rle_records(n_rec, seed):
     return bytes(buf)
 
 
+def _varied(n_rec, seed, max_fresh=40, max_copy=60, alphabet=256):
+    """Records with literal runs of 0..max_fresh bytes and copies of 4..max_copy bytes from random earlier places: many
+    literal-length, match-length and offset codes with small counts each — what the normalisation of the per-block
+    tables has to squeeze into 64..256 cells — over a byte alphabet of the given size."""
+    rng = np.random.default_rng(seed)
+    buf = bytearray(rng.integers(0, alphabet, 64, dtype=np.uint8).tobytes())
+    for _ in range(n_rec):
+        buf += rng.integers(0, alphabet, int(rng.integers(0, max_fresh + 1)), dtype=np.uint8).tobytes()
+        ln = int(rng.integers(4, max_copy + 1))
+        src = int(rng.integers(0, max(1, len(buf) - ln)))
+        buf += buf[src:src + ln]
+    return bytes(buf)
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_many_codes_with_small_counts(ctxs, oracle, seed):
+    """Table normalisation under pressure (more symbols than a 64-cell table has room to round generously), Huffman
+    trees of every alphabet size, both on the higher tier; three decoders judge every frame."""
+    fast, high = ctxs
+    rng = np.random.default_rng(1000 + seed)
+    n_rec = int(rng.choice([130, 200, 400, 700, 1500, 4000, 12000]))
+    alphabet = int(rng.choice([2, 5, 17, 64, 127, 129, 200, 256]))
+    data = _varied(n_rec, seed, max_fresh=int(rng.choice([3, 20, 40, 90])), max_copy=int(rng.choice([8, 30, 60, 200])), alphabet=alphabet)
+    for ctx in (high, fast):
+        frame = ctx.compress(data)
+        _three_decoders(oracle, ctx, frame, data)
+    assert len(high.compress(data)) <= len(fast.compress(data)) + 16
+
+
 def test_level_is_part_of_the_context(ctxs):
     from znippy_amd import hip
     from znippy_amd._lib import ZnippyError
