@@ -50,6 +50,7 @@ struct znippy_ctx {
     size_t shim_in_cap = 0, shim_out_cap = 0;
     // encoder scratch (grow-only) + tables
     int encode_grid = 0, encode_grid_small = 0;
+    int gen_share = 3;  // workgroups per CU the general decoder takes while block items / foreign frames run beside it (4 = the whole register file)
     int level = 19;  // CompressCtx::new(compression_level), codec.rs:L16-28; CONFIG.compression_level is 19 (common_config.rs:L37)
     uint8_t *enc_prov = nullptr;
     size_t enc_prov_cap = 0;
@@ -106,6 +107,7 @@ static void read_switches(znippy_ctx *ctx) {
     ctx->sw.no_roles = on("ZNIPPY_NO_ROLES");
     ctx->sw.no_fz = on("ZNIPPY_NO_FZ");
     if (const char *lv = getenv("ZNIPPY_LEVEL")) { const int v = atoi(lv); if (v >= 1 && v <= 22) ctx->level = v; }  // initial level of every context (tests, A/B runs)
+    if (const char *gs = getenv("ZNIPPY_GEN_SHARE")) { const int v = atoi(gs); if (v >= 1 && v <= 4) ctx->gen_share = v; }  // A/B
     ctx->sw.fz_only = on("ZNIPPY_FZ_ONLY");  // test hook: no serial fallback behind the two-phase path (what it leaves shows up as corrupt rows)
     if (const char *e = getenv("ZNIPPY_ROLES_MIN")) ctx->sw.roles_min = (unsigned)atoi(e);
     if (const char *e = getenv("ZNIPPY_KTIME")) ctx->sw.ktime = atoi(e);
@@ -975,6 +977,42 @@ int znippy_decode_verify_rows_async(znippy_ctx *ctx, znippy_rows *r, const void 
         ktime_begin(ctx, "zstd_decode_blocks", ctx->aux);
         launch_decode(a, std::min<int>(ctx->decode_grid, (int)r->n_items), false, ctx->aux);
         ktime_end(ctx, ctx->aux);
+        if (r->fz_total) {
+            // Foreign frames (what the block items gave up on): entropy-decode every block at once, then execute frame by
+            // frame.  On the auxiliary stream, behind the block items and BESIDE the general decoder on the main stream:
+            // both are a few long-lived waves per frame, neither fills the chip (real text, libzstd -19 frames: the two
+            // used to run back to back, 7.0 + 10.6 ms).
+            FzArgs z{};
+            z.cand_row = r->cand_row; z.cand_fzbase = r->fz_base; z.cand_fzcap = r->fz_cap; z.n_cand = r->n_cand;
+            z.it_cand = r->fz_it_cand; z.total_items = r->fz_total; z.cand_nb = r->fz_nb; z.items = r->fz_items;
+            z.blobs = (const uint8_t *)d_blobs; z.blob_base = blob_base;
+            z.blob_off = r->blob_off; z.blob_size = r->blob_size; z.usize = r->usize; z.out_off = r->out_off; z.out_cap = out_cap;
+            z.out = (uint8_t *)d_out;
+            z.row_flag = r->row_flag; z.status = r->status; z.preset = preset;
+            z.lit_pool = ctx->fz_lit_pool; z.lit_cap = ctx->fz_lit_cap; z.seq_pool = ctx->fz_seq_pool; z.seq_cap = ctx->fz_seq_cap;
+            z.pool_used = reinterpret_cast<unsigned long long *>(r->ctl + 192);  // [lit bytes, seq records], zeroed with the control block
+            z.cursor = r->cursor + 12;
+            if (ctx->sw.ddbg) {  // diagnostic: where the previous run's execute kernel spent its cycles
+                static unsigned long long *dbg = nullptr;
+                if (!dbg) { (void)hipMalloc(&dbg, 256); (void)hipMemset(dbg, 0, 256); }
+                unsigned long long h[32];
+                (void)hipStreamSynchronize(s);
+                (void)hipStreamSynchronize(ctx->aux);
+                (void)hipMemcpy(h, dbg, 256, hipMemcpyDeviceToHost);
+                if (h[0]) fprintf(stderr, "[znippy ddbg] fz exec: frames=%llu groups=%llu seqs=%llu big=%llu rounds=%llu flushes=%llu histreads=%llu rep_groups=%llu | kcycles/frame: total=%.0f records=%.0f rep+scan=%.0f big=%.0f flush=%.0f histread=%.0f lits=%.0f matches=%.0f tail=%.0f\n",
+                                  h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7], h[8] / 1e3 / h[0], h[9] / 1e3 / h[0], h[10] / 1e3 / h[0], h[11] / 1e3 / h[0],
+                                  h[12] / 1e3 / h[0], h[13] / 1e3 / h[0], h[14] / 1e3 / h[0], h[15] / 1e3 / h[0], h[16] / 1e3 / h[0]);
+                (void)hipMemset(dbg, 0, 256);
+                z.dbg = dbg;
+            }
+            launch_fz_scan(z, r->fz_work, r->cursor + 13, ctx->aux);
+            ktime_begin(ctx, "zstd_foreign_entropy", ctx->aux);
+            launch_fz_entropy(z, ctx->cus, r->fz_work, r->cursor + 13, ctx->aux);
+            ktime_end(ctx, ctx->aux);
+            ktime_begin(ctx, "zstd_foreign_execute", ctx->aux);
+            launch_fz_exec(z, ctx->aux);
+            ktime_end(ctx, ctx->aux);
+        }
         HIPCHK(ctx, hipEventRecord(ctx->ev_join, ctx->aux));
     }
     if (r->n_compressed) {
@@ -1001,41 +1039,14 @@ int znippy_decode_verify_rows_async(znippy_ctx *ctx, znippy_rows *r, const void 
             a.dbg = dbg;
         }
         ktime_begin(ctx, "zstd_decode_general");
-        launch_decode(a, std::min<int>(ctx->decode_grid, (int)r->n_compressed), r->wide_rows, s);
+        // A full grid of this kernel (4 workgroups per CU at 128 VGPRs) is the whole register file: whatever the auxiliary
+        // stream launches then waits until workgroups run out of rows (kernel trace of the real-text table: the first
+        // auxiliary kernel sat 3.4 ms).  With candidates for the block / foreign-frame paths it leaves them a quarter.
+        const int gen_grid = r->n_cand ? ctx->decode_grid / 4 * ctx->gen_share : ctx->decode_grid;
+        launch_decode(a, std::min<int>(gen_grid, (int)r->n_compressed), r->wide_rows, s);
         ktime_end(ctx);
-        if (r->n_cand) {  // join, then the frames the block path gave up on
+        if (r->n_cand) {  // join (block items and the foreign-frame path on the auxiliary stream), then what both gave up on
             HIPCHK(ctx, hipStreamWaitEvent(s, ctx->ev_join, 0));
-            if (r->fz_total) {  // foreign frames: entropy-decode every block at once, then execute frame by frame
-                FzArgs z{};
-                z.cand_row = r->cand_row; z.cand_fzbase = r->fz_base; z.cand_fzcap = r->fz_cap; z.n_cand = r->n_cand;
-                z.it_cand = r->fz_it_cand; z.total_items = r->fz_total; z.cand_nb = r->fz_nb; z.items = r->fz_items;
-                z.blobs = (const uint8_t *)d_blobs; z.blob_base = blob_base;
-                z.blob_off = r->blob_off; z.blob_size = r->blob_size; z.usize = r->usize; z.out_off = r->out_off; z.out_cap = out_cap;
-                z.out = (uint8_t *)d_out;
-                z.row_flag = r->row_flag; z.status = r->status; z.preset = preset;
-                z.lit_pool = ctx->fz_lit_pool; z.lit_cap = ctx->fz_lit_cap; z.seq_pool = ctx->fz_seq_pool; z.seq_cap = ctx->fz_seq_cap;
-                z.pool_used = reinterpret_cast<unsigned long long *>(r->ctl + 192);  // [lit bytes, seq records], zeroed with the control block
-                z.cursor = r->cursor + 12;
-                if (ctx->sw.ddbg) {  // diagnostic: where the previous run's execute kernel spent its cycles
-                    static unsigned long long *dbg = nullptr;
-                    if (!dbg) { (void)hipMalloc(&dbg, 256); (void)hipMemset(dbg, 0, 256); }
-                    unsigned long long h[32];
-                    (void)hipStreamSynchronize(s);
-                    (void)hipMemcpy(h, dbg, 256, hipMemcpyDeviceToHost);
-                    if (h[0]) fprintf(stderr, "[znippy ddbg] fz exec: frames=%llu groups=%llu seqs=%llu big=%llu rounds=%llu flushes=%llu histreads=%llu rep_groups=%llu | kcycles/frame: total=%.0f records=%.0f rep+scan=%.0f big=%.0f flush=%.0f histread=%.0f lits=%.0f matches=%.0f tail=%.0f\n",
-                                      h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7], h[8] / 1e3 / h[0], h[9] / 1e3 / h[0], h[10] / 1e3 / h[0], h[11] / 1e3 / h[0],
-                                      h[12] / 1e3 / h[0], h[13] / 1e3 / h[0], h[14] / 1e3 / h[0], h[15] / 1e3 / h[0], h[16] / 1e3 / h[0]);
-                    (void)hipMemset(dbg, 0, 256);
-                    z.dbg = dbg;
-                }
-                launch_fz_scan(z, r->fz_work, r->cursor + 13, s);
-                ktime_begin(ctx, "zstd_foreign_entropy");
-                launch_fz_entropy(z, ctx->cus, r->fz_work, r->cursor + 13, s);
-                ktime_end(ctx);
-                ktime_begin(ctx, "zstd_foreign_execute");
-                launch_fz_exec(z, s);
-                ktime_end(ctx);
-            }
             launch_finish_blocks(b, s);
             a.list_a = nullptr; a.n_list_a = 0;
             a.pending = r->pending2; a.pending_count = r->pending_count + 1;

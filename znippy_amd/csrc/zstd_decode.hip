@@ -1853,7 +1853,9 @@ __device__ int fz_huf_stream(const uint16_t *huf, uint32_t log, const uint8_t *p
     return b.pos == 0 ? 0 : E_CORRUPT;
 }
 
-__global__ __launch_bounds__(128) void k_fz_entropy(FzArgs a, const uint32_t *work, const uint32_t *work_count) {
+// (held to 128 VGPRs — 165 unbounded, same speed alone: the kernel has to fit into the quarter of the register file the
+// general decoder leaves it, api.hip gen_share)
+__global__ __launch_bounds__(128, 4) void k_fz_entropy(FzArgs a, const uint32_t *work, const uint32_t *work_count) {
     __shared__ FzShared S;
     const uint32_t tid = threadIdx.x, lane = tid & 63;
     const bool wave0 = tid < 64;
