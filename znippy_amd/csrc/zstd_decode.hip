@@ -118,6 +118,10 @@ __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {
     return v;
 }
 
+__device__ __forceinline__ uint64_t rdlane64_u(uint64_t v, uint32_t l) {
+    return ((uint64_t)rdlane_u((uint32_t)(v >> 32), l) << 32) | rdlane_u((uint32_t)v, l);
+}
+
 __device__ __forceinline__ uint64_t load8_guard(const uint8_t *p, const uint8_t *end) {
     if (p + 8 <= end) {
         uint64_t v;
@@ -2032,12 +2036,23 @@ __global__ __launch_bounds__(128, 4) void k_fz_entropy(FzArgs a, const uint32_t 
                     const uint8_t *const bbase = bsrc + uni(S.bs_off);
                     int32_t left = (int32_t)uni((uint32_t)S.bs_pos), cb = 0;
                     uint64_t cw = 0;
+                    // The container is refilled about once per sequence.  Taken from memory that is a dependent global load in
+                    // the middle of the serial chain (~1,000 cycles per sequence measured, most of it that round trip); the
+                    // wave keeps 512 bytes of the stream in registers instead — lane k holds bytes [wbase + 8k, +8) — and a
+                    // refill is two v_readlane pairs and a funnel shift.  The window moves down every ~60 refills.
+                    uint64_t wq = 0;
+                    int32_t wbase = -1;
                     auto refill = [&]() {
                         int32_t b0 = ((left + 7) >> 3) - 8;
                         if (b0 < 0) b0 = 0;
-                        uint64_t v;
-                        __builtin_memcpy(&v, bbase + b0, 8);
-                        cw = uni64(v);
+                        if (wbase < 0 || b0 < wbase) {
+                            int32_t nb = ((b0 + 16 + 7) & ~7) - 512;
+                            wbase = nb < 0 ? 0 : nb;
+                            wq = load8_guard(bbase + wbase + 8 * (int32_t)lane, blob_end);
+                        }
+                        const uint32_t d = (uint32_t)(b0 - wbase), j = uni(d >> 3), r = uni((d & 7) * 8);
+                        const uint64_t lo = rdlane64_u(wq, j), hi = rdlane64_u(wq, j < 63 ? j + 1 : 63);
+                        cw = r ? (lo >> r) | (hi << (64 - r)) : lo;
                         cb = b0 * 8;
                     };
                     auto rd = [&](uint32_t nb) -> uint32_t {
