@@ -1033,8 +1033,8 @@ int znippy_decode_verify_rows_async(znippy_ctx *ctx, znippy_rows *r, const void 
             unsigned long long h[8];
             (void)hipStreamSynchronize(s);
             (void)hipMemcpy(h, dbg, 64, hipMemcpyDeviceToHost);
-            if (h[0]) fprintf(stderr, "[znippy ddbg] general decoder frames=%llu  kcycles per frame: header+literals=%.1f seq-tables=%.1f first-batch=%.1f decode+execute=%.1f tail=%.1f\n", h[0],
-                              h[1] / 1e3 / h[0], h[2] / 1e3 / h[0], h[3] / 1e3 / h[0], h[4] / 1e3 / h[0], h[5] / 1e3 / h[0]);
+            if (h[0]) fprintf(stderr, "[znippy ddbg] general decoder frames=%llu  kcycles per frame: headers+tree=%.1f huffman-table=%.1f literal-streams=%.1f seq-tables=%.1f first-batch=%.1f decode+execute=%.1f tail=%.1f\n", h[0],
+                              h[6] / 1e3 / h[0], h[7] / 1e3 / h[0], h[1] / 1e3 / h[0], h[2] / 1e3 / h[0], h[3] / 1e3 / h[0], h[4] / 1e3 / h[0], h[5] / 1e3 / h[0]);
             (void)hipMemset(dbg, 0, 64);
             a.dbg = dbg;
         }

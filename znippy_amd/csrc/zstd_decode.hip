@@ -1026,6 +1026,7 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES == 4 ? 4 : 1) void k_zstd_decod
             }
             __syncthreads();
             if (S.err) break;
+            DSTAMP(6);
             if (S.n_streams) {
                 if (S.huf_valid == 2) {
                     // fill the decoding table: lane = symbol, each writes its canonical range
@@ -1040,6 +1041,7 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES == 4 ? 4 : 1) void k_zstd_decod
                     __syncthreads();
                     if (tid == 0) S.huf_valid = 1;
                 }
+                DSTAMP(7);
                 if (tid < S.n_streams) {
                     int rc = huf_decode_stream(S, bsrc + S.stream_off[tid], S.stream_len[tid], blob_end,
                                                lit_buf + S.stream_out[tid], S.stream_n[tid]);
@@ -1709,7 +1711,7 @@ __global__ __launch_bounds__(64) void k_fz_scan(FzArgs a, uint32_t *work, uint32
     const uint32_t row = a.cand_row[c], base = a.cand_fzbase[c], cap = a.cand_fzcap[c];
     uint32_t nb = 0;
     if (a.row_flag[row] != 0 && !(a.preset && a.status[row] < 0)) {
-        const uint8_t *src = a.blobs + (a.blob_off[row] - a.blob_base);
+        const uint8_t *const src = a.blobs + (a.blob_off[row] - a.blob_base);
         const uint64_t n = a.blob_size[row], fcs_want = a.usize[row];
         bool ok = n >= 9 && n < 0xFFFF0000ull && (src[0] | (src[1] << 8) | (src[2] << 16) | ((uint32_t)src[3] << 24)) == 0xFD2FB528u;
         uint64_t pos = 5;
