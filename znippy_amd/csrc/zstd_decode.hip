@@ -83,6 +83,7 @@ struct SharedT {
     uint32_t huf_log, huf_valid;
     uint32_t n_streams, stream_off[4], stream_len[4], stream_out[4], stream_n[4];
     uint32_t sel[3], log_[3], valid[3];
+    uint32_t bld[3];  // tables described in this block: alphabet size, 0 = nothing to build (built by waves 0..2 after lane 0 has read the counts)
     uint32_t nseq, batch_n;
     uint64_t src_pos, src_end;  // byte offsets inside the frame's blob
     uint64_t out_pos, out_end;  // byte offsets inside the row's output (out_pos: flushed to HBM)
@@ -578,7 +579,7 @@ __device__ __forceinline__ uint32_t win_flush(uint8_t *W, uint8_t *out, uint64_t
 // ---------------------------------------------------------------------------------------------
 template <class Shared>
 __device__ int fse_read_ncount(Shared &S, const uint8_t *src, uint32_t n, int max_log, int max_sym, int *nsym,
-                               int *log, uint32_t *consumed) {
+                               int *log, uint32_t *consumed, int nbase = 0) {
     FwdR b{src, n, 0};
     if (n == 0) return E_TRUNC;
     int alog = 5 + (int)b.read(4);
@@ -597,11 +598,11 @@ __device__ int fse_read_ncount(Shared &S, const uint8_t *src, uint32_t n, int ma
         }
         int proba = (int)val - 1;
         remaining -= proba < 0 ? -proba : proba;
-        S.norm[s++] = (int16_t)proba;
+        S.norm[nbase + s++] = (int16_t)proba;
         if (proba == 0) {
             uint32_t rep = b.read(2);
             for (;;) {
-                for (uint32_t i = 0; i < rep && s <= max_sym; i++) S.norm[s++] = 0;
+                for (uint32_t i = 0; i < rep && s <= max_sym; i++) S.norm[nbase + s++] = 0;
                 if (rep == 3) rep = b.read(2); else break;
             }
         }
@@ -649,6 +650,72 @@ __device__ int fse_build(Shared &S, FseEntry *t, int nsym, int log, int kind) {
         t[i] = e;
     }
     return 0;
+}
+
+// fse_build by one wave, for alphabets of at most 64 symbols (the three sequence tables): lane = symbol for the
+// counts, lane = table cell for the entries.  The serial version is two loops of dependent LDS accesses (spread the
+// symbols, then hand every cell its symbol's next state: ~250 cycles per cell for a lone wave, 100-700 kcycles per block
+// for the three tables).  Here a cell finds its symbol directly: the spread visits cells in the order 0, step, 2*step, ...
+// (mod size) and skips the cells at the top that the "less than 1" symbols own, so cell u is the
+// (u / step mod size) - (top cells visited earlier) -th cell handed out, and its symbol is the one whose cumulative
+// count covers that index; the state a cell gets is its symbol's count plus the cell's rank among the symbol's
+// cells, counted 64 cells at a time with ballots.  scr: 128 u16 of LDS scratch.  Counts are already validated
+// (fse_read_ncount: they sum to the table size).
+__device__ void fse_build_wave(const int16_t *norm, uint32_t nsym, uint32_t log, int kind, FseEntry *t, uint16_t *scr, uint32_t lane) {
+    const uint32_t size = 1u << log, mask = size - 1, step = (size >> 1) + (size >> 3) + 3;
+    uint32_t inv = step;  // inverse of the odd step modulo 2^log (Newton: 3 -> 6 -> 12 correct bits)
+    inv *= 2u - step * inv; inv *= 2u - step * inv;
+    const int c = lane < nsym ? (int)norm[lane] : 0;
+    const bool low = c == -1;
+    const uint32_t cnt = c > 0 ? (uint32_t)c : 0u;
+    const uint64_t lowm = __ballot(low), below = lane ? (~0ull >> (64 - lane)) : 0ull;
+    const uint32_t nlow = (uint32_t)__popcll(lowm), high = size - nlow;
+    auto entry = [&](uint32_t sym, uint32_t ns) -> FseEntry {
+        FseEntry e;
+        const uint32_t nb = log - (uint32_t)hibit(ns);
+        e.next = (uint16_t)((ns << nb) - size);
+        e.nbits = (uint8_t)nb;
+        if (kind == K_LL) { e.base = c_ll_base[sym > 35 ? 35 : sym]; e.addbits = c_ll_bits[sym > 35 ? 35 : sym]; }
+        else if (kind == K_ML) { e.base = c_ml_base[sym > 52 ? 52 : sym]; e.addbits = c_ml_bits[sym > 52 ? 52 : sym]; }
+        else { e.base = 1u << (sym & 31); e.addbits = (uint8_t)sym; }
+        return e;
+    };
+    if (low) t[size - 1 - (uint32_t)__popcll(lowm & below)] = entry(lane, 1);
+    uint32_t incl = cnt;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t y = __shfl_up(incl, d);
+        if (lane >= (uint32_t)d) incl += y;
+    }
+    uint16_t *const cum = scr, *const cur = scr + 64;
+    cum[lane] = (uint16_t)incl;
+    cur[lane] = (uint16_t)cnt;
+    const uint32_t jh = lane < nlow ? ((high + lane) * inv) & mask : 0xFFFFFFFFu;  // when the spread would have reached top cell `lane`
+    __builtin_amdgcn_wave_barrier();
+    for (uint32_t u0 = 0; u0 < high; u0 += 64) {
+        const uint32_t u = u0 + lane;
+        const bool on = u < high;
+        const uint32_t j = (u * inv) & mask;
+        uint32_t less = 0;
+        for (uint32_t r = 0; r < nlow; r++) less += rdlane_u(jh, r) < j ? 1u : 0u;
+        const uint32_t kf = on ? j - less : 0u;
+        uint32_t sidx = 0;
+#pragma unroll
+        for (uint32_t st = 32; st; st >>= 1)
+            if (cum[sidx + st - 1] <= kf) sidx += st;
+        uint64_t todo = __ballot(on);
+        uint32_t ns = 1;
+        while (todo) {
+            const uint32_t l = (uint32_t)__ffsll((long long)todo) - 1, sl = rdlane_u(sidx, l) & 63;
+            const uint64_t same = __ballot(on && sidx == sl);
+            const uint32_t b0 = cur[sl];
+            if (on && sidx == sl) ns = b0 + (uint32_t)__popcll(same & below);
+            if (lane == l) cur[sl] = (uint16_t)(b0 + (uint32_t)__popcll(same));
+            todo &= ~same;
+        }
+        if (on) t[u] = entry(sidx, ns ? ns : 1);
+    }
+    __builtin_amdgcn_wave_barrier();
 }
 
 __device__ int fse_set_rle(FseEntry *e, uint32_t sym, int kind) {
@@ -1059,6 +1126,7 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES == 4 ? 4 : 1) void k_zstd_decod
                 const uint64_t end = bpos + bsize;
                 uint64_t p = S.src_pos;
                 uint32_t nseq = 0;
+                S.bld[0] = S.bld[1] = S.bld[2] = 0;
                 if (p >= end) err = E_TRUNC;
                 else {
                     uint32_t b0 = src[p];
@@ -1086,9 +1154,8 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES == 4 ? 4 : 1) void k_zstd_decod
                             } else if (mode == 2) {
                                 int nsym, log;
                                 uint32_t used;
-                                err = fse_read_ncount(S, src + p, (uint32_t)(end - p), maxlog[k], maxsym[k], &nsym, &log, &used);
-                                if (!err) err = fse_build(S, k == 0 ? S.ll : (k == 1 ? S.of : S.ml), nsym, log, kinds[k]);
-                                if (!err) { p += used; S.sel[k] = 2; S.log_[k] = log; S.valid[k] = 1; }
+                                err = fse_read_ncount(S, src + p, (uint32_t)(end - p), maxlog[k], maxsym[k], &nsym, &log, &used, 64 * k);
+                                if (!err) { p += used; S.sel[k] = 2; S.log_[k] = log; S.valid[k] = 1; S.bld[k] = (uint32_t)nsym; }
                             } else if (!S.valid[k]) err = E_CORRUPT;
                         }
                         if (!err) {
@@ -1113,6 +1180,13 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES == 4 ? 4 : 1) void k_zstd_decod
             }
             __syncthreads();
             if (S.err) break;
+            {   // the tables this block describes: wave k builds table k (LL, OF, ML) from the counts lane 0 left in S.norm
+                const uint32_t w = tid >> 6;
+                if (w < 3 && S.bld[w])
+                    fse_build_wave(S.norm + 64 * w, S.bld[w], S.log_[w], w == 0 ? K_LL : (w == 1 ? K_OF : K_ML),
+                                   w == 0 ? S.ll : (w == 1 ? S.of : S.ml), reinterpret_cast<uint16_t *>(S.fse_next) + 128 * w, tid & 63);
+                __syncthreads();
+            }
 
             DSTAMP(2);
             // -- sequences: lane 0 decodes a batch into LDS, the workgroup executes it --
