@@ -83,6 +83,7 @@ struct SharedT {
     uint32_t huf_log, huf_valid;
     uint32_t n_streams, stream_off[4], stream_len[4], stream_out[4], stream_n[4];
     uint32_t sel[3], log_[3], valid[3];
+    uint32_t tree_off, tree_n;  // a Huffman tree description waits at bsrc + tree_off (tree_n bytes available; 0 = none): read by wave 0 after lane 0's header pass
     uint32_t bld[3];  // tables described in this block: alphabet size, 0 = nothing to build (built by waves 0..2 after lane 0 has read the counts)
     uint32_t nseq, batch_n;
     uint64_t src_pos, src_end;  // byte offsets inside the frame's blob
@@ -677,7 +678,8 @@ __device__ void fse_build_wave(const int16_t *norm, uint32_t nsym, uint32_t log,
         e.nbits = (uint8_t)nb;
         if (kind == K_LL) { e.base = c_ll_base[sym > 35 ? 35 : sym]; e.addbits = c_ll_bits[sym > 35 ? 35 : sym]; }
         else if (kind == K_ML) { e.base = c_ml_base[sym > 52 ? 52 : sym]; e.addbits = c_ml_bits[sym > 52 ? 52 : sym]; }
-        else { e.base = 1u << (sym & 31); e.addbits = (uint8_t)sym; }
+        else if (kind == K_OF) { e.base = 1u << (sym & 31); e.addbits = (uint8_t)sym; }
+        else { e.base = sym; e.addbits = 0; }  // kind < 0: plain symbols (Huffman weights)
         return e;
     };
     if (low) t[size - 1 - (uint32_t)__popcll(lowm & below)] = entry(lane, 1);
@@ -811,6 +813,116 @@ __device__ int huf_read_tree(Shared &S, const uint8_t *src, uint32_t n, const ui
         rank_idx[bits] += len;
     }
     S.huf_log = maxbits;
+    return 0;
+}
+
+// huf_read_tree by one wave (the general / block decoder).  What is serial by nature stays on lane 0 (reading the
+// counts of the weight table, decoding the at most 255 weights with two interleaved states); the weight table itself is
+// built by the wave (fse_build_wave), and so is everything behind the weights: validity, the implied last weight, and every
+// symbol's range in the decoding table — four symbols per lane, ranks by ballots in (weight, symbol) order.  Same
+// verdicts as the serial version, which the foreign-frame path still uses.
+template <class Shared>
+__device__ int huf_read_tree_wave(Shared &S, const uint8_t *src, uint32_t n, const uint8_t *blob_end, uint32_t lane) {
+    if (n < 1) return E_TRUNC;
+    const uint32_t hb = uni((uint32_t)src[0]);
+    uint32_t nw = 0;
+    if (hb >= 128) {
+        nw = hb - 127;
+        const uint32_t bytes = (nw + 1) / 2;
+        if (1 + bytes > n) return E_TRUNC;
+        for (uint32_t i = lane; i < nw; i += 64) {
+            const uint8_t b = src[1 + i / 2];
+            S.weights[i] = (i & 1) ? (b & 15) : (b >> 4);
+        }
+    } else {
+        if (hb == 0 || 1 + hb > n) return E_TRUNC;
+        int rc = 0, nsym = 0, log = 0;
+        uint32_t hdr = 0;
+        if (lane == 0) rc = fse_read_ncount(S, src + 1, hb, 6, 255, &nsym, &log, &hdr);
+        rc = (int)uni((uint32_t)rc); nsym = (int)uni((uint32_t)nsym); log = (int)uni((uint32_t)log); hdr = uni(hdr);
+        if (rc) return rc;
+        FseEntry *t = reinterpret_cast<FseEntry *>(S.seq_ll);  // free while literals are being decoded
+        __builtin_amdgcn_wave_barrier();
+        if (nsym <= 64) fse_build_wave(S.norm, (uint32_t)nsym, (uint32_t)log, -1, t, reinterpret_cast<uint16_t *>(S.fse_next), lane);
+        else {  // a table that names symbols beyond 63 (no weight is that large; the weights decide below)
+            if (lane == 0) rc = fse_build(S, t, nsym, log, -1);
+            rc = (int)uni((uint32_t)rc);
+            if (rc) return rc;
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (hdr >= hb) return E_CORRUPT;
+        if (lane == 0) {
+            BitR b;
+            if (!b.init(src + 1 + hdr, hb - hdr, blob_end)) rc = E_CORRUPT;
+            else {
+                uint32_t s1 = b.read(log), s2 = b.read(log);
+                for (;;) {
+                    if (nw >= 255) { rc = E_CORRUPT; break; }
+                    S.weights[nw++] = (uint8_t)t[s1].base;
+                    s1 = t[s1].next + b.read(t[s1].nbits);
+                    if (b.pos < 0) {
+                        if (nw >= 255) { rc = E_CORRUPT; break; }
+                        S.weights[nw++] = (uint8_t)t[s2].base;
+                        break;
+                    }
+                    if (nw >= 255) { rc = E_CORRUPT; break; }
+                    S.weights[nw++] = (uint8_t)t[s2].base;
+                    s2 = t[s2].next + b.read(t[s2].nbits);
+                    if (b.pos < 0) {
+                        if (nw >= 255) { rc = E_CORRUPT; break; }
+                        S.weights[nw++] = (uint8_t)t[s1].base;
+                        break;
+                    }
+                }
+            }
+        }
+        rc = (int)uni((uint32_t)rc); nw = uni(nw);
+        if (rc) return rc;
+    }
+    __builtin_amdgcn_wave_barrier();
+    // implied last weight, code lengths, canonical start index per symbol: lane owns symbols lane, +64, +128, +192
+    uint32_t w[4], sum = 0;
+    bool bad = false;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const uint32_t idx = lane + 64 * j;
+        w[j] = idx < nw ? S.weights[idx] : 0;
+        if (w[j] > 12) bad = true;
+        sum += (w[j] && w[j] <= 12) ? 1u << (w[j] - 1) : 0;
+    }
+    if (__ballot(bad)) return E_CORRUPT;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) sum += __shfl_xor(sum, d);
+    const uint32_t total = sum;
+    if (total == 0) return E_CORRUPT;
+    const uint32_t maxbits = (uint32_t)hibit(total) + 1;
+    if (maxbits > 11) return E_CORRUPT;
+    const uint32_t left = (1u << maxbits) - total;
+    if (left & (left - 1)) return E_CORRUPT;
+    const uint32_t lastw = (uint32_t)hibit(left) + 1;
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+        if (lane + 64 * j == nw) { w[j] = lastw; S.weights[nw] = (uint8_t)lastw; }
+    const uint64_t below = lane ? (~0ull >> (64 - lane)) : 0ull;
+    uint32_t start = 0, st[4] = {0, 0, 0, 0}, ln[4] = {0, 0, 0, 0};
+    for (uint32_t bits = maxbits; bits >= 1; bits--) {  // longest codes first, as the table is laid out
+        const uint32_t wt = maxbits + 1 - bits, len = 1u << (maxbits - bits);
+        uint32_t before = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const uint64_t m = __ballot(w[j] == wt);
+            if (w[j] == wt) { st[j] = start + ((before + (uint32_t)__popcll(m & below)) << (maxbits - bits)); ln[j] = len; }
+            before += (uint32_t)__popcll(m);
+        }
+        start += before << (maxbits - bits);
+    }
+    if (start != (1u << maxbits)) return E_CORRUPT;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        S.sym_start[lane + 64 * j] = (uint16_t)st[j];
+        S.sym_len[lane + 64 * j] = (uint16_t)ln[j];
+    }
+    if (lane == 0) S.huf_log = maxbits;
     return 0;
 }
 
@@ -1029,6 +1141,7 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES == 4 ? 4 : 1) void k_zstd_decod
             if (tid == 0) {
                 int err = 0;
                 uint32_t n = bsize, used = 0;
+                S.tree_n = 0;
                 if (n < 1) err = E_TRUNC;
                 else {
                     uint32_t b0 = bsrc[0], type = b0 & 3, sf = (b0 >> 2) & 3, regen = 0, comp = 0, hdr = 0;
@@ -1059,9 +1172,15 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES == 4 ? 4 : 1) void k_zstd_decod
                         else if (regen > BLOCK_MAX) err = E_CORRUPT;
                         uint32_t p = hdr, remain = comp;
                         if (!err && type == 2) {
+                            // the tree description: its size is in its first byte; wave 0 reads it after this pass
                             uint32_t tu = 0;
-                            err = huf_read_tree(S, bsrc + p, remain, blob_end, &tu);
-                            if (!err) { p += tu; remain -= tu; S.huf_valid = 2; }  // 2 = table must be (re)filled
+                            if (remain < 1) err = E_TRUNC;
+                            else {
+                                const uint32_t hb = bsrc[p];
+                                tu = hb >= 128 ? 1 + (hb - 127 + 1) / 2 : 1 + hb;
+                                if (hb == 0 || tu > remain) err = E_TRUNC;
+                            }
+                            if (!err) { S.tree_off = p; S.tree_n = remain; p += tu; remain -= tu; S.huf_valid = 2; }  // 2 = table must be (re)filled
                         } else if (!err && !S.huf_valid) err = E_CORRUPT;
                         if (!err) {
                             if (streams == 1) {
@@ -1093,6 +1212,14 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES == 4 ? 4 : 1) void k_zstd_decod
             }
             __syncthreads();
             if (S.err) break;
+            if (S.tree_n) {
+                if (wave0) {
+                    const int rc = huf_read_tree_wave(S, bsrc + S.tree_off, S.tree_n, blob_end, tid);
+                    if (rc && tid == 0) S.err = rc;
+                }
+                __syncthreads();
+                if (S.err) break;
+            }
             DSTAMP(6);
             if (S.n_streams) {
                 if (S.huf_valid == 2) {
