@@ -1002,6 +1002,8 @@ int znippy_decode_verify_rows_async(znippy_ctx *ctx, znippy_rows *r, const void 
                 if (h[0]) fprintf(stderr, "[znippy ddbg] fz exec: frames=%llu groups=%llu seqs=%llu big=%llu rounds=%llu flushes=%llu histreads=%llu rep_groups=%llu | kcycles/frame: total=%.0f records=%.0f rep+scan=%.0f big=%.0f flush=%.0f histread=%.0f lits=%.0f matches=%.0f tail=%.0f\n",
                                   h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7], h[8] / 1e3 / h[0], h[9] / 1e3 / h[0], h[10] / 1e3 / h[0], h[11] / 1e3 / h[0],
                                   h[12] / 1e3 / h[0], h[13] / 1e3 / h[0], h[14] / 1e3 / h[0], h[15] / 1e3 / h[0], h[16] / 1e3 / h[0]);
+                if (h[20]) fprintf(stderr, "[znippy ddbg] fz entropy: blocks=%llu seqs=%llu | kcycles/block: literal tree=%.0f literal table+streams=%.0f sequence tables=%.0f sequence decode=%.0f\n",
+                                   h[20], h[25], h[21] / 1e3 / h[20], h[22] / 1e3 / h[20], h[23] / 1e3 / h[20], h[24] / 1e3 / h[20]);
                 (void)hipMemset(dbg, 0, 256);
                 z.dbg = dbg;
             }

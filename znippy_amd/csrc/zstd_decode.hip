@@ -2119,6 +2119,9 @@ __global__ __launch_bounds__(128, 4) void k_fz_entropy(FzArgs a, const uint32_t 
             S.rep_out[0] = FZ_SYM; S.rep_out[1] = FZ_SYM | (1u << 26); S.rep_out[2] = FZ_SYM | (2u << 26);
         }
         __syncthreads();
+        unsigned long long t_e = a.dbg ? __builtin_amdgcn_s_memtime() : 0;  // diagnostic (ZNIPPY_DDBG): where a block's entropy stage spends its cycles
+#define ESTAMPZ(i) do { if (a.dbg && lane == 0) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); atomicAdd(&a.dbg[i], now_ - t_e); t_e = now_; } } while (0)
+        if (a.dbg && tid == 0) atomicAdd(&a.dbg[20], 1ull);
         if (S.err == 0) {
             if (wave0) {
                 // ---- literals: tree, table, streams ----
@@ -2162,6 +2165,7 @@ __global__ __launch_bounds__(128, 4) void k_fz_entropy(FzArgs a, const uint32_t 
                         if (err) atomicMin(&S.err, err);
                     }
                     __builtin_amdgcn_wave_barrier();
+                    ESTAMPZ(21);
                     if (S.err == 0) {
                         const uint32_t hlog = S.ta.huf_log;
                         for (uint32_t sym = lane; sym < 256; sym += 64) {
@@ -2178,6 +2182,7 @@ __global__ __launch_bounds__(128, 4) void k_fz_entropy(FzArgs a, const uint32_t 
                                                          a.lit_pool + S.lit_off + S.stream_out[lane], S.stream_n[lane]);
                             if (rc) atomicMin(&S.err, rc);
                         }
+                        ESTAMPZ(22);
                     }
                 }
             } else {
@@ -2230,42 +2235,25 @@ __global__ __launch_bounds__(128, 4) void k_fz_entropy(FzArgs a, const uint32_t 
                     if (err) atomicMin(&S.err, err);
                 }
                 __builtin_amdgcn_wave_barrier();
+                ESTAMPZ(23);
                 const uint32_t nseq = uni(S.nseq);
+                if (a.dbg && lane == 0) atomicAdd(&a.dbg[25], (unsigned long long)nseq);
                 if (S.err == 0 && nseq) {
                     const uint32_t sel0 = uni(S.sel[0]), sel1 = uni(S.sel[1]), sel2 = uni(S.sel[2]);
                     const FseEntry *tl = sel0 == 0 ? S.dll : (sel0 == 1 ? &S.rle[0] : S.ll);
                     const FseEntry *to = sel1 == 0 ? S.dof : (sel1 == 1 ? &S.rle[1] : S.of);
                     const FseEntry *tm = sel2 == 0 ? S.dml : (sel2 == 1 ? &S.rle[2] : S.ml);
                     const uint8_t *const bbase = bsrc + uni(S.bs_off);
-                    int32_t left = (int32_t)uni((uint32_t)S.bs_pos), cb = 0;
-                    uint64_t cw = 0;
-                    // The container is refilled about once per sequence.  Taken from memory that is a dependent global load in
-                    // the middle of the serial chain (~1,000 cycles per sequence measured, most of it that round trip); the
-                    // wave keeps 512 bytes of the stream in registers instead — lane k holds bytes [wbase + 8k, +8) — and a
-                    // refill is two v_readlane pairs and a funnel shift.  The window moves down every ~60 refills.
+                    int32_t left = (int32_t)uni((uint32_t)S.bs_pos);
+                    // The bit reader.  512 bytes of the stream live in the wave's registers (lane k holds bytes
+                    // [wbase + 8k, +8)); a sequence takes the 16 bytes that end at its position out of them (three readlane
+                    // pairs and two funnel shifts — no memory access inside the serial chain), and its value bits and state
+                    // bits are two extractions from that 128-bit chunk: at most 59 + 27 bits, always inside it.
+                    // (Measured, ZNIPPY_DDBG: 1,220 cycles per sequence before and after — neither the per-sequence refill
+                    // load nor the per-sequence record store was the cost.  The trip is ~250 executed instructions, 180 of
+                    // them scalar, and a lone wave retires one dependent instruction every ~5 cycles: DESIGN.md 7c.)
                     uint64_t wq = 0;
                     int32_t wbase = -1;
-                    auto refill = [&]() {
-                        int32_t b0 = ((left + 7) >> 3) - 8;
-                        if (b0 < 0) b0 = 0;
-                        if (wbase < 0 || b0 < wbase) {
-                            int32_t nb = ((b0 + 16 + 7) & ~7) - 512;
-                            wbase = nb < 0 ? 0 : nb;
-                            wq = load8_guard(bbase + wbase + 8 * (int32_t)lane, blob_end);
-                        }
-                        const uint32_t d = (uint32_t)(b0 - wbase), j = uni(d >> 3), r = uni((d & 7) * 8);
-                        const uint64_t lo = rdlane64_u(wq, j), hi = rdlane64_u(wq, j < 63 ? j + 1 : 63);
-                        cw = r ? (lo >> r) | (hi << (64 - r)) : lo;
-                        cb = b0 * 8;
-                    };
-                    auto rd = [&](uint32_t nb) -> uint32_t {
-                        const int32_t sh = left - cb - (int32_t)nb;
-                        const uint64_t v = sh >= 0 ? (cw >> sh) : (cw << (sh < -63 ? 63 : -sh));
-                        left -= (int32_t)nb;
-                        return (uint32_t)v & ((1u << nb) - 1u);  // nb <= 31
-                    };
-                    if (((left + 7) >> 3) >= 8) refill();
-                    else cw = uni64(load8_guard(bbase, blob_end));
                     uint32_t sl = uni(S.st_ll), so = uni(S.st_of), sm = uni(S.st_ml);
                     const uint2 *const tl2 = reinterpret_cast<const uint2 *>(tl), *const to2 = reinterpret_cast<const uint2 *>(to),
                                 *const tm2 = reinterpret_cast<const uint2 *>(tm);
@@ -2273,26 +2261,44 @@ __global__ __launch_bounds__(128, 4) void k_fz_entropy(FzArgs a, const uint32_t 
                     uint32_t sum_ll = 0, sum_ml = 0;
                     uint32_t r0 = FZ_SYM, r1 = FZ_SYM | (1u << 26), r2 = FZ_SYM | (2u << 26);
                     int err = 0;
+                    unsigned long long myrec = 0;
                     for (uint32_t i = 0; i < nseq; i++) {
                         const uint2 veo = to2[so], vem = tm2[sm], vel = tl2[sl];
                         const uint32_t eox = uni(veo.x), eoy = uni(veo.y), emx = uni(vem.x), emy = uni(vem.y), elx = uni(vel.x), ely = uni(vel.y);
                         const uint32_t ofb = eox >> 24, mlb = emx >> 24, llb = elx >> 24;
                         const bool more = i + 1 < nseq;
                         const uint32_t nbl = (elx >> 16) & 0xFF, nbm = (emx >> 16) & 0xFF, nbo = (eox >> 16) & 0xFF;
-                        const int32_t need_v = (int32_t)(ofb + mlb + llb), need_s = more ? (int32_t)(nbl + nbm + nbo) : 0;
-                        if (left - cb < need_v + need_s && cb > 0) refill();
-                        const uint32_t ov = eoy + rd(ofb > 31 ? 31 : ofb);
-                        if (need_v + need_s > 56 && left - cb < need_v + need_s - (int32_t)ofb && cb > 0) refill();
-                        const uint32_t ml = emy + rd(mlb);
-                        const uint32_t ll = ely + rd(llb);
-                        if (more) {
-                            if (need_v + need_s > 56 && left - cb < need_s && cb > 0) refill();
-                            sl = (elx & 0xFFFF) + rd(nbl);
-                            sm = (emx & 0xFFFF) + rd(nbm);
-                            so = (eox & 0xFFFF) + rd(nbo);
+                        const uint32_t need_v = ofb + mlb + llb, need_s = more ? nbl + nbm + nbo : 0u;
+                        if (ofb > 27) { err = E_UNSUP; if (lane == 0) S.why = 3; break; }
+                        if (left < (int32_t)(need_v + need_s)) { err = E_CORRUPT; break; }  // the stream ends before the sequence does
+                        const int32_t bend = (left + 7) >> 3, cs = bend > 16 ? bend - 16 : 0;  // the chunk: stream bytes [cs, cs + 16)
+                        if (wbase < 0 || cs < wbase) {
+                            const int32_t nb0 = ((cs + 24 + 7) & ~7) - 512;
+                            wbase = nb0 < 0 ? 0 : nb0;
+                            wq = load8_guard(bbase + wbase + 8 * (int32_t)lane, blob_end);
                         }
+                        const uint32_t d = (uint32_t)(cs - wbase), j = uni(d >> 3), r = uni((d & 7) * 8);
+                        const uint64_t q0 = rdlane64_u(wq, j), q1 = rdlane64_u(wq, j + 1), q2 = rdlane64_u(wq, j + 2 > 63 ? 63 : j + 2);
+                        const uint64_t lo = r ? (q0 >> r) | (q1 << (64 - r)) : q0, hi = r ? (q1 >> r) | (q2 << (64 - r)) : q1;
+                        const uint32_t ptop = (uint32_t)(left - 8 * cs);  // where `left` sits inside the chunk (<= 128)
+                        auto ext = [&](uint32_t top, uint32_t n) -> uint64_t {  // chunk bits [top - n, top), n < 64, top >= n
+                            const uint32_t sh = top - n;
+                            const uint64_t v = sh >= 64 ? hi >> (sh - 64) : (sh ? (lo >> sh) | (hi << (64 - sh)) : lo);
+                            return v & ((1ull << n) - 1ull);
+                        };
+                        const uint64_t xv = ext(ptop, need_v);
+                        const uint32_t ov = eoy + (uint32_t)(xv >> (mlb + llb));
+                        const uint32_t ml = emy + ((uint32_t)(xv >> llb) & ((1u << mlb) - 1u));
+                        const uint32_t ll = ely + ((uint32_t)xv & ((1u << llb) - 1u));
+                        if (more) {
+                            const uint32_t xs = (uint32_t)ext(ptop - need_v, need_s);
+                            sl = (elx & 0xFFFF) + (xs >> (nbm + nbo));
+                            sm = (emx & 0xFFFF) + ((xs >> nbo) & ((1u << nbm) - 1u));
+                            so = (eox & 0xFFFF) + (xs & ((1u << nbo) - 1u));
+                        }
+                        left -= (int32_t)(need_v + need_s);
                         sum_ll += ll; sum_ml += ml;
-                        if (left < 0 || ofb > 27 || sum_ll + sum_ml > BLOCK_MAX) { err = left < 0 ? E_CORRUPT : E_UNSUP; if (lane == 0 && left >= 0) S.why = 3; break; }
+                        if (sum_ll + sum_ml > BLOCK_MAX) { err = E_UNSUP; if (lane == 0) S.why = 3; break; }
                         // repeat offsets (RFC 8878 3.1.1.5), against the symbolic incoming history
                         uint32_t o;
                         if (ov > 3) { o = ov - 3; r2 = r1; r1 = r0; r0 = o; }
@@ -2312,9 +2318,14 @@ __global__ __launch_bounds__(128, 4) void k_fz_entropy(FzArgs a, const uint32_t 
                                 r1 = r0; r0 = o;
                             }
                         }
-                        if (lane == 0) recs[i] = (unsigned long long)ll | ((unsigned long long)ml << 17) | ((unsigned long long)o << 35);
+                        // The record goes to lane (i mod 64); 64 of them leave in one coalesced store (the loop's only memory access
+                        // besides the window reload: the compiler waits for vmcnt(0) before the window's first use in every trip).
+                        if (lane == (i & 63)) myrec = (unsigned long long)ll | ((unsigned long long)ml << 17) | ((unsigned long long)o << 35);
+                        if ((i & 63) == 63) recs[i - 63 + lane] = myrec;
                     }
+                    if (!err && (nseq & 63) && lane < (nseq & 63)) recs[(nseq & ~63u) + lane] = myrec;
                     if (!err && left != 0) err = E_CORRUPT;
+                    ESTAMPZ(24);
                     if (lane == 0) {
                         S.sum_ll = sum_ll; S.sum_ml = sum_ml;
                         S.rep_out[0] = r0; S.rep_out[1] = r1; S.rep_out[2] = r2;
