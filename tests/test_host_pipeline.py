@@ -326,3 +326,31 @@ def test_compress_dir_slots_round_trip(backend, tmp_path, tmp_path_factory):  # 
     assert out == files
     m = ix.read_znippy_manifest(str(tmp_path / "slots.znippy"))
     assert len(m) == 1 and (m[0].pkg_type, m[0].repo, m[0].row_count) == (0, "r", report.chunks)
+
+
+def test_pipelines_hand_the_configured_level_to_the_codec(backend, tmp_path):
+    """CompressCtx::new(CONFIG.compression_level) (stream_packer.rs:L217, slot_packer.rs:L551): both pipelines set the
+    backend's level from the config they run with, and the level is what the archive's metadata records."""
+    import copy
+    from znippy_amd.slot_packer import compress_dir
+    seen = []
+    real = backend.set_level
+    backend.set_level = lambda lv: (seen.append(lv), real(lv))[1]
+    try:
+        cfg = copy.copy(ix.CONFIG)
+        cfg.compression_level = 3
+        sc = compress_stream(str(tmp_path / "lv"), False, backend=backend, config=cfg)
+        sc.sender().send(ArchiveEntry("a.txt", gen.pseudo_text(50_000, seed=3)))
+        sc.finish()
+        schema, _ = ix.read_znippy_index(str(tmp_path / "lv.znippy"))
+        assert {k.decode(): v.decode() for k, v in schema.metadata.items()}["compression_level"] == "3"
+        src = tmp_path / "in"
+        src.mkdir()
+        (src / "b.txt").write_bytes(gen.pseudo_text(20_000, seed=4))
+        compress_dir(str(src), str(tmp_path / "dir"), backend=backend, config=cfg)
+        assert seen == [3, 3]
+        out = decompress_archive(str(tmp_path / "lv.znippy"), True, tmp_path / "o", backend=backend)
+        assert out.corrupt_files == 0 and (tmp_path / "o" / "a.txt").read_bytes() == gen.pseudo_text(50_000, seed=3)
+    finally:
+        backend.set_level = real
+        backend.set_level(19)
