@@ -2253,7 +2253,7 @@ __global__ __launch_bounds__(128, 4) void k_fz_entropy(FzArgs a, const uint32_t 
                     // load nor the per-sequence record store was the cost.  The trip is ~250 executed instructions, 180 of
                     // them scalar, and a lone wave retires one dependent instruction every ~5 cycles: DESIGN.md 7c.)
                     uint64_t wq = 0;
-                    int32_t wbase = -1;
+                    int32_t wbase = INT32_MIN;
                     uint32_t sl = uni(S.st_ll), so = uni(S.st_of), sm = uni(S.st_ml);
                     const uint2 *const tl2 = reinterpret_cast<const uint2 *>(tl), *const to2 = reinterpret_cast<const uint2 *>(to),
                                 *const tm2 = reinterpret_cast<const uint2 *>(tm);
@@ -2271,27 +2271,27 @@ __global__ __launch_bounds__(128, 4) void k_fz_entropy(FzArgs a, const uint32_t 
                         const uint32_t need_v = ofb + mlb + llb, need_s = more ? nbl + nbm + nbo : 0u;
                         if (ofb > 27) { err = E_UNSUP; if (lane == 0) S.why = 3; break; }
                         if (left < (int32_t)(need_v + need_s)) { err = E_CORRUPT; break; }  // the stream ends before the sequence does
-                        const int32_t bend = (left + 7) >> 3, cs = bend > 16 ? bend - 16 : 0;  // the chunk: stream bytes [cs, cs + 16)
-                        if (wbase < 0 || cs < wbase) {
+                        // the chunk: stream bytes [cs, cs + 16), cs = (last byte needed) - 16; bytes in front of the stream read as zero
+                        // (the window may start 16 bytes before it), so every step below is branch-free
+                        const int32_t bend = (left + 7) >> 3, cs = bend - 16;
+                        if (wbase == INT32_MIN || cs < wbase) {
                             const int32_t nb0 = ((cs + 24 + 7) & ~7) - 512;
-                            wbase = nb0 < 0 ? 0 : nb0;
-                            wq = load8_guard(bbase + wbase + 8 * (int32_t)lane, blob_end);
+                            wbase = nb0 < -16 ? -16 : nb0;
+                            const int32_t o8 = wbase + 8 * (int32_t)lane;
+                            wq = o8 < 0 ? 0ull : load8_guard(bbase + o8, blob_end);
                         }
                         const uint32_t d = (uint32_t)(cs - wbase), j = uni(d >> 3), r = uni((d & 7) * 8);
-                        const uint64_t q0 = rdlane64_u(wq, j), q1 = rdlane64_u(wq, j + 1), q2 = rdlane64_u(wq, j + 2 > 63 ? 63 : j + 2);
-                        const uint64_t lo = r ? (q0 >> r) | (q1 << (64 - r)) : q0, hi = r ? (q1 >> r) | (q2 << (64 - r)) : q1;
-                        const uint32_t ptop = (uint32_t)(left - 8 * cs);  // where `left` sits inside the chunk (<= 128)
-                        auto ext = [&](uint32_t top, uint32_t n) -> uint64_t {  // chunk bits [top - n, top), n < 64, top >= n
-                            const uint32_t sh = top - n;
-                            const uint64_t v = sh >= 64 ? hi >> (sh - 64) : (sh ? (lo >> sh) | (hi << (64 - sh)) : lo);
-                            return v & ((1ull << n) - 1ull);
-                        };
-                        const uint64_t xv = ext(ptop, need_v);
+                        const uint64_t q0 = rdlane64_u(wq, j), q1 = rdlane64_u(wq, j + 1), q2 = rdlane64_u(wq, j + 2);
+                        const uint64_t lo = (q0 >> r) | ((q1 << 1) << (63 - r)), hi = (q1 >> r) | ((q2 << 1) << (63 - r));
+                        const uint32_t al = (uint32_t)(8 * bend - left);  // 0..7: the chunk's top bits that lie above `left`
+                        const uint64_t H = (hi << al) | ((lo >> 1) >> (63 - al)), L = lo << al;  // `left` is bit 128 now
+                        const uint64_t xv = (H >> 1) >> (63 - need_v);                            // the top need_v bits
+                        const uint64_t H2 = (H << need_v) | ((L >> 1) >> (63 - need_v));
                         const uint32_t ov = eoy + (uint32_t)(xv >> (mlb + llb));
                         const uint32_t ml = emy + ((uint32_t)(xv >> llb) & ((1u << mlb) - 1u));
                         const uint32_t ll = ely + ((uint32_t)xv & ((1u << llb) - 1u));
                         if (more) {
-                            const uint32_t xs = (uint32_t)ext(ptop - need_v, need_s);
+                            const uint32_t xs = (uint32_t)((H2 >> 1) >> (63 - need_s));           // the next need_s bits
                             sl = (elx & 0xFFFF) + (xs >> (nbm + nbo));
                             sm = (emx & 0xFFFF) + ((xs >> nbo) & ((1u << nbm) - 1u));
                             so = (eox & 0xFFFF) + (xs & ((1u << nbo) - 1u));
