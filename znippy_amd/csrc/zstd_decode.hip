@@ -2245,13 +2245,15 @@ __global__ __launch_bounds__(128, 4) void k_fz_entropy(FzArgs a, const uint32_t 
                     const FseEntry *tm = sel2 == 0 ? S.dml : (sel2 == 1 ? &S.rle[2] : S.ml);
                     const uint8_t *const bbase = bsrc + uni(S.bs_off);
                     int32_t left = (int32_t)uni((uint32_t)S.bs_pos);
-                    // The bit reader.  512 bytes of the stream live in the wave's registers (lane k holds bytes
-                    // [wbase + 8k, +8)); a sequence takes the 16 bytes that end at its position out of them (three readlane
-                    // pairs and two funnel shifts — no memory access inside the serial chain), and its value bits and state
-                    // bits are two extractions from that 128-bit chunk: at most 59 + 27 bits, always inside it.
-                    // (Measured, ZNIPPY_DDBG: 1,220 cycles per sequence before and after — neither the per-sequence refill
-                    // load nor the per-sequence record store was the cost.  The trip is ~250 executed instructions, 180 of
-                    // them scalar, and a lone wave retires one dependent instruction every ~5 cycles: DESIGN.md 7c.)
+                    // Two stages per group of 64 sequences, because one wave gets one issue slot every 4 cycles and the slowest
+                    // block sets this kernel's time:
+                    //   A  the serial chain, and nothing else: the three states walk through their tables, the bit position
+                    //      moves; per sequence the wave notes (states, position) in lane (i mod 64).  The only bits it extracts
+                    //      are the next states' — out of 512 bytes of the stream kept in the wave's registers (lane k holds
+                    //      bytes [wbase + 8k, +8); two readlane pairs and a funnel shift, no memory access in the chain);
+                    //   B  the rest, 64 sequences at a time with lane = sequence: table entries again, 16 bytes of the stream
+                    //      ending at the lane's position, the three values, the sums; then the repeat-offset rules in order
+                    //      (scalar, only for groups that use a repeat code) and one coalesced store of the records.
                     uint64_t wq = 0;
                     int32_t wbase = INT32_MIN;
                     uint32_t sl = uni(S.st_ll), so = uni(S.st_of), sm = uni(S.st_ml);
@@ -2261,69 +2263,109 @@ __global__ __launch_bounds__(128, 4) void k_fz_entropy(FzArgs a, const uint32_t 
                     uint32_t sum_ll = 0, sum_ml = 0;
                     uint32_t r0 = FZ_SYM, r1 = FZ_SYM | (1u << 26), r2 = FZ_SYM | (2u << 26);
                     int err = 0;
-                    unsigned long long myrec = 0;
-                    for (uint32_t i = 0; i < nseq; i++) {
-                        const uint2 veo = to2[so], vem = tm2[sm], vel = tl2[sl];
-                        const uint32_t eox = uni(veo.x), eoy = uni(veo.y), emx = uni(vem.x), emy = uni(vem.y), elx = uni(vel.x), ely = uni(vel.y);
-                        const uint32_t ofb = eox >> 24, mlb = emx >> 24, llb = elx >> 24;
-                        const bool more = i + 1 < nseq;
-                        const uint32_t nbl = (elx >> 16) & 0xFF, nbm = (emx >> 16) & 0xFF, nbo = (eox >> 16) & 0xFF;
-                        const uint32_t need_v = ofb + mlb + llb, need_s = more ? nbl + nbm + nbo : 0u;
-                        if (ofb > 27) { err = E_UNSUP; if (lane == 0) S.why = 3; break; }
-                        if (left < (int32_t)(need_v + need_s)) { err = E_CORRUPT; break; }  // the stream ends before the sequence does
-                        // the chunk: stream bytes [cs, cs + 16), cs = (last byte needed) - 16; bytes in front of the stream read as zero
-                        // (the window may start 16 bytes before it), so every step below is branch-free
-                        const int32_t bend = (left + 7) >> 3, cs = bend - 16;
-                        if (wbase == INT32_MIN || cs < wbase) {
-                            const int32_t nb0 = ((cs + 24 + 7) & ~7) - 512;
-                            wbase = nb0 < -16 ? -16 : nb0;
-                            const int32_t o8 = wbase + 8 * (int32_t)lane;
-                            wq = o8 < 0 ? 0ull : load8_guard(bbase + o8, blob_end);
+                    for (uint32_t g0 = 0; g0 < nseq && !err; g0 += 64) {
+                        const uint32_t cnt = nseq - g0 < 64 ? nseq - g0 : 64;
+                        uint32_t my_st = 0;
+                        int32_t my_left = 0;
+                        bool bad_far = false, bad_end = false;
+                        // ---- A ----
+                        for (uint32_t g = 0; g < cnt; g++) {
+                            const uint32_t eox = uni(to2[so].x), emx = uni(tm2[sm].x), elx = uni(tl2[sl].x);  // next:16 | nbits:8 | addbits:8
+                            const uint32_t ofb = eox >> 24, need_v = ofb + (emx >> 24) + (elx >> 24);
+                            const uint32_t nbl = (elx >> 16) & 0xFF, nbm = (emx >> 16) & 0xFF, nbo = (eox >> 16) & 0xFF;
+                            const bool more = g0 + g + 1 < nseq;
+                            const uint32_t need_s = more ? nbl + nbm + nbo : 0u;
+                            // verdicts are collected, not branched on: one way out of the loop keeps its state in place (with early
+                            // exits the compiler copied every loop-carried register twice per trip); a stream that has gone wrong
+                            // only moves `left` below zero and reads zero bytes in front of the stream
+                            bad_far |= ofb > 27;
+                            bad_end |= left < (int32_t)(need_v + need_s);  // the stream ends before the sequence does
+                            if (lane == g) { my_st = so | (sm << 9) | (sl << 18); my_left = left; }
+                            if (more) {
+                                // the state bits end at `pos`: the 8 stream bytes that end there hold all of them (<= 27 bits)
+                                const int32_t pos0 = left - (int32_t)need_v, pos = pos0 < 0 ? 0 : pos0, bend = (pos + 7) >> 3, cs = bend - 8;
+                                if (wbase == INT32_MIN || cs < wbase) {
+                                    const int32_t nb0 = ((cs + 16 + 7) & ~7) - 512;
+                                    wbase = nb0 < -8 ? -8 : nb0;  // bytes in front of the stream read as zero
+                                    const int32_t o8 = wbase + 8 * (int32_t)lane;
+                                    wq = o8 < 0 ? 0ull : load8_guard(bbase + o8, blob_end);
+                                }
+                                const uint32_t d = (uint32_t)(cs - wbase), j = uni(d >> 3), r = uni((d & 7) * 8);
+                                const uint64_t q0 = rdlane64_u(wq, j), q1 = rdlane64_u(wq, j + 1);
+                                const uint64_t v8 = (q0 >> r) | ((q1 << 1) << (63 - r));
+                                const uint32_t al = (uint32_t)(8 * bend - pos);                    // 0..7 bits of the chunk lie above pos
+                                const uint32_t xs = (uint32_t)(((v8 << al) >> 1) >> (63 - need_s));  // its top need_s bits below pos
+                                sl = (elx & 0xFFFF) + (xs >> (nbm + nbo));
+                                sm = (emx & 0xFFFF) + ((xs >> nbo) & ((1u << nbm) - 1u));
+                                so = (eox & 0xFFFF) + (xs & ((1u << nbo) - 1u));
+                            }
+                            left -= (int32_t)(need_v + need_s);
                         }
-                        const uint32_t d = (uint32_t)(cs - wbase), j = uni(d >> 3), r = uni((d & 7) * 8);
-                        const uint64_t q0 = rdlane64_u(wq, j), q1 = rdlane64_u(wq, j + 1), q2 = rdlane64_u(wq, j + 2);
-                        const uint64_t lo = (q0 >> r) | ((q1 << 1) << (63 - r)), hi = (q1 >> r) | ((q2 << 1) << (63 - r));
-                        const uint32_t al = (uint32_t)(8 * bend - left);  // 0..7: the chunk's top bits that lie above `left`
-                        const uint64_t H = (hi << al) | ((lo >> 1) >> (63 - al)), L = lo << al;  // `left` is bit 128 now
-                        const uint64_t xv = (H >> 1) >> (63 - need_v);                            // the top need_v bits
-                        const uint64_t H2 = (H << need_v) | ((L >> 1) >> (63 - need_v));
-                        const uint32_t ov = eoy + (uint32_t)(xv >> (mlb + llb));
-                        const uint32_t ml = emy + ((uint32_t)(xv >> llb) & ((1u << mlb) - 1u));
-                        const uint32_t ll = ely + ((uint32_t)xv & ((1u << llb) - 1u));
-                        if (more) {
-                            const uint32_t xs = (uint32_t)((H2 >> 1) >> (63 - need_s));           // the next need_s bits
-                            sl = (elx & 0xFFFF) + (xs >> (nbm + nbo));
-                            sm = (emx & 0xFFFF) + ((xs >> nbo) & ((1u << nbm) - 1u));
-                            so = (eox & 0xFFFF) + (xs & ((1u << nbo) - 1u));
+                        if (bad_end) { err = E_CORRUPT; break; }
+                        if (bad_far) { err = E_UNSUP; if (lane == 0) S.why = 3; break; }
+                        // ---- B ----
+                        const bool on = lane < cnt;
+                        uint32_t ov = 4, ml = 0, ll = 0;
+                        if (on) {
+                            const uint2 eo = to2[my_st & 511], em = tm2[(my_st >> 9) & 511], el = tl2[my_st >> 18];
+                            const uint32_t ofb = eo.x >> 24, mlb = em.x >> 24, llb = el.x >> 24, need_v = ofb + mlb + llb;
+                            const int32_t bend = (my_left + 7) >> 3;
+                            uint64_t lo8 = 0, hi8 = 0;  // stream bytes [bend - 16, bend - 8) and [bend - 8, bend); zero in front of the stream
+                            if (bend >= 16) {
+                                __builtin_memcpy(&lo8, bbase + bend - 16, 8);
+                                __builtin_memcpy(&hi8, bbase + bend - 8, 8);
+                            } else {
+                                for (int32_t k = 0; k < 16; k++) {
+                                    const int32_t o = bend - 16 + k;
+                                    const uint64_t byte = o >= 0 ? bbase[o] : 0;
+                                    if (k < 8) lo8 |= byte << (8 * k); else hi8 |= byte << (8 * (k - 8));
+                                }
+                            }
+                            const uint32_t al = (uint32_t)(8 * bend - my_left);
+                            const uint64_t H = (hi8 << al) | ((lo8 >> 1) >> (63 - al));  // the lane's position is bit 64 now
+                            const uint64_t xv = (H >> 1) >> (63 - need_v);                 // the top need_v (<= 59) bits
+                            ov = eo.y + (uint32_t)(xv >> (mlb + llb));
+                            ml = em.y + ((uint32_t)(xv >> llb) & ((1u << mlb) - 1u));
+                            ll = el.y + ((uint32_t)xv & ((1u << llb) - 1u));
                         }
-                        left -= (int32_t)(need_v + need_s);
-                        sum_ll += ll; sum_ml += ml;
+                        {
+                            uint32_t a_ll = ll, a_ml = ml;
+#pragma unroll
+                            for (int dd = 32; dd >= 1; dd >>= 1) { a_ll += __shfl_xor(a_ll, dd); a_ml += __shfl_xor(a_ml, dd); }
+                            sum_ll += a_ll; sum_ml += a_ml;
+                        }
                         if (sum_ll + sum_ml > BLOCK_MAX) { err = E_UNSUP; if (lane == 0) S.why = 3; break; }
                         // repeat offsets (RFC 8878 3.1.1.5), against the symbolic incoming history
-                        uint32_t o;
-                        if (ov > 3) { o = ov - 3; r2 = r1; r1 = r0; r0 = o; }
-                        else {
-                            const uint32_t idx = ov - 1 + (ll == 0 ? 1u : 0u);
-                            if (idx == 0) o = r0;
-                            else {
-                                if (idx < 3) o = idx == 1 ? r1 : r2;
-                                else if (r0 & FZ_SYM) {  // incoming entry minus one more
-                                    o = r0 + 1;
-                                    if ((o & 0x3FFFFFFu) == 0x3FFFFFFu) { err = E_UNSUP; if (lane == 0) S.why = 3; break; }
-                                } else {
-                                    o = r0 - 1;
-                                    if (o == 0) { err = E_CORRUPT; break; }
+                        uint32_t o_mine = ov - 3;
+                        if (__ballot(on && ov <= 3) == 0ull && cnt >= 3) {
+                            r0 = rdlane_u(o_mine, cnt - 1); r1 = rdlane_u(o_mine, cnt - 2); r2 = rdlane_u(o_mine, cnt - 3);
+                        } else {
+                            for (uint32_t j = 0; j < cnt; j++) {
+                                const uint32_t ovj = rdlane_u(ov, j), llj = rdlane_u(ll, j);
+                                uint32_t o;
+                                if (ovj > 3) { o = ovj - 3; r2 = r1; r1 = r0; r0 = o; }
+                                else {
+                                    const uint32_t idx = ovj - 1 + (llj == 0 ? 1u : 0u);
+                                    if (idx == 0) o = r0;
+                                    else {
+                                        if (idx < 3) o = idx == 1 ? r1 : r2;
+                                        else if (r0 & FZ_SYM) {  // incoming entry minus one more
+                                            o = r0 + 1;
+                                            if ((o & 0x3FFFFFFu) == 0x3FFFFFFu) { err = E_UNSUP; if (lane == 0) S.why = 3; break; }
+                                        } else {
+                                            o = r0 - 1;
+                                            if (o == 0) { err = E_CORRUPT; break; }
+                                        }
+                                        if (idx > 1) r2 = r1;
+                                        r1 = r0; r0 = o;
+                                    }
                                 }
-                                if (idx > 1) r2 = r1;
-                                r1 = r0; r0 = o;
+                                if (lane == j) o_mine = o;
                             }
+                            if (err) break;
                         }
-                        // The record goes to lane (i mod 64); 64 of them leave in one coalesced store (the loop's only memory access
-                        // besides the window reload: the compiler waits for vmcnt(0) before the window's first use in every trip).
-                        if (lane == (i & 63)) myrec = (unsigned long long)ll | ((unsigned long long)ml << 17) | ((unsigned long long)o << 35);
-                        if ((i & 63) == 63) recs[i - 63 + lane] = myrec;
+                        if (on) recs[g0 + lane] = (unsigned long long)ll | ((unsigned long long)ml << 17) | ((unsigned long long)o_mine << 35);
                     }
-                    if (!err && (nseq & 63) && lane < (nseq & 63)) recs[(nseq & ~63u) + lane] = myrec;
                     if (!err && left != 0) err = E_CORRUPT;
                     ESTAMPZ(24);
                     if (lane == 0) {
