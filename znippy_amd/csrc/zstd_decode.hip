@@ -1853,6 +1853,7 @@ struct FzTmp {  // scratch of fse_read_ncount / fse_build / huf_read_tree: one p
     uint16_t sym_len[256];
     uint32_t seq_ll[128];  // 64 FseEntry: the FSE table of the Huffman weights
     uint32_t huf_log;
+    uint32_t bld[3];  // sequence tables whose counts wait in norm[64 k ..] (alphabet size; 0 = nothing to build): built by the wave after lane 0's parse
 };
 
 struct FzShared {
@@ -2010,13 +2011,11 @@ __device__ int fz_seq_tables(FzShared &S, FzTmp &T, const uint8_t *q, uint32_t n
         } else if (mode == 2) {
             int nsym, log;
             uint32_t used;
-            int rc = fse_read_ncount(T, q + p, n - p, maxlog[k], maxsym[k], &nsym, &log, &used);
+            // counts of a wanted table stay in norm[64 k ..] for the wave to build from (k_fz_entropy); a table that is only
+            // stepped over is read into the spare quarter
+            int rc = fse_read_ncount(T, q + p, n - p, maxlog[k], maxsym[k], &nsym, &log, &used, wanted ? 64 * k : 192);
             if (rc) return rc;
-            if (wanted) {
-                rc = fse_build(T, k == 0 ? S.ll : (k == 1 ? S.of : S.ml), nsym, log, kinds[k]);
-                if (rc) return rc;
-                S.sel[k] = 2; S.log_[k] = log;
-            }
+            if (wanted) { T.bld[k] = (uint32_t)nsym; S.sel[k] = 2; S.log_[k] = log; }
             p += used;
         } else if (wanted) miss |= 1u << k;
     }
@@ -2192,6 +2191,7 @@ __global__ __launch_bounds__(128, 4) void k_fz_entropy(FzArgs a, const uint32_t 
                     const uint8_t *q = bsrc + S.seq_pos;
                     const uint32_t qn = bsize - S.seq_pos;
                     uint32_t miss = 0, nseq = 0, bits_at = 0;
+                    S.tb.bld[0] = S.tb.bld[1] = S.tb.bld[2] = 0;
                     if (S.seq_pos >= bsize) err = E_TRUNC;
                     if (!err) err = fz_seq_tables(S, S.tb, q, qn, 7u, &miss, &nseq, &bits_at);
                     if (!err && nseq == 0 && bits_at != qn) err = E_CORRUPT;
@@ -2235,6 +2235,11 @@ __global__ __launch_bounds__(128, 4) void k_fz_entropy(FzArgs a, const uint32_t 
                     if (err) atomicMin(&S.err, err);
                 }
                 __builtin_amdgcn_wave_barrier();
+                if (S.err == 0 && uni(S.nseq))
+                    for (uint32_t k = 0; k < 3; k++)
+                        if (uni(S.tb.bld[k]))
+                            fse_build_wave(S.tb.norm + 64 * k, uni(S.tb.bld[k]), uni(S.log_[k]), k == 0 ? K_LL : (k == 1 ? K_OF : K_ML),
+                                           k == 0 ? S.ll : (k == 1 ? S.of : S.ml), S.tb.fse_next, lane);
                 ESTAMPZ(23);
                 const uint32_t nseq = uni(S.nseq);
                 if (a.dbg && lane == 0) atomicAdd(&a.dbg[25], (unsigned long long)nseq);
