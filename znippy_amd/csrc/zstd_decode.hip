@@ -1328,29 +1328,18 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES == 4 ? 4 : 1) void k_zstd_decod
                     const FseEntry *tl = sel0 == 0 ? S.dll : (sel0 == 1 ? &S.rle[0] : S.ll);
                     const FseEntry *to = sel1 == 0 ? S.dof : (sel1 == 1 ? &S.rle[1] : S.of);
                     const FseEntry *tm = sel2 == 0 ? S.dml : (sel2 == 1 ? &S.rle[2] : S.ml);
-                    // backward bit reader: `left` unread bits, a 64-bit container covering stream bits [cb, cb + 64);
-                    // bits below bit 0 read as zero and drive `left` negative, which is the corruption test
+                    // Two stages per group of 64 sequences (one wave gets one issue slot every 4 cycles, so the serial chain carries
+                    // nothing it does not have to; the same scheme as k_fz_entropy):
+                    //   A  the three states walk through their tables and the bit position moves; the wave notes (states, position)
+                    //      in lane (i mod 64).  The only bits it extracts are the next states', out of 512 bytes of the stream
+                    //      kept in its registers (lane k holds bytes [wbase + 8k, +8): two readlane pairs and a funnel shift);
+                    //   B  lane = sequence: table entries again, the 16 stream bytes that end at the lane's position, the three
+                    //      values; then repeat offsets (in order only for groups that use one) and the literal / match bounds.
+                    // Bytes in front of the stream read as zero; a sequence that needs more bits than are left is the corruption test.
                     const uint8_t *const bbase = src + uni(S.bs_off);
-                    int32_t left = (int32_t)uni((uint32_t)S.bs_pos), cb = 0;  // a block's bitstream is < 2^20 bits
-                    uint64_t c = 0;
-                    // the container always starts 8 bytes below the byte holding bit `left` (or at the stream's first
-                    // byte); past the first load it can only move down inside the stream, so it needs no bounds check
-                    auto refill = [&]() {
-                        int32_t b0 = ((left + 7) >> 3) - 8;
-                        if (b0 < 0) b0 = 0;
-                        uint64_t v;
-                        __builtin_memcpy(&v, bbase + b0, 8);
-                        c = uni64(v);
-                        cb = b0 * 8;
-                    };
-                    auto rd = [&](uint32_t nb) -> uint32_t {
-                        const int32_t sh = left - cb - (int32_t)nb;
-                        const uint64_t v = sh >= 0 ? (c >> sh) : (c << (sh < -63 ? 63 : -sh));
-                        left -= (int32_t)nb;
-                        return (uint32_t)v & ((1u << nb) - 1u);  // nb <= 31
-                    };
-                    if (((left + 7) >> 3) >= 8) refill();
-                    else c = uni64(load8_guard(bbase, blob_end));  // a stream shorter than 8 bytes: everything is in, cb stays 0
+                    int32_t left = (int32_t)uni((uint32_t)S.bs_pos);  // a block's bitstream is < 2^20 bits
+                    uint64_t wq = 0;
+                    int32_t wbase = INT32_MIN;
                     uint32_t sl = uni(S.st_ll), so = uni(S.st_of), sm = uni(S.st_ml);
                     uint32_t r0 = uni(S.rep[0]), r1 = uni(S.rep[1]), r2 = uni(S.rep[2]);
                     int err = 0;
@@ -1363,44 +1352,73 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES == 4 ? 4 : 1) void k_zstd_decod
                                 *const tm2 = reinterpret_cast<const uint2 *>(tm);
                     const bool lane0 = (tid & 63) == 0;
                     const bool predef = sel0 == 0 && sel1 == 0 && sel2 == 0;
-                    const uint2 rl = tl2[predef ? (tid & 63) : 0], rm = tm2[predef ? (tid & 63) : 0], ro = to2[predef ? (tid & 31) : 0];
+                    const uint32_t rlx = tl2[predef ? (tid & 63) : 0].x, rmx = tm2[predef ? (tid & 63) : 0].x, rox = to2[predef ? (tid & 31) : 0].x;
                     auto rdl = [](uint32_t v, uint32_t l) -> uint32_t { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)l); };
-                    for (uint32_t i = 0; i < bn; i++) {
-                        // entry = {next:16 | nbits:8 | addbits:8, base}
-                        uint32_t eox, eoy, emx, emy, elx, ely;
-                        if (predef) {  // predefined tables sit in registers, one entry per lane: a lookup is a v_readlane
-                            eox = rdl(ro.x, so); eoy = rdl(ro.y, so); emx = rdl(rm.x, sm); emy = rdl(rm.y, sm);
-                            elx = rdl(rl.x, sl); ely = rdl(rl.y, sl);
-                        } else {
-                            const uint2 veo = to2[so], vem = tm2[sm], vel = tl2[sl];
-                            eox = uni(veo.x); eoy = uni(veo.y); emx = uni(vem.x); emy = uni(vem.y); elx = uni(vel.x); ely = uni(vel.y);
-                        }
-                        const uint32_t ofb = eox >> 24, mlb = emx >> 24, llb = elx >> 24;
-                        const bool more = seq_done + i + 1 < nseq;
-                        const uint32_t nbl = (elx >> 16) & 0xFF, nbm = (emx >> 16) & 0xFF, nbo = (eox >> 16) & 0xFF;
-                        const int32_t need_v = (int32_t)(ofb + mlb + llb), need_s = more ? (int32_t)(nbl + nbm + nbo) : 0;
-                        if (left - cb < need_v + need_s && cb > 0) refill();  // usually the one refill of the sequence
-                        const uint32_t ov = eoy + rd(ofb > 31 ? 31 : ofb);
-                        if (need_v + need_s > 56 && left - cb < need_v + need_s - (int32_t)ofb && cb > 0) refill();  // long offsets
-                        const uint32_t ml = emy + rd(mlb);
-                        const uint32_t ll = ely + rd(llb);
-                        if (more) {
-                            if (need_v + need_s > 56 && left - cb < need_s && cb > 0) refill();
-                            sl = (elx & 0xFFFF) + rd(nbl);
-                            sm = (emx & 0xFFFF) + rd(nbm);
-                            so = (eox & 0xFFFF) + rd(nbo);
-                        }
-                        if (left < 0) { err = E_CORRUPT; break; }
-                        if (lane0) { S.seq_ll[buf][i] = ll; S.seq_ml[buf][i] = ml; S.seq_off[buf][i] = ov; }  // raw offset value: resolved below
-                    }
-                    // Everything that is not the bitstream's serial dependency happens 64 sequences at a time: repeat
-                    // offsets (only groups that contain one walk their sequences in order), literal / match bounds.
                     const uint32_t lane = tid & 63;
                     for (uint32_t g0 = 0; g0 < bn && !err; g0 += 64) {
                         const uint32_t cnt = bn - g0 < 64 ? bn - g0 : 64;
+                        uint32_t my_st = 0;
+                        int32_t my_left = 0;
+                        bool bad_end = false;
+                        // ---- A ----
+                        for (uint32_t g = 0; g < cnt; g++) {
+                            // entry.x = next:16 | nbits:8 | addbits:8 (predefined tables sit in registers, one entry per lane)
+                            uint32_t eox, emx, elx;
+                            if (predef) { eox = rdl(rox, so); emx = rdl(rmx, sm); elx = rdl(rlx, sl); }
+                            else { eox = uni(to2[so].x); emx = uni(tm2[sm].x); elx = uni(tl2[sl].x); }
+                            const uint32_t need_v = (eox >> 24) + (emx >> 24) + (elx >> 24);
+                            const uint32_t nbl = (elx >> 16) & 0xFF, nbm = (emx >> 16) & 0xFF, nbo = (eox >> 16) & 0xFF;
+                            const bool more = seq_done + g0 + g + 1 < nseq;
+                            const uint32_t need_s = more ? nbl + nbm + nbo : 0u;
+                            bad_end |= left < (int32_t)(need_v + need_s);
+                            if (lane == g) { my_st = so | (sm << 9) | (sl << 18); my_left = left; }
+                            if (more) {
+                                const int32_t pos0 = left - (int32_t)need_v, pos = pos0 < 0 ? 0 : pos0, bend = (pos + 7) >> 3, cs = bend - 8;
+                                if (wbase == INT32_MIN || cs < wbase) {
+                                    const int32_t nb0 = ((cs + 16 + 7) & ~7) - 512;
+                                    wbase = nb0 < -8 ? -8 : nb0;
+                                    const int32_t o8 = wbase + 8 * (int32_t)lane;
+                                    wq = o8 < 0 ? 0ull : load8_guard(bbase + o8, blob_end);
+                                }
+                                const uint32_t d = (uint32_t)(cs - wbase), j = uni(d >> 3), r = uni((d & 7) * 8);
+                                const uint64_t q0 = rdlane64_u(wq, j), q1 = rdlane64_u(wq, j + 1);
+                                const uint64_t v8 = (q0 >> r) | ((q1 << 1) << (63 - r));
+                                const uint32_t al = (uint32_t)(8 * bend - pos);
+                                const uint32_t xs = (uint32_t)(((v8 << al) >> 1) >> (63 - need_s));
+                                sl = (elx & 0xFFFF) + (xs >> (nbm + nbo));
+                                sm = (emx & 0xFFFF) + ((xs >> nbo) & ((1u << nbm) - 1u));
+                                so = (eox & 0xFFFF) + (xs & ((1u << nbo) - 1u));
+                            }
+                            left -= (int32_t)(need_v + need_s);
+                        }
+                        if (bad_end) { err = E_CORRUPT; break; }
+                        // ---- B ----
                         const bool on = lane < cnt;
-                        const uint32_t ll = on ? S.seq_ll[buf][g0 + lane] : 0, ml = on ? S.seq_ml[buf][g0 + lane] : 0;
-                        const uint32_t ov = on ? S.seq_off[buf][g0 + lane] : 4;
+                        uint32_t ov = 4, ml = 0, ll = 0;
+                        if (on) {
+                            const uint2 eo = to2[my_st & 511], em = tm2[(my_st >> 9) & 511], el = tl2[my_st >> 18];
+                            const uint32_t ofb = eo.x >> 24, mlb = em.x >> 24, llb = el.x >> 24, need_v = ofb + mlb + llb;
+                            const int32_t bend = (my_left + 7) >> 3;
+                            uint64_t lo8 = 0, hi8 = 0;  // stream bytes [bend - 16, bend - 8) and [bend - 8, bend)
+                            if (bend >= 16) {
+                                __builtin_memcpy(&lo8, bbase + bend - 16, 8);
+                                __builtin_memcpy(&hi8, bbase + bend - 8, 8);
+                            } else {
+                                for (int32_t k = 0; k < 16; k++) {
+                                    const int32_t o = bend - 16 + k;
+                                    const uint64_t byte = o >= 0 ? bbase[o] : 0;
+                                    if (k < 8) lo8 |= byte << (8 * k); else hi8 |= byte << (8 * (k - 8));
+                                }
+                            }
+                            const uint32_t al = (uint32_t)(8 * bend - my_left);
+                            const uint64_t H = (hi8 << al) | ((lo8 >> 1) >> (63 - al));
+                            const uint64_t xv = (H >> 1) >> (63 - need_v);  // need_v <= 63
+                            ov = eo.y + (uint32_t)(xv >> (mlb + llb));
+                            ml = em.y + ((uint32_t)(xv >> llb) & ((1u << mlb) - 1u));
+                            ll = el.y + ((uint32_t)xv & ((1u << llb) - 1u));
+                            S.seq_ll[buf][g0 + lane] = ll;
+                            S.seq_ml[buf][g0 + lane] = ml;
+                        }
                         uint32_t offset = ov - 3;
                         if (__ballot(on && ov <= 3) != 0ull || cnt < 3) {
                             // A block item starts with an undefined history (all 0): a repeat code is good once the block's
