@@ -1384,6 +1384,16 @@ int znippy_decompress(znippy_ctx *ctx, const void *frame, size_t n, void *dst, s
 }  // extern "C"
 
 
+// A run's results (offsets, sizes, digests: 48 bytes per round) leave through this kernel, written straight into the
+// slot's pinned host mirror (device-visible: hipHostMalloc).  hipMemcpyAsync did the same with a blit kernel of its own,
+// but the CALL blocked 6.7-7.4 ms once per table — in the third run, whatever had been copied before (time marks around
+// every HIP call of that run: everything else 0.06 ms together; tools/write_steps.py) — which put one 7-12 ms step among
+// bench.py's 0.8 ms write steps, behind its three warm-up steps: a quarter of the write leg's rate.  A launch has no such
+// mode.
+__global__ __launch_bounds__(256) void k_results_out(uint4 *dst, const uint4 *src, uint32_t n16) {
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n16; i += gridDim.x * 256) dst[i] = src[i];
+}
+
 // ---- write side ------------------------------------------------------------------------------------
 extern "C" int znippy_encode_hash_rounds_async(znippy_ctx *ctx, znippy_rounds *r, const void *d_src, void *d_blob_out,
                                                uint64_t blob_cap) {
@@ -1492,7 +1502,13 @@ extern "C" int znippy_encode_hash_rounds_async(znippy_ctx *ctx, znippy_rounds *r
     // the next run
     HIPCHK(ctx, hipEventRecord(r->ev_enc[slot], s));
     HIPCHK(ctx, hipStreamWaitEvent(ctx->copy, r->ev_enc[slot], 0));
-    HIPCHK(ctx, hipMemcpyAsync(r->h_res, r->res, r->res_bytes, hipMemcpyDeviceToHost, ctx->copy));
+    {
+        const uint32_t n16 = (uint32_t)((r->res_bytes + 15) / 16);  // both buffers are allocated in whole 16-byte units and more
+        // few workgroups: the copy only has to be done before the next run but one needs the slab, and it shares the chip with
+        // the next run's kernels (4-16 workgroups: 0.84 ms per C2 write step, 64: 0.88, 1,024: 0.90)
+        hipLaunchKernelGGL(k_results_out, dim3(std::min<uint32_t>((n16 + 255) / 256, 8)), dim3(256), 0, ctx->copy,
+                           reinterpret_cast<uint4 *>(r->h_res), reinterpret_cast<const uint4 *>(r->res), n16);
+    }
     HIPCHK(ctx, hipEventRecord(r->ev_res[slot], ctx->copy));
     r->run_seq++;
     HIPCHK(ctx, hipGetLastError());
