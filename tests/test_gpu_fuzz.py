@@ -132,6 +132,17 @@ def test_every_bit_of_block_heads_in_big_frames(gpu_ctx, oracle):
     _run(gpu_ctx, oracle, bases, 96, 6, 20, 100, mutants=_all_bit_flips)
 
 
+def test_every_bit_of_entropy_headers_in_text_frames(gpu_ctx, oracle):
+    """The general decoder's table readers against the oracle, exhaustively: every single-bit flip of the first 220 bytes
+    (Huffman tree description with FSE-compressed or direct weights, stream sizes, sequence count, modes, the three FSE
+    table descriptions, the start of the bitstreams) and of the last 16 of single-block frames of non-periodic text —
+    libzstd's at two levels and this build's own higher-tier ones.  The tree is read and the tables are built by whole
+    waves (huf_read_tree_wave, fse_build_wave): every verdict has to equal the one-lane oracle's."""
+    bases = [(gen.pseudo_text(6000, 21), 19), (gen.pseudo_text(20000, 22), 3), (gen.pseudo_text(3000, 23), 19),
+             (bytes(np.random.default_rng(24).integers(0, 256, 9000, dtype=np.uint8) // 3 * 3), 19)]
+    _run(gpu_ctx, oracle, bases, 220, 9, 200, 1500, mutants=_all_bit_flips)
+
+
 def test_mutant_table_is_decoded_the_same_every_time(gpu_ctx, oracle):
     """The exhaustive single-bit table (role-split kernel + its left-over list + general decoder in one run) ten times
     over: the digests, statuses and counters of every run equal the first one's.  (A wrong digest for one valid row in
