@@ -926,6 +926,9 @@ __device__ int huf_read_tree_wave(Shared &S, const uint8_t *src, uint32_t n, con
     return 0;
 }
 
+__device__ int fz_huf_stream(const uint16_t *huf, uint32_t log, const uint8_t *p, uint32_t n, const uint8_t *blob_end,
+                             uint8_t *dst, uint32_t n_out);
+
 // One lane decodes one Huffman stream (n_out symbols) from [p, p+n) into dst.
 template <class Shared>
 __device__ int huf_decode_stream(const Shared &S, const uint8_t *p, uint32_t n, const uint8_t *blob_end,
@@ -1237,8 +1240,9 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES == 4 ? 4 : 1) void k_zstd_decod
                 }
                 DSTAMP(7);
                 if (tid < S.n_streams) {
-                    int rc = huf_decode_stream(S, bsrc + S.stream_off[tid], S.stream_len[tid], blob_end,
-                                               lit_buf + S.stream_out[tid], S.stream_n[tid]);
+                    // (four symbols per 8-byte load while 64 or more bits are unread: the foreign-frame path's stream decoder)
+                    int rc = fz_huf_stream(S.huf, S.huf_log, bsrc + S.stream_off[tid], S.stream_len[tid], blob_end,
+                                           lit_buf + S.stream_out[tid], S.stream_n[tid]);
                     if (rc) atomicMin(&S.err, rc);
                 }
                 __syncthreads();  // literal bytes visible to the whole workgroup (same CU)
