@@ -277,3 +277,38 @@ def _blocks_any(frame):
         p += 3 + (1 if typ == 1 else size)
         if last:
             return out
+
+
+@pytest.mark.parametrize("kind,cap", [("text", 4e6), ("binary", 12e6)])
+def test_real_files_of_the_image_through_both_tiers(ctxs, oracle, kind, cap):
+    """Files found in the image (Python / C++ sources; shared objects in 8 MiB rounds), one Round each, through both
+    tiers: every frame is decoded by libzstd and compared, the table comes back through the GPU read path with every
+    digest verified, and the higher tier is the smaller one."""
+    import torch
+    import workloads
+    from znippy_amd import hip
+    ents = workloads.image_corpus(kind, cap, whole_files=False)
+    assert len(ents) >= 2
+    lens = np.array([len(e) for e in ents], np.uint64)
+    offs = np.concatenate([[0], np.cumsum(lens)[:-1]]).astype(np.uint64)
+    total = int(lens.sum())
+    d_src = torch.from_numpy(np.frombuffer(b"".join(ents) + bytes(64), np.uint8).copy()).cuda()
+    sizes = {}
+    for label, ctx in zip(("fast", "high"), ctxs):
+        rt = hip.RoundTable(ctx, offs, lens)
+        d_blob = torch.zeros(rt.blob_bound() + 64, dtype=torch.uint8, device="cuda")
+        enc = {k: (v.copy() if hasattr(v, "copy") else v) for k, v in rt.encode_hash(d_src, d_blob).items()}
+        sizes[label] = int(enc["blob_size"].sum())
+        hb = d_blob.cpu().numpy()
+        for i, e in enumerate(ents):
+            f = hb[int(enc["blob_offset"][i]):int(enc["blob_offset"][i] + enc["blob_size"][i])].tobytes()
+            assert oracle.libzstd_decompress(f, max(len(e), 1)) == e, (label, i, len(e))
+            assert bytes(enc["checksum"][i]) == oracle.blake3(e)
+        rows = hip.RowTable(ctx, enc["blob_offset"], enc["blob_size"], lens, offs, None, enc["checksum"])
+        d_out = torch.zeros(total + 64, dtype=torch.uint8, device="cuda")
+        c, corrupt, status = rows.decode_verify(d_blob, d_out)
+        assert c["corrupt_rows"] == 0 and c["decode_errors"] == 0 and c["verified_bytes"] == total
+        assert bool((d_out[:total] == d_src[:total]).all())
+        rows.close()
+        rt.close()
+    assert sizes["high"] < sizes["fast"] < total

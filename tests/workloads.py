@@ -124,9 +124,10 @@ def libzstd_compress_adv(data, level=19, checksum=False, window_log=0) -> bytes:
         z.ZSTD_freeCCtx(cctx)
 
 
-def image_corpus(kind, cap):
+def image_corpus(kind, cap, whole_files=True):
     """Real files found in the image (not a BASELINE config): kind "text" = Python / C++ sources, "binary" = shared
-    objects; cut into rounds of at most 8 MiB, up to cap bytes."""
+    objects; cut into rounds of at most 8 MiB, up to cap bytes (whole_files: the file that crosses the cap is taken to its end —
+    the corpus of the real-data reports — otherwise the cut is at the round that crosses it)."""
     import glob, os
     pats = {"text": ["/usr/lib/python3.10/**/*.py", "/usr/lib/python3/dist-packages/**/*.py", "/opt/rocm/include/**/*.h*"],
             "binary": ["/opt/rocm/lib/*.so*", "/usr/lib/x86_64-linux-gnu/*.so*"]}[kind]
@@ -144,6 +145,8 @@ def image_corpus(kind, cap):
             for o in range(0, len(b), 8 << 20):
                 out.append(b[o:o + (8 << 20)])
                 tot += len(out[-1])
+                if tot >= cap and not whole_files:
+                    return out
             if tot >= cap:
                 return out
     return out
