@@ -45,6 +45,8 @@ for kind, cap in (("text", 64e6), ("binary", cap_bin)):
             td.append(time.perf_counter() - t0)
         same = bool((d_out[:total] == d_src[:total]).all())
         kt = {k: round(v, 2) for k, v in dict(ctx.kernel_times()).items() if v > 0.05}
-        print(f"[{kind}] level {level}: ratio {int(enc['blob_size'].sum())/total:.4f}  encode {min(ts)*1e3:.1f} ms ({total/2**20/min(ts):.0f} MB/s)  "
+        import hashlib
+        dig = hashlib.sha1(hb[:int(enc['blob_size'].sum())].tobytes()).hexdigest()[:16]
+        print(f"[{kind}] level {level}: blob sha1 {dig} ratio {int(enc['blob_size'].sum())/total:.4f}  encode {min(ts)*1e3:.1f} ms ({total/2**20/min(ts):.0f} MB/s)  "
               f"libzstd-bad {bad}  gpu decode {min(td)*1e3:.1f} ms same={same} corrupt={c['corrupt_rows']} errs={c['decode_errors']} {kt}", flush=True)
         rows.close(); rt.close(); ctx.close()
