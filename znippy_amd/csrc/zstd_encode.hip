@@ -1130,9 +1130,10 @@ __global__ __launch_bounds__(64) void k_zstd_encode(EncodeArgs a) {
                     // position's next 8 bytes once and every candidate's that is still alive, instead of one extension loop
                     // per candidate one after the other.  Lengths, and with them the choice below, are what the separate loops
                     // gave (the common prefix, capped at LMAX and at the block's end): the blobs of the real-data corpora are
-                    // bit-identical (tools/ratio.py prints their SHA-1), the matcher is 4-6 % faster.  A window is still
-                    // ~17,000 cycles on binaries (ZNIPPY_EDBG): three dependent round trips — candidate check, extension,
-                    // the bytes in front — before the pick.
+                    // bit-identical (tools/ratio.py prints their SHA-1).  Together with the 24-byte first load below the matcher
+                    // is 13-18 % faster (binaries 75 -> 65 ms, text 25 -> 21 ms); a window is still ~15,000 cycles on binaries
+                    // (ZNIPPY_EDBG): what is left is the address processing of the wave's scattered loads, three dozen
+                    // instructions of 64 different lines each.
                     uint32_t cc[11], len[11];
                     uint32_t alive = 0;
                     const uint32_t rw[3] = {r0w, r1w, r2w};
@@ -1145,15 +1146,44 @@ __global__ __launch_bounds__(64) void k_zstd_encode(EncodeArgs a) {
                     }
 #pragma unroll
                     for (int i = 0; i < 3; i++) cc[8 + i] = (rw[i] && pos >= rw[i]) ? pos - rw[i] : 0xFFFFFFFFu;
-#pragma unroll
-                    for (int w = 0; w < 11; w++) {
-                        const uint32_t cvw = cc[w] != 0xFFFFFFFFu ? ld32(inb + cc[w]) : ~v;
-                        len[w] = 0;
-                        if (cvw == v && cc[w] != 0xFFFFFFFFu) { alive |= 1u << w; len[w] = 4; }
-                    }
+                    uint32_t bk[11];
                     {
                         const uint32_t lim = nq - pos < LMAX ? nq - pos : LMAX;
                         uint32_t k = 4;
+                        if (pos >= 8 && pos + 16 <= nq) {
+                            // the first round trip brings 24 bytes around every candidate (8 in front, 16 from it on) and around the
+                            // position: most matches end inside them, and what a chosen match can take over in front of it is
+                            // known without a round trip of its own
+                            uint64_t x0, x1, x2;
+                            __builtin_memcpy(&x0, inb + pos - 8, 8);
+                            __builtin_memcpy(&x1, inb + pos, 8);
+                            __builtin_memcpy(&x2, inb + pos + 8, 8);
+#pragma unroll
+                            for (int w = 0; w < 11; w++) {
+                                len[w] = 0; bk[w] = 0;
+                                if (cc[w] != 0xFFFFFFFFu) {
+                                    uint64_t y0 = ~x0, y1, y2;
+                                    __builtin_memcpy(&y1, inb + cc[w], 8);
+                                    __builtin_memcpy(&y2, inb + cc[w] + 8, 8);
+                                    if (cc[w] >= 8) __builtin_memcpy(&y0, inb + cc[w] - 8, 8);
+                                    const uint64_t d1 = x1 ^ y1, d2 = x2 ^ y2, d0 = x0 ^ y0;
+                                    if ((uint32_t)d1 == 0) {
+                                        if (d1) len[w] = (uint32_t)(__ffsll((long long)d1) - 1) >> 3;
+                                        else if (d2) len[w] = 8 + ((uint32_t)(__ffsll((long long)d2) - 1) >> 3);
+                                        else { len[w] = 16; if (lim > 16) alive |= 1u << w; }
+                                        bk[w] = cc[w] >= 8 ? (d0 ? (uint32_t)__clzll((long long)d0) >> 3 : 8u) : 0u;
+                                    }
+                                }
+                            }
+                            k = 16;
+                        } else {
+#pragma unroll
+                            for (int w = 0; w < 11; w++) {
+                                const uint32_t cvw = cc[w] != 0xFFFFFFFFu ? ld32(inb + cc[w]) : ~v;
+                                len[w] = 0; bk[w] = 0;
+                                if (cvw == v && cc[w] != 0xFFFFFFFFu) { alive |= 1u << w; len[w] = 4; }
+                            }
+                        }
                         while (alive && k + 8 <= lim) {
                             uint64_t x;
                             __builtin_memcpy(&x, inb + pos + k, 8);
@@ -1176,9 +1206,10 @@ __global__ __launch_bounds__(64) void k_zstd_encode(EncodeArgs a) {
                                 len[w] = kk;
                             }
                     }
+                    uint32_t pick = 11;
 #pragma unroll
                     for (int w = 0; w < 8; w++)
-                        if (len[w] > mlen) { mlen = len[w]; cand = cc[w]; }  // ties stay with the newer (closer) one
+                        if (len[w] > mlen) { mlen = len[w]; cand = cc[w]; pick = w; }  // ties stay with the newer (closer) one
                     if (mlen) {
                         const uint32_t off = pos - cand;
                         if ((mlen == 4 && off > 2048u) || (mlen == 5 && off > 32768u)) mlen = 0;
@@ -1189,15 +1220,21 @@ __global__ __launch_bounds__(64) void k_zstd_encode(EncodeArgs a) {
                         for (int i = 0; i < 3; i++)
                             if (len[8 + i]) {
                                 const uint32_t k = len[8 + i];
-                                if (k + 1 > score || (i == 0 && k + 1 >= score)) { score = k + 1; mlen = k; cand = cc[8 + i]; }
+                                if (k + 1 > score || (i == 0 && k + 1 >= score)) { score = k + 1; mlen = k; cand = cc[8 + i]; pick = 8 + i; }
                             }
                     }
                     if (mlen && cand >= 8) {  // bytes in front of the match that agree too (up to 8): literals it can take over
-                        uint64_t x, y;
-                        __builtin_memcpy(&x, inb + pos - 8, 8);
-                        __builtin_memcpy(&y, inb + cand - 8, 8);
-                        const uint64_t d = x ^ y;
-                        back = d ? (uint32_t)__clzll((long long)d) >> 3 : 8u;
+                        if (pos >= 8 && pos + 16 <= nq) {
+#pragma unroll
+                            for (int w = 0; w < 11; w++)
+                                if (pick == (uint32_t)w) back = bk[w];
+                        } else {
+                            uint64_t x, y;
+                            __builtin_memcpy(&x, inb + pos - 8, 8);
+                            __builtin_memcpy(&y, inb + cand - 8, 8);
+                            const uint64_t d = x ^ y;
+                            back = d ? (uint32_t)__clzll((long long)d) >> 3 : 8u;
+                        }
                     }
                 }
                 const uint64_t hitm = __ballot(mlen != 0);
