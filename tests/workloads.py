@@ -137,7 +137,8 @@ def image_corpus(kind, cap, whole_files=True):
             if os.path.islink(f) or not os.path.isfile(f):
                 continue
             try:
-                b = open(f, "rb").read()
+                with open(f, "rb") as fh:  # (not more of a file than the cap can take: the first shared object is 1 GB)
+                    b = fh.read() if whole_files else fh.read(int(cap - tot) + (8 << 20))
             except OSError:
                 continue
             if not b:
