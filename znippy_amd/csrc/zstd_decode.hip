@@ -1369,7 +1369,7 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES == 4 ? 4 : 1) void k_zstd_decod
                             // entry.x = next:16 | nbits:8 | addbits:8 (predefined tables sit in registers, one entry per lane)
                             uint32_t eox, emx, elx;
                             if (predef) { eox = rdl(rox, so); emx = rdl(rmx, sm); elx = rdl(rlx, sl); }
-                            else { eox = uni(to2[so].x); emx = uni(tm2[sm].x); elx = uni(tl2[sl].x); }
+                            else { const uint32_t vo_ = to2[so].x, vm_ = tm2[sm].x, vl_ = tl2[sl].x; eox = uni(vo_); emx = uni(vm_); elx = uni(vl_); }  // three reads in flight, then the waits
                             const uint32_t need_v = (eox >> 24) + (emx >> 24) + (elx >> 24);
                             const uint32_t nbl = (elx >> 16) & 0xFF, nbm = (emx >> 16) & 0xFF, nbo = (eox >> 16) & 0xFF;
                             const bool more = seq_done + g0 + g + 1 < nseq;
@@ -2297,7 +2297,8 @@ __global__ __launch_bounds__(128, 4) void k_fz_entropy(FzArgs a, const uint32_t 
                         bool bad_far = false, bad_end = false;
                         // ---- A ----
                         for (uint32_t g = 0; g < cnt; g++) {
-                            const uint32_t eox = uni(to2[so].x), emx = uni(tm2[sm].x), elx = uni(tl2[sl].x);  // next:16 | nbits:8 | addbits:8
+                            const uint32_t vo_ = to2[so].x, vm_ = tm2[sm].x, vl_ = tl2[sl].x;  // three LDS reads in flight together ...
+                            const uint32_t eox = uni(vo_), emx = uni(vm_), elx = uni(vl_);    // ... before the first is waited for (next:16 | nbits:8 | addbits:8)
                             const uint32_t ofb = eox >> 24, need_v = ofb + (emx >> 24) + (elx >> 24);
                             const uint32_t nbl = (elx >> 16) & 0xFF, nbm = (emx >> 16) & 0xFF, nbo = (eox >> 16) & 0xFF;
                             const bool more = g0 + g + 1 < nseq;
