@@ -120,6 +120,15 @@ __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {
     return v;
 }
 
+// lane l (uniform) of four registers replaced by four uniform values: four v_writelane behind one lane select in M0
+// (one wait state behind its write), instead of a compare and four selects fed from four moves
+__device__ __forceinline__ void wrlane4_u(uint32_t &v0, uint32_t &v1, uint32_t &v2, uint32_t &v3, uint32_t x0, uint32_t x1, uint32_t x2,
+                                          uint32_t x3, uint32_t l) {
+    asm volatile("s_mov_b32 m0, %8\n\ts_nop 0\n\tv_writelane_b32 %0, %4, m0\n\tv_writelane_b32 %1, %5, m0\n\t"
+                 "v_writelane_b32 %2, %6, m0\n\tv_writelane_b32 %3, %7, m0"
+                 : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3) : "s"(x0), "s"(x1), "s"(x2), "s"(x3), "s"(l) : "m0");
+}
+
 __device__ __forceinline__ uint64_t rdlane64_u(uint64_t v, uint32_t l) {
     return ((uint64_t)rdlane_u((uint32_t)(v >> 32), l) << 32) | rdlane_u((uint32_t)v, l);
 }
@@ -1361,9 +1370,8 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES == 4 ? 4 : 1) void k_zstd_decod
                     const uint32_t lane = tid & 63;
                     for (uint32_t g0 = 0; g0 < bn && !err; g0 += 64) {
                         const uint32_t cnt = bn - g0 < 64 ? bn - g0 : 64;
-                        uint32_t my_st = 0;
-                        int32_t my_left = 0;
-                        bool bad_end = false;
+                        uint32_t my_so = 0, my_sm = 0, my_sl = 0, my_leftu = 0;
+                        int32_t margin = 0;
                         // ---- A ----
                         for (uint32_t g = 0; g < cnt; g++) {
                             // entry.x = next:16 | nbits:8 | addbits:8 (predefined tables sit in registers, one entry per lane)
@@ -1374,8 +1382,8 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES == 4 ? 4 : 1) void k_zstd_decod
                             const uint32_t nbl = (elx >> 16) & 0xFF, nbm = (emx >> 16) & 0xFF, nbo = (eox >> 16) & 0xFF;
                             const bool more = seq_done + g0 + g + 1 < nseq;
                             const uint32_t need_s = more ? nbl + nbm + nbo : 0u;
-                            bad_end |= left < (int32_t)(need_v + need_s);
-                            if (lane == g) { my_st = so | (sm << 9) | (sl << 18); my_left = left; }
+                            margin = min(margin, left - (int32_t)(need_v + need_s));  // below zero: the stream ends before a sequence does
+                            wrlane4_u(my_so, my_sm, my_sl, my_leftu, so, sm, sl, (uint32_t)left, g);
                             if (more) {
                                 const int32_t pos0 = left - (int32_t)need_v, pos = pos0 < 0 ? 0 : pos0, bend = (pos + 7) >> 3, cs = bend - 8;
                                 if (wbase == INT32_MIN || cs < wbase) {
@@ -1395,14 +1403,14 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES == 4 ? 4 : 1) void k_zstd_decod
                             }
                             left -= (int32_t)(need_v + need_s);
                         }
-                        if (bad_end) { err = E_CORRUPT; break; }
+                        if (margin < 0) { err = E_CORRUPT; break; }
                         // ---- B ----
                         const bool on = lane < cnt;
                         uint32_t ov = 4, ml = 0, ll = 0;
                         if (on) {
-                            const uint2 eo = to2[my_st & 511], em = tm2[(my_st >> 9) & 511], el = tl2[my_st >> 18];
+                            const uint2 eo = to2[my_so], em = tm2[my_sm], el = tl2[my_sl];
                             const uint32_t ofb = eo.x >> 24, mlb = em.x >> 24, llb = el.x >> 24, need_v = ofb + mlb + llb;
-                            const int32_t bend = (my_left + 7) >> 3;
+                            const int32_t my_left = (int32_t)my_leftu, bend = (my_left + 7) >> 3;
                             uint64_t lo8 = 0, hi8 = 0;  // stream bytes [bend - 16, bend - 8) and [bend - 8, bend)
                             if (bend >= 16) {
                                 __builtin_memcpy(&lo8, bbase + bend - 16, 8);
@@ -2292,9 +2300,8 @@ __global__ __launch_bounds__(128, 4) void k_fz_entropy(FzArgs a, const uint32_t 
                     int err = 0;
                     for (uint32_t g0 = 0; g0 < nseq && !err; g0 += 64) {
                         const uint32_t cnt = nseq - g0 < 64 ? nseq - g0 : 64;
-                        uint32_t my_st = 0;
-                        int32_t my_left = 0;
-                        bool bad_far = false, bad_end = false;
+                        uint32_t my_so = 0, my_sm = 0, my_sl = 0, my_leftu = 0, max_ofb = 0;
+                        int32_t margin = 0;
                         // ---- A ----
                         for (uint32_t g = 0; g < cnt; g++) {
                             const uint32_t vo_ = to2[so].x, vm_ = tm2[sm].x, vl_ = tl2[sl].x;  // three LDS reads in flight together ...
@@ -2306,9 +2313,9 @@ __global__ __launch_bounds__(128, 4) void k_fz_entropy(FzArgs a, const uint32_t 
                             // verdicts are collected, not branched on: one way out of the loop keeps its state in place (with early
                             // exits the compiler copied every loop-carried register twice per trip); a stream that has gone wrong
                             // only moves `left` below zero and reads zero bytes in front of the stream
-                            bad_far |= ofb > 27;
-                            bad_end |= left < (int32_t)(need_v + need_s);  // the stream ends before the sequence does
-                            if (lane == g) { my_st = so | (sm << 9) | (sl << 18); my_left = left; }
+                            max_ofb = max(max_ofb, ofb);
+                            margin = min(margin, left - (int32_t)(need_v + need_s));  // below zero: the stream ends before a sequence does
+                            wrlane4_u(my_so, my_sm, my_sl, my_leftu, so, sm, sl, (uint32_t)left, g);
                             if (more) {
                                 // the state bits end at `pos`: the 8 stream bytes that end there hold all of them (<= 27 bits)
                                 const int32_t pos0 = left - (int32_t)need_v, pos = pos0 < 0 ? 0 : pos0, bend = (pos + 7) >> 3, cs = bend - 8;
@@ -2329,15 +2336,15 @@ __global__ __launch_bounds__(128, 4) void k_fz_entropy(FzArgs a, const uint32_t 
                             }
                             left -= (int32_t)(need_v + need_s);
                         }
-                        if (bad_end) { err = E_CORRUPT; break; }
-                        if (bad_far) { err = E_UNSUP; if (lane == 0) S.why = 3; break; }
+                        if (margin < 0) { err = E_CORRUPT; break; }
+                        if (max_ofb > 27) { err = E_UNSUP; if (lane == 0) S.why = 3; break; }
                         // ---- B ----
                         const bool on = lane < cnt;
                         uint32_t ov = 4, ml = 0, ll = 0;
                         if (on) {
-                            const uint2 eo = to2[my_st & 511], em = tm2[(my_st >> 9) & 511], el = tl2[my_st >> 18];
+                            const uint2 eo = to2[my_so], em = tm2[my_sm], el = tl2[my_sl];
                             const uint32_t ofb = eo.x >> 24, mlb = em.x >> 24, llb = el.x >> 24, need_v = ofb + mlb + llb;
-                            const int32_t bend = (my_left + 7) >> 3;
+                            const int32_t my_left = (int32_t)my_leftu, bend = (my_left + 7) >> 3;
                             uint64_t lo8 = 0, hi8 = 0;  // stream bytes [bend - 16, bend - 8) and [bend - 8, bend); zero in front of the stream
                             if (bend >= 16) {
                                 __builtin_memcpy(&lo8, bbase + bend - 16, 8);
