@@ -1352,7 +1352,7 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES == 4 ? 4 : 1) void k_zstd_decod
                     const uint8_t *const bbase = src + uni(S.bs_off);
                     int32_t left = (int32_t)uni((uint32_t)S.bs_pos);  // a block's bitstream is < 2^20 bits
                     uint64_t wq = 0;
-                    int32_t wbase = INT32_MIN;
+                    int32_t wbits = INT32_MAX;  // bit position of the end of the window's first 8 bytes (none loaded yet)
                     uint32_t sl = uni(S.st_ll), so = uni(S.st_of), sm = uni(S.st_ml);
                     uint32_t r0 = uni(S.rep[0]), r1 = uni(S.rep[1]), r2 = uni(S.rep[2]);
                     int err = 0;
@@ -1373,35 +1373,46 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES == 4 ? 4 : 1) void k_zstd_decod
                         uint32_t my_so = 0, my_sm = 0, my_sl = 0, my_leftu = 0;
                         int32_t margin = 0;
                         // ---- A ----
-                        for (uint32_t g = 0; g < cnt; g++) {
+                        // (the block's last sequence takes no state bits: it is handled behind the loop, which so has no such case)
+                        const bool has_last = seq_done + g0 + cnt == nseq;
+                        const uint32_t cnt_a = has_last ? cnt - 1 : cnt;
+                        for (uint32_t g = 0; g < cnt_a; g++) {
                             // entry.x = next:16 | nbits:8 | addbits:8 (predefined tables sit in registers, one entry per lane)
                             uint32_t eox, emx, elx;
                             if (predef) { eox = rdl(rox, so); emx = rdl(rmx, sm); elx = rdl(rlx, sl); }
                             else { const uint32_t vo_ = to2[so].x, vm_ = tm2[sm].x, vl_ = tl2[sl].x; eox = uni(vo_); emx = uni(vm_); elx = uni(vl_); }  // three reads in flight, then the waits
                             const uint32_t need_v = (eox >> 24) + (emx >> 24) + (elx >> 24);
-                            const uint32_t nbl = (elx >> 16) & 0xFF, nbm = (emx >> 16) & 0xFF, nbo = (eox >> 16) & 0xFF;
-                            const bool more = seq_done + g0 + g + 1 < nseq;
-                            const uint32_t need_s = more ? nbl + nbm + nbo : 0u;
+                            const uint32_t nbl = (elx >> 16) & 0xFF, nbm = (emx >> 16) & 0xFF, nbo = (eox >> 16) & 0xFF, need_s = nbl + nbm + nbo;
                             margin = min(margin, left - (int32_t)(need_v + need_s));  // below zero: the stream ends before a sequence does
                             wrlane4_u(my_so, my_sm, my_sl, my_leftu, so, sm, sl, (uint32_t)left, g);
-                            if (more) {
-                                const int32_t pos0 = left - (int32_t)need_v, pos = pos0 < 0 ? 0 : pos0, bend = (pos + 7) >> 3, cs = bend - 8;
-                                if (wbase == INT32_MIN || cs < wbase) {
-                                    const int32_t nb0 = ((cs + 16 + 7) & ~7) - 512;
-                                    wbase = nb0 < -8 ? -8 : nb0;
-                                    const int32_t o8 = wbase + 8 * (int32_t)lane;
-                                    wq = o8 < 0 ? 0ull : load8_guard(bbase + o8, blob_end);
-                                }
-                                const uint32_t d = (uint32_t)(cs - wbase), j = uni(d >> 3), r = uni((d & 7) * 8);
-                                const uint64_t q0 = rdlane64_u(wq, j), q1 = rdlane64_u(wq, j + 1);
-                                const uint64_t v8 = (q0 >> r) | ((q1 << 1) << (63 - r));
-                                const uint32_t al = (uint32_t)(8 * bend - pos);
-                                const uint32_t xs = (uint32_t)(((v8 << al) >> 1) >> (63 - need_s));
-                                sl = (elx & 0xFFFF) + (xs >> (nbm + nbo));
-                                sm = (emx & 0xFFFF) + ((xs >> nbo) & ((1u << nbm) - 1u));
-                                so = (eox & 0xFFFF) + (xs & ((1u << nbo) - 1u));
+                            // the 64 stream bits that end where the state bits end, straight out of the window: `off` is their first
+                            // bit counted from the window's
+                            const int32_t pos0 = left - (int32_t)need_v, pos = pos0 < 0 ? 0 : pos0;
+                            int32_t off = pos - wbits;
+                            if (off < 0) {
+                                const int32_t nb0 = ((((pos + 7) >> 3) - 504) & ~7), wbase = nb0 < -8 ? -8 : nb0;  // bytes in front of the stream read as zero
+                                const int32_t o8 = wbase + 8 * (int32_t)lane;
+                                wq = o8 < 0 ? 0ull : load8_guard(bbase + o8, blob_end);
+                                wbits = 8 * wbase + 64;
+                                off = pos - wbits;
                             }
+                            const uint32_t j = uni((uint32_t)off >> 6), r = uni((uint32_t)off & 63);
+                            const uint64_t q0 = rdlane64_u(wq, j), q1 = rdlane64_u(wq, j + 1);
+                            const uint64_t v64 = (q0 >> r) | ((q1 << 1) << (63 - r));
+                            const uint32_t xs = (uint32_t)((v64 >> 1) >> (63 - need_s));  // its top need_s (<= 27) bits
+                            sl = (elx & 0xFFFF) + (xs >> (nbm + nbo));
+                            sm = (emx & 0xFFFF) + ((xs >> nbo) & ((1u << nbm) - 1u));
+                            so = (eox & 0xFFFF) + (xs & ((1u << nbo) - 1u));
                             left -= (int32_t)(need_v + need_s);
+                        }
+                        if (has_last) {
+                            uint32_t eox, emx, elx;
+                            if (predef) { eox = rdl(rox, so); emx = rdl(rmx, sm); elx = rdl(rlx, sl); }
+                            else { const uint32_t vo_ = to2[so].x, vm_ = tm2[sm].x, vl_ = tl2[sl].x; eox = uni(vo_); emx = uni(vm_); elx = uni(vl_); }
+                            const uint32_t need_v = (eox >> 24) + (emx >> 24) + (elx >> 24);
+                            margin = min(margin, left - (int32_t)need_v);
+                            wrlane4_u(my_so, my_sm, my_sl, my_leftu, so, sm, sl, (uint32_t)left, cnt - 1);
+                            left -= (int32_t)need_v;
                         }
                         if (margin < 0) { err = E_CORRUPT; break; }
                         // ---- B ----
@@ -2290,7 +2301,7 @@ __global__ __launch_bounds__(128, 4) void k_fz_entropy(FzArgs a, const uint32_t 
                     //      ending at the lane's position, the three values, the sums; then the repeat-offset rules in order
                     //      (scalar, only for groups that use a repeat code) and one coalesced store of the records.
                     uint64_t wq = 0;
-                    int32_t wbase = INT32_MIN;
+                    int32_t wbits = INT32_MAX;  // bit position of the end of the window's first 8 bytes (none loaded yet)
                     uint32_t sl = uni(S.st_ll), so = uni(S.st_of), sm = uni(S.st_ml);
                     const uint2 *const tl2 = reinterpret_cast<const uint2 *>(tl), *const to2 = reinterpret_cast<const uint2 *>(to),
                                 *const tm2 = reinterpret_cast<const uint2 *>(tm);
@@ -2303,38 +2314,48 @@ __global__ __launch_bounds__(128, 4) void k_fz_entropy(FzArgs a, const uint32_t 
                         uint32_t my_so = 0, my_sm = 0, my_sl = 0, my_leftu = 0, max_ofb = 0;
                         int32_t margin = 0;
                         // ---- A ----
-                        for (uint32_t g = 0; g < cnt; g++) {
+                        // (the block's last sequence takes no state bits: it is handled behind the loop, which so has no such case;
+                        // verdicts are a running min / max, not branches: one way out of the loop keeps its state in place — with
+                        // early exits the compiler copied every loop-carried register twice per trip — and a stream that has gone
+                        // wrong only moves `left` below zero and reads zero bytes in front of the stream)
+                        const bool has_last = g0 + cnt == nseq;
+                        const uint32_t cnt_a = has_last ? cnt - 1 : cnt;
+                        for (uint32_t g = 0; g < cnt_a; g++) {
                             const uint32_t vo_ = to2[so].x, vm_ = tm2[sm].x, vl_ = tl2[sl].x;  // three LDS reads in flight together ...
                             const uint32_t eox = uni(vo_), emx = uni(vm_), elx = uni(vl_);    // ... before the first is waited for (next:16 | nbits:8 | addbits:8)
                             const uint32_t ofb = eox >> 24, need_v = ofb + (emx >> 24) + (elx >> 24);
-                            const uint32_t nbl = (elx >> 16) & 0xFF, nbm = (emx >> 16) & 0xFF, nbo = (eox >> 16) & 0xFF;
-                            const bool more = g0 + g + 1 < nseq;
-                            const uint32_t need_s = more ? nbl + nbm + nbo : 0u;
-                            // verdicts are collected, not branched on: one way out of the loop keeps its state in place (with early
-                            // exits the compiler copied every loop-carried register twice per trip); a stream that has gone wrong
-                            // only moves `left` below zero and reads zero bytes in front of the stream
+                            const uint32_t nbl = (elx >> 16) & 0xFF, nbm = (emx >> 16) & 0xFF, nbo = (eox >> 16) & 0xFF, need_s = nbl + nbm + nbo;
                             max_ofb = max(max_ofb, ofb);
                             margin = min(margin, left - (int32_t)(need_v + need_s));  // below zero: the stream ends before a sequence does
                             wrlane4_u(my_so, my_sm, my_sl, my_leftu, so, sm, sl, (uint32_t)left, g);
-                            if (more) {
-                                // the state bits end at `pos`: the 8 stream bytes that end there hold all of them (<= 27 bits)
-                                const int32_t pos0 = left - (int32_t)need_v, pos = pos0 < 0 ? 0 : pos0, bend = (pos + 7) >> 3, cs = bend - 8;
-                                if (wbase == INT32_MIN || cs < wbase) {
-                                    const int32_t nb0 = ((cs + 16 + 7) & ~7) - 512;
-                                    wbase = nb0 < -8 ? -8 : nb0;  // bytes in front of the stream read as zero
-                                    const int32_t o8 = wbase + 8 * (int32_t)lane;
-                                    wq = o8 < 0 ? 0ull : load8_guard(bbase + o8, blob_end);
-                                }
-                                const uint32_t d = (uint32_t)(cs - wbase), j = uni(d >> 3), r = uni((d & 7) * 8);
-                                const uint64_t q0 = rdlane64_u(wq, j), q1 = rdlane64_u(wq, j + 1);
-                                const uint64_t v8 = (q0 >> r) | ((q1 << 1) << (63 - r));
-                                const uint32_t al = (uint32_t)(8 * bend - pos);                    // 0..7 bits of the chunk lie above pos
-                                const uint32_t xs = (uint32_t)(((v8 << al) >> 1) >> (63 - need_s));  // its top need_s bits below pos
-                                sl = (elx & 0xFFFF) + (xs >> (nbm + nbo));
-                                sm = (emx & 0xFFFF) + ((xs >> nbo) & ((1u << nbm) - 1u));
-                                so = (eox & 0xFFFF) + (xs & ((1u << nbo) - 1u));
+                            // the 64 stream bits that end where the state bits end, straight out of the window: `off` is their first
+                            // bit counted from the window's
+                            const int32_t pos0 = left - (int32_t)need_v, pos = pos0 < 0 ? 0 : pos0;
+                            int32_t off = pos - wbits;
+                            if (off < 0) {
+                                const int32_t nb0 = ((((pos + 7) >> 3) - 504) & ~7), wbase = nb0 < -8 ? -8 : nb0;  // bytes in front of the stream read as zero
+                                const int32_t o8 = wbase + 8 * (int32_t)lane;
+                                wq = o8 < 0 ? 0ull : load8_guard(bbase + o8, blob_end);
+                                wbits = 8 * wbase + 64;
+                                off = pos - wbits;
                             }
+                            const uint32_t j = uni((uint32_t)off >> 6), r = uni((uint32_t)off & 63);
+                            const uint64_t q0 = rdlane64_u(wq, j), q1 = rdlane64_u(wq, j + 1);
+                            const uint64_t v64 = (q0 >> r) | ((q1 << 1) << (63 - r));
+                            const uint32_t xs = (uint32_t)((v64 >> 1) >> (63 - need_s));  // its top need_s (<= 27) bits
+                            sl = (elx & 0xFFFF) + (xs >> (nbm + nbo));
+                            sm = (emx & 0xFFFF) + ((xs >> nbo) & ((1u << nbm) - 1u));
+                            so = (eox & 0xFFFF) + (xs & ((1u << nbo) - 1u));
                             left -= (int32_t)(need_v + need_s);
+                        }
+                        if (has_last) {
+                            const uint32_t vo_ = to2[so].x, vm_ = tm2[sm].x, vl_ = tl2[sl].x;
+                            const uint32_t eox = uni(vo_), emx = uni(vm_), elx = uni(vl_);
+                            const uint32_t ofb = eox >> 24, need_v = ofb + (emx >> 24) + (elx >> 24);
+                            max_ofb = max(max_ofb, ofb);
+                            margin = min(margin, left - (int32_t)need_v);
+                            wrlane4_u(my_so, my_sm, my_sl, my_leftu, so, sm, sl, (uint32_t)left, cnt - 1);
+                            left -= (int32_t)need_v;
                         }
                         if (margin < 0) { err = E_CORRUPT; break; }
                         if (max_ofb > 27) { err = E_UNSUP; if (lane == 0) S.why = 3; break; }
