@@ -1150,7 +1150,8 @@ __global__ __launch_bounds__(64) void k_zstd_encode(EncodeArgs a) {
                     {
                         const uint32_t lim = nq - pos < LMAX ? nq - pos : LMAX;
                         uint32_t k = 4;
-                        if (pos >= 8 && pos + 16 <= nq) {
+                        const bool wide_first = misses < 8 && pos >= 8 && pos + 16 <= nq;  // (not through incompressible stretches: there nearly every candidate fails its first 4 bytes)
+                        if (wide_first) {
                             // the first round trip brings 24 bytes around every candidate (8 in front, 16 from it on) and around the
                             // position: most matches end inside them, and what a chosen match can take over in front of it is
                             // known without a round trip of its own
@@ -1224,7 +1225,7 @@ __global__ __launch_bounds__(64) void k_zstd_encode(EncodeArgs a) {
                             }
                     }
                     if (mlen && cand >= 8) {  // bytes in front of the match that agree too (up to 8): literals it can take over
-                        if (pos >= 8 && pos + 16 <= nq) {
+                        if (misses < 8 && pos >= 8 && pos + 16 <= nq) {
 #pragma unroll
                             for (int w = 0; w < 11; w++)
                                 if (pick == (uint32_t)w) back = bk[w];
