@@ -609,4 +609,442 @@ __device__ __forceinline__ uint32_t fz_lit_section_bytes(const LitHdr &h) {
     return h.hdr + (h.type == 0 ? h.regen : (h.type == 1 ? 1u : h.comp));
 }
 
+// ---------------------------------------------------------------------------------------------
+// lane-0 serial helpers
+// ---------------------------------------------------------------------------------------------
+template <class Shared>
+__device__ int fse_read_ncount(Shared &S, const uint8_t *src, uint32_t n, int max_log, int max_sym, int *nsym,
+                               int *log, uint32_t *consumed, int nbase = 0) {
+    FwdR b{src, n, 0};
+    if (n == 0) return E_TRUNC;
+    int alog = 5 + (int)b.read(4);
+    if (alog > max_log) return E_CORRUPT;
+    int remaining = 1 << alog, s = 0;
+    while (remaining > 0 && s <= max_sym) {
+        int bits = hibit((uint32_t)remaining + 1) + 1;
+        uint32_t val = b.read(bits);
+        uint32_t lower_mask = (1u << (bits - 1)) - 1;
+        uint32_t threshold = (1u << bits) - 1 - ((uint32_t)remaining + 1);
+        if ((val & lower_mask) < threshold) {
+            b.bitpos -= 1;
+            val &= lower_mask;
+        } else if (val > lower_mask) {
+            val -= threshold;
+        }
+        int proba = (int)val - 1;
+        remaining -= proba < 0 ? -proba : proba;
+        S.norm[nbase + s++] = (int16_t)proba;
+        if (proba == 0) {
+            uint32_t rep = b.read(2);
+            for (;;) {
+                for (uint32_t i = 0; i < rep && s <= max_sym; i++) S.norm[nbase + s++] = 0;
+                if (rep == 3) rep = b.read(2); else break;
+            }
+        }
+    }
+    if (remaining != 0) return E_CORRUPT;
+    if ((b.bitpos + 7) / 8 > n) return E_TRUNC;
+    *nsym = s;
+    *log = alog;
+    *consumed = (b.bitpos + 7) / 8;
+    return 0;
+}
+
+// Build a decoding table from S.norm[0..nsym).  kind selects how (symbol -> base, addbits) maps:
+// LL / ML use the RFC's code tables, OF codes carry `code` extra bits on base 1<<code,
+// kind < 0 = plain symbols (Huffman weights).
+template <class Shared>
+__device__ int fse_build(Shared &S, FseEntry *t, int nsym, int log, int kind) {
+    const int size = 1 << log;
+    int high = size;
+    for (int s = 0; s < nsym; s++)
+        if (S.norm[s] == -1) { S.fse_sym[--high] = (uint8_t)s; S.fse_next[s] = 1; }
+    const int step = (size >> 1) + (size >> 3) + 3, mask = size - 1;
+    int pos = 0;
+    for (int s = 0; s < nsym; s++) {
+        int c = S.norm[s];
+        if (c <= 0) continue;
+        S.fse_next[s] = (uint16_t)c;
+        for (int i = 0; i < c; i++) {
+            S.fse_sym[pos] = (uint8_t)s;
+            do { pos = (pos + step) & mask; } while (pos >= high);
+        }
+    }
+    if (pos != 0) return E_CORRUPT;
+    for (int i = 0; i < size; i++) {
+        uint32_t sym = S.fse_sym[i];
+        uint32_t ns = S.fse_next[sym]++;
+        int nb = log - hibit(ns);
+        FseEntry e;
+        e.next = (uint16_t)((ns << nb) - size);
+        e.nbits = (uint8_t)nb;
+        if (kind == K_LL) { if (sym > 35) return E_CORRUPT; e.base = c_ll_base[sym]; e.addbits = c_ll_bits[sym]; }
+        else if (kind == K_ML) { if (sym > 52) return E_CORRUPT; e.base = c_ml_base[sym]; e.addbits = c_ml_bits[sym]; }
+        else if (kind == K_OF) { if (sym > 31) return E_CORRUPT; e.base = 1u << sym; e.addbits = (uint8_t)sym; }
+        else { e.base = sym; e.addbits = 0; }
+        t[i] = e;
+    }
+    return 0;
+}
+
+// fse_build by one wave, for alphabets of at most 64 symbols (the three sequence tables): lane = symbol for the
+// counts, lane = table cell for the entries.  The serial version is two loops of dependent LDS accesses (spread the
+// symbols, then hand every cell its symbol's next state: ~250 cycles per cell for a lone wave, 100-700 kcycles per block
+// for the three tables).  Here a cell finds its symbol directly: the spread visits cells in the order 0, step, 2*step, ...
+// (mod size) and skips the cells at the top that the "less than 1" symbols own, so cell u is the
+// (u / step mod size) - (top cells visited earlier) -th cell handed out, and its symbol is the one whose cumulative
+// count covers that index; the state a cell gets is its symbol's count plus the cell's rank among the symbol's
+// cells, counted 64 cells at a time with ballots.  scr: 128 u16 of LDS scratch.  Counts are already validated
+// (fse_read_ncount: they sum to the table size).
+__device__ void fse_build_wave(const int16_t *norm, uint32_t nsym, uint32_t log, int kind, FseEntry *t, uint16_t *scr, uint32_t lane) {
+    const uint32_t size = 1u << log, mask = size - 1, step = (size >> 1) + (size >> 3) + 3;
+    uint32_t inv = step;  // inverse of the odd step modulo 2^log (Newton: 3 -> 6 -> 12 correct bits)
+    inv *= 2u - step * inv; inv *= 2u - step * inv;
+    const int c = lane < nsym ? (int)norm[lane] : 0;
+    const bool low = c == -1;
+    const uint32_t cnt = c > 0 ? (uint32_t)c : 0u;
+    const uint64_t lowm = __ballot(low), below = lane ? (~0ull >> (64 - lane)) : 0ull;
+    const uint32_t nlow = (uint32_t)__popcll(lowm), high = size - nlow;
+    auto entry = [&](uint32_t sym, uint32_t ns) -> FseEntry {
+        FseEntry e;
+        const uint32_t nb = log - (uint32_t)hibit(ns);
+        e.next = (uint16_t)((ns << nb) - size);
+        e.nbits = (uint8_t)nb;
+        if (kind == K_LL) { e.base = c_ll_base[sym > 35 ? 35 : sym]; e.addbits = c_ll_bits[sym > 35 ? 35 : sym]; }
+        else if (kind == K_ML) { e.base = c_ml_base[sym > 52 ? 52 : sym]; e.addbits = c_ml_bits[sym > 52 ? 52 : sym]; }
+        else if (kind == K_OF) { e.base = 1u << (sym & 31); e.addbits = (uint8_t)sym; }
+        else { e.base = sym; e.addbits = 0; }  // kind < 0: plain symbols (Huffman weights)
+        return e;
+    };
+    if (low) t[size - 1 - (uint32_t)__popcll(lowm & below)] = entry(lane, 1);
+    uint32_t incl = cnt;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t y = __shfl_up(incl, d);
+        if (lane >= (uint32_t)d) incl += y;
+    }
+    uint16_t *const cum = scr, *const cur = scr + 64;
+    cum[lane] = (uint16_t)incl;
+    cur[lane] = (uint16_t)cnt;
+    const uint32_t jh = lane < nlow ? ((high + lane) * inv) & mask : 0xFFFFFFFFu;  // when the spread would have reached top cell `lane`
+    __builtin_amdgcn_wave_barrier();
+    for (uint32_t u0 = 0; u0 < high; u0 += 64) {
+        const uint32_t u = u0 + lane;
+        const bool on = u < high;
+        const uint32_t j = (u * inv) & mask;
+        uint32_t less = 0;
+        for (uint32_t r = 0; r < nlow; r++) less += rdlane_u(jh, r) < j ? 1u : 0u;
+        const uint32_t kf = on ? j - less : 0u;
+        uint32_t sidx = 0;
+#pragma unroll
+        for (uint32_t st = 32; st; st >>= 1)
+            if (cum[sidx + st - 1] <= kf) sidx += st;
+        uint64_t todo = __ballot(on);
+        uint32_t ns = 1;
+        while (todo) {
+            const uint32_t l = (uint32_t)__ffsll((long long)todo) - 1, sl = rdlane_u(sidx, l) & 63;
+            const uint64_t same = __ballot(on && sidx == sl);
+            const uint32_t b0 = cur[sl];
+            if (on && sidx == sl) ns = b0 + (uint32_t)__popcll(same & below);
+            if (lane == l) cur[sl] = (uint16_t)(b0 + (uint32_t)__popcll(same));
+            todo &= ~same;
+        }
+        if (on) t[u] = entry(sidx, ns ? ns : 1);
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+
+__device__ int fse_set_rle(FseEntry *e, uint32_t sym, int kind) {
+    e->next = 0; e->nbits = 0;
+    if (kind == K_LL) { if (sym > 35) return E_CORRUPT; e->base = c_ll_base[sym]; e->addbits = c_ll_bits[sym]; }
+    else if (kind == K_ML) { if (sym > 52) return E_CORRUPT; e->base = c_ml_base[sym]; e->addbits = c_ml_bits[sym]; }
+    else { if (sym > 31) return E_CORRUPT; e->base = 1u << sym; e->addbits = (uint8_t)sym; }
+    return 0;
+}
+
+// Huffman tree description -> S.weights / S.sym_start / S.sym_len / S.huf_log (lane 0).
+template <class Shared>
+__device__ int huf_read_tree(Shared &S, const uint8_t *src, uint32_t n, const uint8_t *blob_end, uint32_t *consumed) {
+    if (n < 1) return E_TRUNC;
+    uint32_t hb = src[0];
+    int nw = 0;
+    if (hb >= 128) {
+        int num = (int)hb - 127;
+        uint32_t bytes = (uint32_t)(num + 1) / 2;
+        if (1 + bytes > n) return E_TRUNC;
+        for (int i = 0; i < num; i++) {
+            uint8_t b = src[1 + i / 2];
+            S.weights[i] = (i & 1) ? (b & 15) : (b >> 4);
+        }
+        nw = num;
+        *consumed = 1 + bytes;
+    } else {
+        if (hb == 0 || 1 + hb > n) return E_TRUNC;
+        int nsym, log;
+        uint32_t hdr;
+        int rc = fse_read_ncount(S, src + 1, hb, 6, 255, &nsym, &log, &hdr);
+        if (rc) return rc;
+        // weights table reuses the `of` slot region? no: keep sequence tables intact (repeat mode) -> use ll? also live.
+        // A 64-entry table fits in the dml slot only if ML is not in default mode later, so build into a
+        // private region: the seq_ll batch buffer is free while literals are being decoded.
+        FseEntry *t = reinterpret_cast<FseEntry *>(S.seq_ll);
+        rc = fse_build(S, t, nsym, log, -1);
+        if (rc) return rc;
+        if (hdr >= hb) return E_CORRUPT;
+        BitR b;
+        if (!b.init(src + 1 + hdr, hb - hdr, blob_end)) return E_CORRUPT;
+        uint32_t s1 = b.read(log), s2 = b.read(log);
+        for (;;) {
+            if (nw >= 255) return E_CORRUPT;
+            S.weights[nw++] = (uint8_t)t[s1].base;
+            s1 = t[s1].next + b.read(t[s1].nbits);
+            if (b.pos < 0) {
+                if (nw >= 255) return E_CORRUPT;
+                S.weights[nw++] = (uint8_t)t[s2].base;
+                break;
+            }
+            if (nw >= 255) return E_CORRUPT;
+            S.weights[nw++] = (uint8_t)t[s2].base;
+            s2 = t[s2].next + b.read(t[s2].nbits);
+            if (b.pos < 0) {
+                if (nw >= 255) return E_CORRUPT;
+                S.weights[nw++] = (uint8_t)t[s1].base;
+                break;
+            }
+        }
+        *consumed = 1 + hb;
+    }
+    // implied last weight, code lengths, canonical start index per symbol
+    uint32_t total = 0;
+    for (int i = 0; i < nw; i++) {
+        uint32_t w = S.weights[i];
+        if (w > 12) return E_CORRUPT;
+        total += w ? 1u << (w - 1) : 0;
+    }
+    if (total == 0) return E_CORRUPT;
+    int maxbits = hibit(total) + 1;
+    if (maxbits > 11) return E_CORRUPT;
+    uint32_t left = (1u << maxbits) - total;
+    if (left & (left - 1)) return E_CORRUPT;
+    S.weights[nw] = (uint8_t)(hibit(left) + 1);
+    int nsym = nw + 1;
+    uint32_t rank_count[13], rank_idx[13];
+    for (int i = 0; i < 13; i++) rank_count[i] = 0;
+    for (int i = 0; i < nsym; i++) {
+        uint32_t w = S.weights[i];
+        rank_count[w ? maxbits + 1 - w : 0]++;
+    }
+    rank_idx[maxbits] = 0;
+    for (int i = maxbits; i >= 1; i--) rank_idx[i - 1] = rank_idx[i] + rank_count[i] * (1u << (maxbits - i));
+    if (rank_idx[0] != (1u << maxbits)) return E_CORRUPT;
+    for (int i = 0; i < 256; i++) S.sym_len[i] = 0;
+    for (int i = 0; i < nsym; i++) {
+        uint32_t w = S.weights[i];
+        if (!w) continue;
+        uint32_t bits = maxbits + 1 - w, len = 1u << (maxbits - bits);
+        S.sym_start[i] = (uint16_t)rank_idx[bits];
+        S.sym_len[i] = (uint16_t)len;
+        rank_idx[bits] += len;
+    }
+    S.huf_log = maxbits;
+    return 0;
+}
+
+// huf_read_tree by one wave (the general / block decoder).  What is serial by nature stays on lane 0 (reading the
+// counts of the weight table, decoding the at most 255 weights with two interleaved states); the weight table itself is
+// built by the wave (fse_build_wave), and so is everything behind the weights: validity, the implied last weight, and every
+// symbol's range in the decoding table — four symbols per lane, ranks by ballots in (weight, symbol) order.  Same
+// verdicts as the serial version, which the foreign-frame path still uses.
+template <class Shared>
+__device__ int huf_read_tree_wave(Shared &S, const uint8_t *src, uint32_t n, const uint8_t *blob_end, uint32_t lane) {
+    if (n < 1) return E_TRUNC;
+    const uint32_t hb = uni((uint32_t)src[0]);
+    uint32_t nw = 0;
+    if (hb >= 128) {
+        nw = hb - 127;
+        const uint32_t bytes = (nw + 1) / 2;
+        if (1 + bytes > n) return E_TRUNC;
+        for (uint32_t i = lane; i < nw; i += 64) {
+            const uint8_t b = src[1 + i / 2];
+            S.weights[i] = (i & 1) ? (b & 15) : (b >> 4);
+        }
+    } else {
+        if (hb == 0 || 1 + hb > n) return E_TRUNC;
+        int rc = 0, nsym = 0, log = 0;
+        uint32_t hdr = 0;
+        if (lane == 0) rc = fse_read_ncount(S, src + 1, hb, 6, 255, &nsym, &log, &hdr);
+        rc = (int)uni((uint32_t)rc); nsym = (int)uni((uint32_t)nsym); log = (int)uni((uint32_t)log); hdr = uni(hdr);
+        if (rc) return rc;
+        FseEntry *t = reinterpret_cast<FseEntry *>(S.seq_ll);  // free while literals are being decoded
+        __builtin_amdgcn_wave_barrier();
+        if (nsym <= 64) fse_build_wave(S.norm, (uint32_t)nsym, (uint32_t)log, -1, t, reinterpret_cast<uint16_t *>(S.fse_next), lane);
+        else {  // a table that names symbols beyond 63 (no weight is that large; the weights decide below)
+            if (lane == 0) rc = fse_build(S, t, nsym, log, -1);
+            rc = (int)uni((uint32_t)rc);
+            if (rc) return rc;
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (hdr >= hb) return E_CORRUPT;
+        if (lane == 0) {
+            BitR b;
+            if (!b.init(src + 1 + hdr, hb - hdr, blob_end)) rc = E_CORRUPT;
+            else {
+                uint32_t s1 = b.read(log), s2 = b.read(log);
+                for (;;) {
+                    if (nw >= 255) { rc = E_CORRUPT; break; }
+                    S.weights[nw++] = (uint8_t)t[s1].base;
+                    s1 = t[s1].next + b.read(t[s1].nbits);
+                    if (b.pos < 0) {
+                        if (nw >= 255) { rc = E_CORRUPT; break; }
+                        S.weights[nw++] = (uint8_t)t[s2].base;
+                        break;
+                    }
+                    if (nw >= 255) { rc = E_CORRUPT; break; }
+                    S.weights[nw++] = (uint8_t)t[s2].base;
+                    s2 = t[s2].next + b.read(t[s2].nbits);
+                    if (b.pos < 0) {
+                        if (nw >= 255) { rc = E_CORRUPT; break; }
+                        S.weights[nw++] = (uint8_t)t[s1].base;
+                        break;
+                    }
+                }
+            }
+        }
+        rc = (int)uni((uint32_t)rc); nw = uni(nw);
+        if (rc) return rc;
+    }
+    __builtin_amdgcn_wave_barrier();
+    // implied last weight, code lengths, canonical start index per symbol: lane owns symbols lane, +64, +128, +192
+    uint32_t w[4], sum = 0;
+    bool bad = false;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const uint32_t idx = lane + 64 * j;
+        w[j] = idx < nw ? S.weights[idx] : 0;
+        if (w[j] > 12) bad = true;
+        sum += (w[j] && w[j] <= 12) ? 1u << (w[j] - 1) : 0;
+    }
+    if (__ballot(bad)) return E_CORRUPT;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) sum += __shfl_xor(sum, d);
+    const uint32_t total = sum;
+    if (total == 0) return E_CORRUPT;
+    const uint32_t maxbits = (uint32_t)hibit(total) + 1;
+    if (maxbits > 11) return E_CORRUPT;
+    const uint32_t left = (1u << maxbits) - total;
+    if (left & (left - 1)) return E_CORRUPT;
+    const uint32_t lastw = (uint32_t)hibit(left) + 1;
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+        if (lane + 64 * j == nw) { w[j] = lastw; S.weights[nw] = (uint8_t)lastw; }
+    const uint64_t below = lane ? (~0ull >> (64 - lane)) : 0ull;
+    uint32_t start = 0, st[4] = {0, 0, 0, 0}, ln[4] = {0, 0, 0, 0};
+    for (uint32_t bits = maxbits; bits >= 1; bits--) {  // longest codes first, as the table is laid out
+        const uint32_t wt = maxbits + 1 - bits, len = 1u << (maxbits - bits);
+        uint32_t before = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const uint64_t m = __ballot(w[j] == wt);
+            if (w[j] == wt) { st[j] = start + ((before + (uint32_t)__popcll(m & below)) << (maxbits - bits)); ln[j] = len; }
+            before += (uint32_t)__popcll(m);
+        }
+        start += before << (maxbits - bits);
+    }
+    if (start != (1u << maxbits)) return E_CORRUPT;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        S.sym_start[lane + 64 * j] = (uint16_t)st[j];
+        S.sym_len[lane + 64 * j] = (uint16_t)ln[j];
+    }
+    if (lane == 0) S.huf_log = maxbits;
+    return 0;
+}
+
+__device__ int fz_huf_stream(const uint16_t *huf, uint32_t log, const uint8_t *p, uint32_t n, const uint8_t *blob_end,
+                             uint8_t *dst, uint32_t n_out);
+
+// One lane decodes one Huffman stream (n_out symbols) from [p, p+n) into dst.
+template <class Shared>
+__device__ int huf_decode_stream(const Shared &S, const uint8_t *p, uint32_t n, const uint8_t *blob_end,
+                                 uint8_t *dst, uint32_t n_out) {
+    BitR b;
+    if (!b.init(p, n, blob_end)) return E_CORRUPT;
+    const uint32_t log = S.huf_log;
+    for (uint32_t i = 0; i < n_out; i++) {
+        uint32_t e = S.huf[b.peek(log)];
+        dst[i] = (uint8_t)e;
+        b.pos -= e >> 8;
+    }
+    return b.pos == 0 ? 0 : E_CORRUPT;
+}
+
+// XXH64 (RFC 8878 §3.1.1 content checksum), seed 0, computed by lanes 0..3 of one wave (one stripe
+// accumulator each; the stripe recurrence is serial by definition), finalised by lane 0.
+__device__ uint64_t wave_xxh64(const uint8_t *p, uint64_t len, uint32_t lane) {
+    const uint64_t P1 = 0x9E3779B185EBCA87ull, P2 = 0xC2B2AE3D27D4EB4Full, P3 = 0x165667B19E3779F9ull,
+                   P4 = 0x85EBCA77C2B2AE63ull, P5 = 0x27D4EB2F165667C5ull;
+    auto rotl = [](uint64_t x, int r) { return (x << r) | (x >> (64 - r)); };
+    auto rd64 = [](const uint8_t *q) { uint64_t v; __builtin_memcpy(&v, q, 8); return v; };
+    auto rd32 = [](const uint8_t *q) { uint32_t v; __builtin_memcpy(&v, q, 4); return v; };
+    auto round = [&](uint64_t acc, uint64_t in) { acc += in * P2; acc = rotl(acc, 31); return acc * P1; };
+    uint64_t v = 0;
+    const uint64_t stripes = len / 32;
+    if (lane < 4) {
+        v = lane == 0 ? P1 + P2 : (lane == 1 ? P2 : (lane == 2 ? 0 : 0 - P1));
+        const uint8_t *q = p + 8 * lane;
+        for (uint64_t i = 0; i < stripes; i++) v = round(v, rd64(q + 32 * i));
+    }
+    const uint64_t v1 = __shfl(v, 0), v2 = __shfl(v, 1), v3 = __shfl(v, 2), v4 = __shfl(v, 3);
+    uint64_t h;
+    if (len >= 32) {
+        h = rotl(v1, 1) + rotl(v2, 7) + rotl(v3, 12) + rotl(v4, 18);
+        auto merge = [&](uint64_t acc, uint64_t val) { val = round(0, val); acc ^= val; return acc * P1 + P4; };
+        h = merge(h, v1); h = merge(h, v2); h = merge(h, v3); h = merge(h, v4);
+    } else {
+        h = P5;
+    }
+    h += len;
+    const uint8_t *q = p + stripes * 32, *end = p + len;
+    while (q + 8 <= end) { h ^= round(0, rd64(q)); h = rotl(h, 27) * P1 + P4; q += 8; }
+    if (q + 4 <= end) { h ^= (uint64_t)rd32(q) * P1; h = rotl(h, 23) * P2 + P3; q += 4; }
+    while (q < end) { h ^= (*q) * P5; h = rotl(h, 11) * P1; q++; }
+    h ^= h >> 33; h *= P2; h ^= h >> 29; h *= P3; h ^= h >> 32;
+    return h;
+}
+
+// One lane, one Huffman stream.  While 64 or more bits are unread four symbols (<= 44 bits) come out of one 8-byte
+// load with no end-of-stream case and leave as one 4-byte store; the last few go through the guarded reader.
+__device__ int fz_huf_stream(const uint16_t *huf, uint32_t log, const uint8_t *p, uint32_t n, const uint8_t *blob_end,
+                             uint8_t *dst, uint32_t n_out) {
+    BitR b;
+    if (!b.init(p, n, blob_end)) return E_CORRUPT;
+    const uint32_t mask = (1u << log) - 1;
+    uint32_t i = 0;
+    int64_t pos = b.pos;
+    while (i + 4 <= n_out && pos >= 64) {
+        const int64_t b0 = ((pos + 7) >> 3) - 8;
+        uint64_t c;
+        __builtin_memcpy(&c, p + b0, 8);
+        int32_t avail = (int32_t)(pos - b0 * 8);  // 57..64 bits of c lie below `pos`
+        uint32_t w = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const uint32_t e = huf[(uint32_t)(c >> (avail - (int32_t)log)) & mask];
+            w |= (e & 0xFFu) << (8 * j);
+            avail -= (int32_t)(e >> 8);
+        }
+        pos = b0 * 8 + avail;
+        __builtin_memcpy(dst + i, &w, 4);
+        i += 4;
+    }
+    b.pos = pos;
+    b.refill();
+    for (; i < n_out; i++) {
+        const uint32_t e = huf[b.peek(log)];
+        dst[i] = (uint8_t)e;
+        b.pos -= e >> 8;
+    }
+    return b.pos == 0 ? 0 : E_CORRUPT;
+}
+
 }  // namespace zn
