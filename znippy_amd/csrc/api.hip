@@ -65,6 +65,11 @@ struct znippy_ctx {
     uint8_t *fz_lit_pool = nullptr;
     unsigned long long *fz_seq_pool = nullptr;
     uint64_t fz_lit_cap = 0, fz_seq_cap = 0;
+    // the batch path's table pools (zstd_batch.hip, k_bx_*): FSE decoding tables as 4-byte cells (the predefined ones at
+    // the head), Huffman decoding tables as 2-byte cells
+    uint32_t *bx_fse_pool = nullptr;
+    uint16_t *bx_huf_pool = nullptr;
+    uint64_t bx_fse_cap = 0, bx_huf_cap = 0;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     // kernel timing
     std::vector<KTime> ktimes;
@@ -84,7 +89,7 @@ struct znippy_ctx {
         int dbg = 0;             // ZNIPPY_DBG bit set (FusedArgs::dbg)
         unsigned lds_pad = 0;    // ZNIPPY_LDS_PAD
         bool no_block_items = false, no_fused_blocks = false, ddbg = false, edbg = false, no_fused_store = false,
-             nohash = false, no_roles = false, no_fz = false, fz_only = false;
+             nohash = false, no_roles = false, no_fz = false, fz_only = false, no_bx = false;
         // ZNIPPY_ROLES_MIN: small tiles from which the role-split persistent kernel takes the table (0 = never; below
         // a few CU-fillings a persistent grid only adds start-up latency)
         unsigned roles_min = 2048;
@@ -106,6 +111,7 @@ static void read_switches(znippy_ctx *ctx) {
     ctx->sw.nohash = on("ZNIPPY_NOHASH");
     ctx->sw.no_roles = on("ZNIPPY_NO_ROLES");
     ctx->sw.no_fz = on("ZNIPPY_NO_FZ");
+    ctx->sw.no_bx = on("ZNIPPY_NO_BX");  // A/B: foreign frames through the round-2 paths (serial decoder + wave-per-block two-phase path)
     if (const char *lv = getenv("ZNIPPY_LEVEL")) { const int v = atoi(lv); if (v >= 1 && v <= 22) ctx->level = v; }  // initial level of every context (tests, A/B runs)
     if (const char *gs = getenv("ZNIPPY_GEN_SHARE")) { const int v = atoi(gs); if (v >= 1 && v <= 4) ctx->gen_share = v; }  // A/B
     ctx->sw.fz_only = on("ZNIPPY_FZ_ONLY");  // test hook: no serial fallback behind the two-phase path (what it leaves shows up as corrupt rows)
@@ -290,7 +296,7 @@ struct znippy_rows {
     // One allocation, cleared (or preset) by ONE stream operation per run: [counters 8 x u64][hand-over counts 16 x u32]
     // [work cursors 16 x u32][pad 64 B][status n x i32]
     uint8_t *ctl = nullptr;
-    static constexpr size_t CTL_HEAD = 256;
+    static constexpr size_t CTL_HEAD = 512;  // [256, 384): pool counters of the batch path (16 x u64), [384, 448): its work counters (16 x u32)
     size_t ctl_bytes = 0;
     int32_t *status = nullptr;
     uint32_t *digests = nullptr;
@@ -328,6 +334,12 @@ struct znippy_rows {
     zn::FzItem *fz_items = nullptr;
     uint32_t fz_total = 0;
     uint64_t fz_bytes = 0;  // content bytes of all candidates
+    // batch path (k_bx_*): candidate slots (one per compressed row at most), item slots, the two entropy work lists
+    uint32_t bx_slots = 0, bx_item_cap = 0;
+    uint64_t bx_bytes = 0;  // content bytes of all compressed rows
+    uint32_t *bx_cand_row = nullptr, *bx_cand_base = nullptr, *bx_cand_nb = nullptr, *bx_huf_list = nullptr, *bx_seq_list = nullptr;
+    zn::FzItem *bx_items = nullptr;
+    zn::BxPrep *bx_prep = nullptr;
     uint32_t *item_row = nullptr, *item_k = nullptr, *item_src = nullptr, *row_flag = nullptr;
     // fused block kernel: big-slice tiles of the candidate rows, the item each belongs to, and what it got done
     uint32_t n_bt = 0;
@@ -440,6 +452,32 @@ static int ensure_fz_pools(znippy_ctx *ctx, uint64_t content_bytes, uint32_t ite
     }
     return ZNIPPY_OK;
 }
+// Table pools of the batch path: a 10 KiB text frame needs ~1.5 KB of FSE cells and ~2 KB of Huffman cells; half a byte of
+// each per content byte (+ 64 bytes per item) covers frames down to ~1 KiB, and a block that finds a pool empty stays with
+// the serial decoder.
+static int ensure_bx_pools(znippy_ctx *ctx, uint64_t content_bytes, uint32_t items) {
+    constexpr uint64_t CAP = 16ull << 30;
+    const uint64_t bytes = std::min<uint64_t>(content_bytes / 2 + 64ull * items + 4096, CAP);
+    const uint64_t fse = bytes / 4 + BX_POOL_FIRST, huf = bytes / 2;
+    if (fse > ctx->bx_fse_cap) {
+        (void)hipStreamSynchronize(ctx->stream);
+        if (ctx->bx_fse_pool) (void)hipFree(ctx->bx_fse_pool);
+        ctx->bx_fse_pool = nullptr; ctx->bx_fse_cap = 0;
+        if (hipMalloc(&ctx->bx_fse_pool, fse * 4) != hipSuccess) { (void)hipGetLastError(); ctx->bx_fse_pool = nullptr; return ZNIPPY_OK; }
+        uint32_t predef[BX_POOL_FIRST];
+        bx_predefined_tables(predef);
+        if (hipMemcpy(ctx->bx_fse_pool, predef, sizeof predef, hipMemcpyHostToDevice) != hipSuccess) return ZNIPPY_E_HIP;
+        ctx->bx_fse_cap = fse;
+    }
+    if (huf > ctx->bx_huf_cap) {
+        (void)hipStreamSynchronize(ctx->stream);
+        if (ctx->bx_huf_pool) (void)hipFree(ctx->bx_huf_pool);
+        ctx->bx_huf_pool = nullptr; ctx->bx_huf_cap = 0;
+        if (hipMalloc(&ctx->bx_huf_pool, huf * 2) != hipSuccess) { (void)hipGetLastError(); ctx->bx_huf_pool = nullptr; return ZNIPPY_OK; }
+        ctx->bx_huf_cap = huf;
+    }
+    return ZNIPPY_OK;
+}
 static int ensure_encoder(znippy_ctx *ctx) {
     if (ctx->enc_tabs) return ZNIPPY_OK;
     EncTables t;
@@ -499,6 +537,8 @@ void znippy_ctx_destroy(znippy_ctx *ctx) {
     if (ctx->lit_scratch_b) (void)hipFree(ctx->lit_scratch_b);
     if (ctx->fz_lit_pool) (void)hipFree(ctx->fz_lit_pool);
     if (ctx->fz_seq_pool) (void)hipFree(ctx->fz_seq_pool);
+    if (ctx->bx_fse_pool) (void)hipFree(ctx->bx_fse_pool);
+    if (ctx->bx_huf_pool) (void)hipFree(ctx->bx_huf_pool);
     if (ctx->cursor) (void)hipFree(ctx->cursor);
     if (ctx->shim_in) (void)hipFree(ctx->shim_in);
     if (ctx->shim_out) (void)hipFree(ctx->shim_out);
@@ -540,7 +580,8 @@ int znippy_rows_foreign_stats(znippy_ctx *ctx, znippy_rows *r, uint64_t stats[8]
     if (!ctx || !r || r->ctx != ctx || !stats) return ZNIPPY_E_INVAL;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    HIPCHK(ctx, hipMemcpy(stats, r->ctl + 192, 64, hipMemcpyDeviceToHost));
+    // the path that ran for this table: the batch path's counters sit at +256, the round-2 two-phase path's at +192
+    HIPCHK(ctx, hipMemcpy(stats, r->ctl + (r->bx_slots ? 256 : 192), 64, hipMemcpyDeviceToHost));
     return ZNIPPY_OK;
 }
 
@@ -629,7 +670,8 @@ void znippy_rows_destroy(znippy_rows *r) {
     void *ptrs[] = {r->blob_off, r->blob_size, r->usize, r->out_off, r->compressed, r->checksum,
                     r->ctl, r->digests, r->corrupt, r->list_a, r->pending,
                     r->cand_row, r->cand_base, r->cand_nblocks, r->fz_base, r->fz_cap, r->fz_it_cand, r->fz_nb, r->fz_work, r->fz_items, r->item_row, r->item_k, r->item_src, r->row_flag, r->pending2,
-                    r->bt_tile, r->bt_item, r->tile_done, r->item_done, r->todo, r->status_init, r->slow_list};
+                    r->bt_tile, r->bt_item, r->tile_done, r->item_done, r->todo, r->status_init, r->slow_list,
+                    r->bx_cand_row, r->bx_cand_base, r->bx_cand_nb, r->bx_huf_list, r->bx_seq_list, r->bx_items, r->bx_prep};
     for (void *p : ptrs)
         tfree(r->ctx, p);
     if (r->h_counters) {
@@ -724,7 +766,7 @@ int znippy_rows_create(znippy_ctx *ctx, const uint64_t *blob_offset, const uint6
             cand_base.push_back((uint32_t)item_row.size());
             cand_nb.push_back((uint32_t)nb);
             for (uint32_t k = 0; k < nb; k++) { item_row.push_back(i); item_k.push_back(k); }
-            if (!ctx->sw.no_fz && fz_it_cand.size() + 2 * nb + 8 < 0x7FFFFFFFull) {
+            if (!ctx->sw.no_fz && ctx->sw.no_bx && fz_it_cand.size() + 2 * nb + 8 < 0x7FFFFFFFull) {
                 const uint32_t cap = (uint32_t)(2 * nb + 8);
                 fz_base.push_back((uint32_t)fz_it_cand.size());
                 fz_cap.push_back(cap);
@@ -734,6 +776,32 @@ int znippy_rows_create(znippy_ctx *ctx, const uint64_t *blob_offset, const uint6
         } else la.push_back(i);
     }
     r->n_list_a = (uint32_t)la.size();
+    if (r->n_compressed) {
+        // what the block-item path, the batch path and the serial decoder tell each other about a row, and the serial
+        // decoder's list
+        if (tmalloc(ctx, &r->row_flag, std::max<size_t>(4 * (size_t)n, 16)) != hipSuccess ||
+            tmalloc(ctx, &r->pending2, std::max<size_t>(4 * (size_t)r->n_compressed, 16)) != hipSuccess) {
+            znippy_rows_destroy(r);
+            return ZNIPPY_E_NOMEM;
+        }
+        if (!ctx->sw.no_bx) {
+            uint64_t nblk = 0;
+            for (uint32_t i = 0; i < n; i++)
+                if (comp[i]) { const uint64_t us = uncompressed_size[row_begin + i]; nblk += us ? (us + BLK - 1) / BLK : 1; r->bx_bytes += us; }
+            const uint64_t cap = nblk + nblk / 2 + 1024;  // a writer may split blocks: half as many again, shared by all frames
+            if (cap < 0x7FFFFFFFull) {
+                r->bx_slots = r->n_compressed;
+                r->bx_item_cap = (uint32_t)cap;
+                if (tmalloc(ctx, &r->bx_cand_row, 4 * (size_t)r->bx_slots) != hipSuccess || tmalloc(ctx, &r->bx_cand_base, 4 * (size_t)r->bx_slots) != hipSuccess ||
+                    tmalloc(ctx, &r->bx_cand_nb, 4 * (size_t)r->bx_slots) != hipSuccess || tmalloc(ctx, &r->bx_huf_list, 4 * (size_t)cap) != hipSuccess ||
+                    tmalloc(ctx, &r->bx_seq_list, 4 * (size_t)cap) != hipSuccess || tmalloc(ctx, &r->bx_items, sizeof(zn::FzItem) * (size_t)cap) != hipSuccess ||
+                    tmalloc(ctx, &r->bx_prep, sizeof(zn::BxPrep) * (size_t)cap) != hipSuccess) {
+                    znippy_rows_destroy(r);
+                    return ZNIPPY_E_NOMEM;
+                }
+            }
+        }
+    }
     // 1024-thread workgroups pay off where a few very long copies dominate (multi-MiB frames of periodic or stored
     // data: a frame that is < 2 % of its content); entropy-coded frames are a serial bitstream and want the narrow
     // variant's window execution instead, whatever their size
@@ -749,8 +817,7 @@ int znippy_rows_create(znippy_ctx *ctx, const uint64_t *blob_offset, const uint6
             znippy_rows_destroy(r);
             return rc;
         }
-        if (tmalloc(ctx, &r->item_src, 4 * (size_t)r->n_items) != hipSuccess || tmalloc(ctx, &r->row_flag, std::max<size_t>(4 * (size_t)n, 16)) != hipSuccess ||
-            tmalloc(ctx, &r->pending2, std::max<size_t>(4 * (size_t)r->n_cand, 16)) != hipSuccess) {
+        if (tmalloc(ctx, &r->item_src, 4 * (size_t)r->n_items) != hipSuccess) {
             znippy_rows_destroy(r);
             return ZNIPPY_E_NOMEM;
         }
@@ -854,6 +921,12 @@ int znippy_decode_verify_rows_async(znippy_ctx *ctx, znippy_rows *r, const void 
     { const int rc0 = ensure_decoder(ctx); if (rc0) return rc0; }
     { const int rc0 = rows_validate(ctx, r, blob_base, out_cap); if (rc0) return rc0; }
     if (r->fz_total) { const int rc0 = ensure_fz_pools(ctx, r->fz_bytes, r->fz_total); if (rc0) return rc0; }
+    if (r->bx_slots) {
+        int rc0 = ensure_fz_pools(ctx, r->bx_bytes, r->bx_item_cap);
+        if (!rc0) rc0 = ensure_bx_pools(ctx, r->bx_bytes, r->bx_item_cap);
+        if (rc0) return rc0;
+    }
+    const bool bx = r->bx_slots && ctx->fz_lit_pool && ctx->fz_seq_pool && ctx->bx_fse_pool && ctx->bx_huf_pool;
     const int preset = r->n_bad ? 1 : 0;
     // counters, hand-over counts, work cursors and the status column: one stream operation
     if (preset) HIPCHK(ctx, hipMemcpyAsync(r->ctl, r->status_init, r->ctl_bytes, hipMemcpyDeviceToDevice, s));
@@ -1040,6 +1113,41 @@ int znippy_decode_verify_rows_async(znippy_ctx *ctx, znippy_rows *r, const void 
             (void)hipMemset(dbg, 0, 64);
             a.dbg = dbg;
         }
+        if (bx) {
+            // Batch path: every frame that is still undecoded — big single-block rows, what the fused kernel handed over,
+            // block candidates the block-item path flagged — goes through the lane-per-block kernels in ONE pass (the
+            // more blocks, the fuller their waves), behind the block items; the serial decoder takes what they leave.
+            if (r->n_cand) {
+                HIPCHK(ctx, hipStreamWaitEvent(s, ctx->ev_join, 0));
+                launch_finish_blocks(b, s, true);  // unflagged candidates are done; flagged ones wait for the batch path's verdict
+            }
+            BxArgs x{};
+            x.list_a = r->list_a; x.n_list_a = r->n_list_a;
+            x.pending = r->pending; x.pending_count = r->pending_count;
+            x.bc_row = r->cand_row; x.n_bc = r->n_cand;
+            x.blobs = (const uint8_t *)d_blobs; x.blob_base = blob_base;
+            x.blob_off = r->blob_off; x.blob_size = r->blob_size; x.usize = r->usize; x.out_off = r->out_off; x.out_cap = out_cap;
+            x.out = (uint8_t *)d_out;
+            x.status = r->status; x.preset = preset; x.row_flag = r->row_flag;
+            x.cand_row = r->bx_cand_row; x.cand_base = r->bx_cand_base; x.cand_nb = r->bx_cand_nb; x.slot_cap = r->bx_slots;
+            x.items = r->bx_items; x.prep = r->bx_prep; x.item_cap = r->bx_item_cap;
+            x.ctr = reinterpret_cast<uint32_t *>(r->ctl + 384);
+            x.huf_list = r->bx_huf_list; x.seq_list = r->bx_seq_list;
+            x.lit_pool = ctx->fz_lit_pool; x.lit_cap = ctx->fz_lit_cap; x.seq_pool = ctx->fz_seq_pool; x.seq_cap = ctx->fz_seq_cap;
+            x.fse_pool = ctx->bx_fse_pool; x.fse_cap = ctx->bx_fse_cap; x.huf_pool = ctx->bx_huf_pool; x.huf_cap = ctx->bx_huf_cap;
+            x.pool_used = reinterpret_cast<unsigned long long *>(r->ctl + 256);
+            x.pending2 = r->pending2; x.pending2_count = r->pending_count + 1;
+            ktime_begin(ctx, "zstd_batch");
+            launch_bx(x, ctx->cus, s);
+            ktime_end(ctx);
+            a.list_a = nullptr; a.n_list_a = 0;
+            a.pending = r->pending2; a.pending_count = r->pending_count + 1;
+            a.cursor = r->cursor + 8;
+            ktime_begin(ctx, "zstd_decode_fallback");
+            if (!ctx->sw.fz_only)
+                launch_decode(a, std::min<int>(ctx->decode_grid, (int)r->n_compressed), r->wide_rows, s);
+            ktime_end(ctx);
+        } else {
         ktime_begin(ctx, "zstd_decode_general");
         // A full grid of this kernel (4 workgroups per CU at 128 VGPRs) is the whole register file: whatever the auxiliary
         // stream launches then waits until workgroups run out of rows (kernel trace of the real-text table: the first
@@ -1049,7 +1157,7 @@ int znippy_decode_verify_rows_async(znippy_ctx *ctx, znippy_rows *r, const void 
         ktime_end(ctx);
         if (r->n_cand) {  // join (block items and the foreign-frame path on the auxiliary stream), then what both gave up on
             HIPCHK(ctx, hipStreamWaitEvent(s, ctx->ev_join, 0));
-            launch_finish_blocks(b, s);
+            launch_finish_blocks(b, s, false);
             a.list_a = nullptr; a.n_list_a = 0;
             a.pending = r->pending2; a.pending_count = r->pending_count + 1;
             a.cursor = r->cursor + 8;
@@ -1057,6 +1165,7 @@ int znippy_decode_verify_rows_async(znippy_ctx *ctx, znippy_rows *r, const void 
             if (!ctx->sw.fz_only)
             launch_decode(a, std::min<int>(ctx->decode_grid, (int)r->n_cand), r->wide_rows, s);
             ktime_end(ctx);
+        }
         }
     }
     // 3) second hash pass: slices of big rows + rows the general decoder finished

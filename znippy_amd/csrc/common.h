@@ -152,7 +152,7 @@ struct BlockScanArgs {
 };
 void launch_scan_blocks(const BlockScanArgs &a, hipStream_t s);
 void launch_compact_items(const uint8_t *item_done, uint32_t n_items, uint32_t *todo, uint32_t *n_todo, hipStream_t s);
-void launch_finish_blocks(const BlockScanArgs &a, hipStream_t s);
+void launch_finish_blocks(const BlockScanArgs &a, hipStream_t s, bool defer_flagged);  // defer_flagged: a flagged candidate is left to the batch path
 
 // Foreign frames in two phases (zstd_decode.hip, k_fz_*): frames of >= 2 blocks that the block-item path gave up on
 // (another writer's frames: repeat offsets, reused entropy tables, matches reaching into earlier blocks, any block
@@ -200,5 +200,52 @@ struct FzArgs {
 void launch_fz_scan(const FzArgs &a, uint32_t *work, uint32_t *work_count, hipStream_t s);
 void launch_fz_entropy(const FzArgs &a, int cus, const uint32_t *work, const uint32_t *work_count, hipStream_t s);
 void launch_fz_exec(const FzArgs &a, hipStream_t s);
+
+// Many foreign frames at once (zstd_batch.hip, k_bx_*): the serial chains of a block — table descriptions, Huffman
+// streams, the FSE sequence bitstream — are decoded with LANE = block (or stream), 64 of them per wave, tables in
+// scratch pools in device memory; execution stays wave = frame (k_fz_exec's body).  Everything is sized and listed on
+// the device: the candidates are the host's list of big single-block rows, the rows the fused kernel handed over, and
+// the block candidates the block-item path flagged.
+struct BxPrep {            // per block item, written by k_bx_prep
+    uint32_t frame;        // candidate slot
+    uint32_t k;            // index of the block inside its frame
+    uint32_t n_streams;    // Huffman streams (0: raw / RLE literals)
+    uint32_t huf_off;      // decoding table in the Huffman pool (u16 cells), 1 << huf_log of them
+    uint32_t huf_log;
+    uint32_t st_off[4];    // streams: offset from the frame's first byte, bytes
+    uint32_t st_len[4];
+    uint32_t tab[3];       // LL / OF / ML decoding table in the FSE pool (u32 cells)
+    uint32_t logs;         // log LL | log OF << 8 | log ML << 16
+    uint32_t bs_off;       // sequences bitstream: offset from the frame's first byte
+    uint32_t bs_len;       // bytes
+};
+constexpr uint32_t BX_PREDEF_LL = 0, BX_PREDEF_OF = 64, BX_PREDEF_ML = 96, BX_POOL_FIRST = 160;  // predefined tables at the head of the FSE pool
+// FSE pool cell: next:9 | nbits:4 << 9 | addbits:5 << 13 | symbol:6 << 18
+struct BxArgs {
+    const uint32_t *list_a; uint32_t n_list_a;
+    const uint32_t *pending; const uint32_t *pending_count;
+    const uint32_t *bc_row; uint32_t n_bc;  // block candidates: taken when row_flag != 0
+    const uint8_t *blobs; uint64_t blob_base;
+    const uint64_t *blob_off, *blob_size, *usize, *out_off;
+    uint64_t out_cap;
+    uint8_t *out;
+    int32_t *status;
+    int preset;
+    uint32_t *row_flag;  // per row: 1 = taken here and not (yet) decoded
+    uint32_t *cand_row, *cand_base, *cand_nb;  // per candidate slot (written by the scan)
+    uint32_t slot_cap;
+    FzItem *items; BxPrep *prep; uint32_t item_cap;
+    uint32_t *ctr;  // [0] slots, [1] items, [2] Huffman list, [3] sequence list, [4..7] work cursors (zeroed per run)
+    uint32_t *huf_list, *seq_list;
+    uint8_t *lit_pool; uint64_t lit_cap;
+    unsigned long long *seq_pool; uint64_t seq_cap;
+    uint32_t *fse_pool; uint64_t fse_cap;   // cells
+    uint16_t *huf_pool; uint64_t huf_cap;   // cells
+    unsigned long long *pool_used;  // [0] literal bytes [1] records [2] frames decoded [3] blocks given up [4..7] why [8] FSE cells [9] Huffman cells (zeroed per run)
+    uint32_t *pending2, *pending2_count;  // what is left for the serial decoder
+    unsigned long long *dbg;
+};
+void launch_bx(const BxArgs &a, int cus, hipStream_t s);
+void bx_predefined_tables(uint32_t cells[160]);  // host: the three predefined tables as pool cells
 
 }  // namespace zn

@@ -1,5 +1,6 @@
 // Foreign zstd frames, block-parallel (gfx950): the two-phase path of codec::decompress_into
 // (znippy-common/src/codec.rs:L67-78) for frames another writer produced.  See the section comments.
+#include <algorithm>
 #include "zstd_dev.h"
 
 namespace zn {
@@ -521,11 +522,9 @@ __global__ __launch_bounds__(128, 4) void k_fz_entropy(FzArgs a, const uint32_t 
     }
 }
 
+// One frame, executed by one wave: the blocks' records and literals come from the pools, W is the wave's LDS window.
 template <bool PROF>
-__global__ __launch_bounds__(64) void k_fz_exec(FzArgs a) {
-    __shared__ __attribute__((aligned(16))) uint8_t W[WIN_HIST + WIN_CAP + 64];
-    const uint32_t c = blockIdx.x, lane = threadIdx.x;
-    if (c >= a.n_cand) return;
+__device__ __forceinline__ void fz_exec_frame(const FzArgs &a, const uint32_t c, uint8_t *const W, const uint32_t lane) {
     const uint32_t nb = a.cand_nb[c];
     if (!nb) return;
     const uint32_t row = a.cand_row[c], base = a.cand_fzbase[c];
@@ -704,6 +703,12 @@ linc = wave_incl_scan(linc); pinc = wave_incl_scan(pinc);
     }
 }
 
+template <bool PROF>
+__global__ __launch_bounds__(64) void k_fz_exec(FzArgs a) {
+    __shared__ __attribute__((aligned(16))) uint8_t W[WIN_HIST + WIN_CAP + 64];
+    if (blockIdx.x < a.n_cand) fz_exec_frame<PROF>(a, blockIdx.x, W, threadIdx.x);
+}
+
 void launch_fz_scan(const FzArgs &a, uint32_t *work, uint32_t *work_count, hipStream_t s) {
     hipLaunchKernelGGL(k_fz_scan, dim3(a.n_cand), dim3(64), 0, s, a, work, work_count);
 }
@@ -716,5 +721,854 @@ void launch_fz_exec(const FzArgs &a, hipStream_t s) {
     else hipLaunchKernelGGL(k_fz_exec<false>, dim3(a.n_cand), dim3(64), 0, s, a);
 }
 
+
+
+// =============================================================================================
+// Many foreign frames at once: LANE = block.
+// The two-phase kernels above give every block a wave (or two) and run its serial chains — table descriptions, Huffman
+// streams, the FSE sequence bitstream — on one lane or on the scalar unit: 63 of 64 lanes idle, and an archive of
+// 100,000 small text frames decodes at the rate of ~1,000 lone waves.  With that many frames the chains
+// are vectorised ACROSS blocks instead: 64 blocks per wave, one per lane, each lane running plain per-thread code on
+// its own block with its tables in scratch pools in device memory (a lane's table lookups are gathers served by
+// L2 / Infinity Cache; 64 chains per wave and thousands of waves hide their latency).
+//   k_bx_scan   lane = candidate frame (the host's list of big single-block rows, the rows the fused kernel handed
+//               over, the block candidates the block-item path flagged): frame header, walk of the block headers,
+//               item slots handed out by one atomic per wave
+//   k_bx_prep   lane = block: literals header, Huffman tree description -> weights -> decoding table (Huffman pool);
+//               sequences header, table descriptions -> decoding tables (FSE pool, 4-byte cells); pool space for the
+//               block's literals and records; the block joins the Huffman and / or the sequence list
+//   k_bx_huf    lane = Huffman stream, 16 blocks per wave with their tables copied into LDS
+//   k_bx_fse    lane = block: the sequence bitstream -> 8-byte records, repeat offsets resolved on the way (against a
+//               symbolic incoming history for blocks that are not the first of their frame, as k_fz_entropy does)
+//   k_bx_exec   wave = frame: fz_exec_frame
+//   k_bx_finish lane = candidate: decoded -> status 2, anything else -> the serial decoder's list
+// Any error or anything unsupported leaves the frame to the serial decoder, which also produces the error code.
+// =============================================================================================
+struct BxScratch {  // per wave; [i * 64 + lane]: a lane's i-th entry (consecutive lanes, consecutive addresses)
+    int16_t norm[64 * 64];
+    uint16_t nxt[64 * 64];
+    uint16_t wtab[64 * 64];     // FSE table of the Huffman weights: weight:4 | nbits:3 << 4 | next:6 << 7
+    uint8_t weights[256 * 64];
+    uint16_t rank[16 * 64];
+};
+
+// every lane asks for `mine` units: one atomic per wave (all 64 lanes call this, converged)
+__device__ __forceinline__ uint32_t wave_alloc32(uint32_t *counter, uint32_t mine, uint32_t lane) {
+    const uint32_t incl = wave_incl_scan(mine);
+    const uint32_t total = rdlane_u(incl, 63);
+    uint32_t base = 0;
+    if (lane == 0 && total) base = atomicAdd(counter, total);
+    return rdlane_u(base, 0) + incl - mine;
+}
+__device__ __forceinline__ uint64_t wave_alloc64(unsigned long long *counter, uint32_t mine, uint32_t lane) {
+    const uint32_t incl = wave_incl_scan(mine);
+    const uint32_t total = rdlane_u(incl, 63);
+    unsigned long long base = 0;
+    if (lane == 0 && total) base = atomicAdd(counter, (unsigned long long)total);
+    return rdlane64_u(base, 0) + incl - mine;
+}
+
+// forward bit reader with a 64-bit register window (table descriptions); bytes past n read as zero
+struct FwdW {
+    const uint8_t *p;
+    uint32_t n, bitpos, wbit;
+    uint64_t win;
+    __device__ __forceinline__ void fill(uint32_t byte) {
+        uint64_t v = 0;
+        if (byte + 8 <= n) __builtin_memcpy(&v, p + byte, 8);
+        else for (uint32_t i = 0; i < 8 && byte + i < n; i++) v |= (uint64_t)p[byte + i] << (8 * i);
+        win = v;
+        wbit = byte * 8;
+    }
+    __device__ __forceinline__ void init(const uint8_t *src, uint32_t len) { p = src; n = len; bitpos = 0; fill(0); }
+    __device__ __forceinline__ uint32_t peek(uint32_t nb) {  // nb <= 25
+        if (bitpos + nb > wbit + 64) fill(bitpos >> 3);
+        return (uint32_t)(win >> (bitpos - wbit)) & ((1u << nb) - 1u);
+    }
+    __device__ __forceinline__ uint32_t read(uint32_t nb) { const uint32_t v = peek(nb); bitpos += nb; return v; }
+};
+
+#define BX_NORM(i) S.norm[(i) * 64 + lane]
+#define BX_NXT(i) S.nxt[(i) * 64 + lane]
+#define BX_W(i) S.weights[(i) * 64 + lane]
+
+// fse_read_ncount for one lane (RFC 8878 4.1.1); at most 64 symbols (what a lane's scratch holds)
+__device__ int bx_read_ncount(BxScratch &S, const uint32_t lane, const uint8_t *src, uint32_t n, int max_log, int max_sym, int *nsym,
+                              int *log, uint32_t *consumed) {
+    if (n == 0) return E_TRUNC;
+    FwdW b;
+    b.init(src, n);
+    const int alog = 5 + (int)b.read(4);
+    if (alog > max_log) return E_CORRUPT;
+    int remaining = 1 << alog, s = 0;
+    while (remaining > 0 && s <= max_sym) {
+        const int bits = hibit((uint32_t)remaining + 1) + 1;
+        uint32_t val = b.peek((uint32_t)bits);
+        const uint32_t lower_mask = (1u << (bits - 1)) - 1, threshold = (1u << bits) - 1 - ((uint32_t)remaining + 1);
+        if ((val & lower_mask) < threshold) { b.bitpos += (uint32_t)bits - 1; val &= lower_mask; }
+        else { b.bitpos += (uint32_t)bits; if (val > lower_mask) val -= threshold; }
+        const int proba = (int)val - 1;
+        remaining -= proba < 0 ? -proba : proba;
+        if (s >= 64) return E_UNSUP;
+        BX_NORM(s++) = (int16_t)proba;
+        if (proba == 0) {
+            uint32_t rep = b.read(2);
+            for (;;) {
+                for (uint32_t i = 0; i < rep && s <= max_sym; i++) { if (s >= 64) return E_UNSUP; BX_NORM(s++) = 0; }
+                if (rep == 3) rep = b.read(2); else break;
+            }
+        }
+    }
+    if (remaining != 0) return E_CORRUPT;
+    if ((b.bitpos + 7) / 8 > n) return E_TRUNC;
+    *nsym = s;
+    *log = alog;
+    *consumed = (b.bitpos + 7) / 8;
+    return 0;
+}
+
+// Spread of the symbols over the table cells (RFC 8878 4.1.1): put(cell, symbol); the lane's next-state counters are set.
+template <class Put>
+__device__ __forceinline__ int bx_fse_spread(BxScratch &S, const uint32_t lane, int nsym, int log, Put put) {
+    const int size = 1 << log;
+    int high = size;
+    for (int s = 0; s < nsym; s++)
+        if (BX_NORM(s) == -1) { put((uint32_t)--high, (uint32_t)s); BX_NXT(s) = 1; }
+    const int step = (size >> 1) + (size >> 3) + 3, mask = size - 1;
+    int pos = 0;
+    for (int s = 0; s < nsym; s++) {
+        const int c = BX_NORM(s);
+        if (c <= 0) continue;
+        BX_NXT(s) = (uint16_t)c;
+        for (int i = 0; i < c; i++) {
+            put((uint32_t)pos, (uint32_t)s);
+            do { pos = (pos + step) & mask; } while (pos >= high);
+        }
+    }
+    return pos == 0 ? 0 : E_CORRUPT;
+}
+
+__device__ __forceinline__ uint32_t bx_cell(uint32_t next, uint32_t nb, uint32_t addbits, uint32_t sym) {
+    return next | (nb << 9) | (addbits << 13) | (sym << 18);
+}
+__device__ __forceinline__ int bx_addbits(int kind, uint32_t sym, uint32_t *ab) {
+    if (kind == K_LL) { if (sym > 35) return E_CORRUPT; *ab = c_ll_bits[sym]; }
+    else if (kind == K_ML) { if (sym > 52) return E_CORRUPT; *ab = c_ml_bits[sym]; }
+    else { if (sym > 31) return E_CORRUPT; *ab = sym; }
+    return 0;
+}
+
+// One sequence table of one lane's block, from its counts (BX_NORM) into cells[0 .. 1 << log) of the FSE pool.
+__device__ int bx_build_seq_table(BxScratch &S, const uint32_t lane, int nsym, int log, int kind, uint32_t *cells) {
+    int rc = bx_fse_spread(S, lane, nsym, log, [&](uint32_t u, uint32_t sym) { cells[u] = sym; });
+    if (rc) return rc;
+    const uint32_t size = 1u << log;
+    for (uint32_t u = 0; u < size; u++) {
+        const uint32_t sym = cells[u] & 63;  // this lane's own store (vector memory operations of a wave stay in order)
+        const uint32_t ns = BX_NXT(sym);
+        BX_NXT(sym) = (uint16_t)(ns + 1);
+        const uint32_t nb = (uint32_t)log - (uint32_t)hibit(ns);
+        uint32_t ab = 0;
+        rc = bx_addbits(kind, sym, &ab);
+        if (rc) return rc;
+        cells[u] = bx_cell((ns << nb) - size, nb, ab, sym);
+    }
+    return 0;
+}
+
+// Huffman tree description -> this lane's weights (BX_W) -> decoding table in the Huffman pool.
+// Returns 0 and sets *consumed (bytes of the description), *hlog, *hoff (first cell), or an error.
+__device__ int bx_read_tree(BxScratch &S, const uint32_t lane, const BxArgs &a, const uint8_t *src, uint32_t n, const uint8_t *blob_end,
+                            uint32_t *consumed, uint32_t *hlog, uint32_t *hoff) {
+    if (n < 1) return E_TRUNC;
+    const uint32_t hb = src[0];
+    uint32_t nw = 0;
+    if (hb >= 128) {
+        nw = hb - 127;
+        const uint32_t bytes = (nw + 1) / 2;
+        if (1 + bytes > n) return E_TRUNC;
+        for (uint32_t i = 0; i < nw; i++) {
+            const uint8_t b = src[1 + i / 2];
+            BX_W(i) = (i & 1) ? (b & 15) : (b >> 4);
+        }
+        *consumed = 1 + bytes;
+    } else {
+        if (hb == 0 || 1 + hb > n) return E_TRUNC;
+        int nsym = 0, log = 0;
+        uint32_t hdr = 0;
+        int rc = bx_read_ncount(S, lane, src + 1, hb, 6, 255, &nsym, &log, &hdr);
+        if (rc) return rc;
+        rc = bx_fse_spread(S, lane, nsym, log, [&](uint32_t u, uint32_t sym) { S.wtab[u * 64 + lane] = (uint16_t)sym; });
+        if (rc) return rc;
+        const uint32_t size = 1u << log;
+        for (uint32_t u = 0; u < size; u++) {
+            const uint32_t sym = S.wtab[u * 64 + lane];
+            const uint32_t ns = BX_NXT(sym);
+            BX_NXT(sym) = (uint16_t)(ns + 1);
+            const uint32_t nb = (uint32_t)log - (uint32_t)hibit(ns);
+            S.wtab[u * 64 + lane] = (uint16_t)((sym > 15 ? 15u : sym) | (nb << 4) | (((ns << nb) - size) << 7));  // a weight above 12 is rejected below
+        }
+        if (hdr >= hb) return E_CORRUPT;
+        BitR b;
+        if (!b.init(src + 1 + hdr, hb - hdr, blob_end)) return E_CORRUPT;
+        uint32_t s1 = b.read((uint32_t)log), s2 = b.read((uint32_t)log);
+        for (;;) {
+            const uint32_t e1 = S.wtab[s1 * 64 + lane];
+            if (nw >= 255) return E_CORRUPT;
+            BX_W(nw++) = (uint8_t)(e1 & 15);
+            s1 = (e1 >> 7) + b.read((e1 >> 4) & 7);
+            const uint32_t e2 = S.wtab[s2 * 64 + lane];
+            if (b.pos < 0) {
+                if (nw >= 255) return E_CORRUPT;
+                BX_W(nw++) = (uint8_t)(e2 & 15);
+                break;
+            }
+            if (nw >= 255) return E_CORRUPT;
+            BX_W(nw++) = (uint8_t)(e2 & 15);
+            s2 = (e2 >> 7) + b.read((e2 >> 4) & 7);
+            if (b.pos < 0) {
+                if (nw >= 255) return E_CORRUPT;
+                BX_W(nw++) = (uint8_t)(S.wtab[s1 * 64 + lane] & 15);
+                break;
+            }
+        }
+        *consumed = 1 + hb;
+    }
+    // implied last weight, code lengths, first cell of every rank
+    uint32_t total = 0;
+    for (uint32_t i = 0; i < nw; i++) {
+        const uint32_t w = BX_W(i);
+        if (w > 12) return E_CORRUPT;
+        total += w ? 1u << (w - 1) : 0;
+    }
+    if (total == 0) return E_CORRUPT;
+    const uint32_t maxbits = (uint32_t)hibit(total) + 1;
+    if (maxbits > 11) return E_CORRUPT;
+    const uint32_t left = (1u << maxbits) - total;
+    if (left & (left - 1)) return E_CORRUPT;
+    BX_W(nw) = (uint8_t)(hibit(left) + 1);
+    const uint32_t nsym = nw + 1;
+    for (uint32_t i = 0; i < 16; i++) S.rank[i * 64 + lane] = 0;
+    for (uint32_t i = 0; i < nsym; i++) {
+        const uint32_t w = BX_W(i);
+        if (w) S.rank[(maxbits + 1 - w) * 64 + lane] += 1;  // count per code length
+    }
+    {   // counts -> first cells, longest codes first (as the table is laid out)
+        uint32_t start = 0;
+        for (uint32_t bits = maxbits; bits >= 1; bits--) {
+            const uint32_t cnt = S.rank[bits * 64 + lane];
+            S.rank[bits * 64 + lane] = (uint16_t)start;
+            start += cnt << (maxbits - bits);
+        }
+        if (start != (1u << maxbits)) return E_CORRUPT;
+    }
+    const uint32_t cells = 1u << maxbits, room = cells < 8 ? 8u : cells;  // 16-byte granules
+    const unsigned long long off = atomicAdd(&a.pool_used[9], (unsigned long long)room);
+    if (off + room > a.huf_cap) return E_UNSUP;
+    uint16_t *const t = a.huf_pool + off;
+    for (uint32_t sym = 0; sym < nsym; sym++) {
+        const uint32_t w = BX_W(sym);
+        if (!w) continue;
+        const uint32_t bits = maxbits + 1 - w, len = 1u << (w - 1);
+        const uint32_t st = S.rank[bits * 64 + lane];
+        S.rank[bits * 64 + lane] = (uint16_t)(st + len);
+        const uint32_t e = sym | (bits << 8), e2 = e | (e << 16);
+        if (len >= 8) {
+            const uint4 v = make_uint4(e2, e2, e2, e2);
+            for (uint32_t i = 0; i < len; i += 8) *reinterpret_cast<uint4 *>(t + st + i) = v;  // st is a multiple of len
+        } else for (uint32_t i = 0; i < len; i++) t[st + i] = (uint16_t)e;
+    }
+    *hlog = maxbits;
+    *hoff = (uint32_t)off;
+    return 0;
+}
+
+// Sequences_Section_Header of the section [q, q + n) of one lane's block: number of sequences, then the table
+// descriptions.  Kinds in `want` (bit 0 LL, 1 OF, 2 ML) that are described here get their table (tab[], logs[]); those in
+// Repeat_Mode come back in *missing.
+__device__ int bx_seq_tables(BxScratch &S, const uint32_t lane, const BxArgs &a, const uint8_t *q, uint32_t n, uint32_t want, uint32_t *missing,
+                             uint32_t *nseq_out, uint32_t *bits_at, uint32_t tab[3], uint32_t logs[3]) {
+    if (n < 1) return E_TRUNC;
+    uint32_t p = 0, nseq = 0;
+    const uint32_t b0 = q[0];
+    if (b0 == 0) { nseq = 0; p = 1; }
+    else if (b0 < 128) { nseq = b0; p = 1; }
+    else if (b0 < 255) { if (n < 2) return E_TRUNC; nseq = ((b0 - 128) << 8) + q[1]; p = 2; }
+    else { if (n < 3) return E_TRUNC; nseq = q[1] + ((uint32_t)q[2] << 8) + 0x7F00; p = 3; }
+    *nseq_out = nseq;
+    *missing = want;
+    *bits_at = p;
+    if (!nseq) return 0;
+    if (p >= n) return E_TRUNC;
+    const uint32_t modes = q[p++];
+    if (modes & 3) return E_CORRUPT;
+    uint32_t miss = 0;
+    for (int k = 0; k < 3; k++) {
+        const uint32_t mode = (modes >> (6 - 2 * k)) & 3;
+        const bool wanted = (want >> k) & 1;
+        const int kind = k == 0 ? K_LL : (k == 1 ? K_OF : K_ML);
+        if (mode == 0) {
+            if (wanted) { tab[k] = k == 0 ? BX_PREDEF_LL : (k == 1 ? BX_PREDEF_OF : BX_PREDEF_ML); logs[k] = k == 1 ? 5 : 6; }
+        } else if (mode == 1) {
+            if (p >= n) return E_TRUNC;
+            if (wanted) {
+                const uint32_t sym = q[p];
+                uint32_t ab = 0;
+                const int rc = bx_addbits(kind, sym, &ab);
+                if (rc) return rc;
+                const unsigned long long off = atomicAdd(&a.pool_used[8], 1ull) + BX_POOL_FIRST;
+                if (off + 1 > a.fse_cap) return E_UNSUP;
+                a.fse_pool[off] = bx_cell(0, 0, ab, sym);
+                tab[k] = (uint32_t)off; logs[k] = 0;
+            }
+            p++;
+        } else if (mode == 2) {
+            int nsym = 0, log = 0;
+            uint32_t used = 0;
+            int rc = bx_read_ncount(S, lane, q + p, n - p, k == 1 ? 8 : 9, k == 0 ? 35 : (k == 1 ? 31 : 52), &nsym, &log, &used);
+            if (rc) return rc;
+            if (wanted) {
+                const unsigned long long off = atomicAdd(&a.pool_used[8], 1ull << log) + BX_POOL_FIRST;
+                if (off + (1ull << log) > a.fse_cap) return E_UNSUP;
+                rc = bx_build_seq_table(S, lane, nsym, log, kind, a.fse_pool + off);
+                if (rc) return rc;
+                tab[k] = (uint32_t)off; logs[k] = (uint32_t)log;
+            }
+            p += used;
+        } else if (wanted) miss |= 1u << k;
+    }
+    *missing = miss;
+    *bits_at = p;
+    return 0;
+}
+
+__global__ __launch_bounds__(64) void k_bx_scan(BxArgs a) {
+    const uint32_t lane = threadIdx.x;
+    const uint32_t n_pend = *a.pending_count;
+    const uint32_t n_slots = a.n_list_a + n_pend + a.n_bc;
+    if (blockIdx.x == 0 && lane == 0) a.ctr[0] = n_slots;
+    for (uint32_t t0 = blockIdx.x * 64; t0 < n_slots; t0 += gridDim.x * 64) {
+        const uint32_t t = t0 + lane;
+        bool take = t < n_slots;
+        uint32_t row = 0xFFFFFFFFu;
+        if (take) {
+            if (t < a.n_list_a) row = a.list_a[t];
+            else if (t < a.n_list_a + n_pend) row = a.pending[t - a.n_list_a];
+            else { row = a.bc_row[t - a.n_list_a - n_pend]; take = a.row_flag[row] != 0; }
+            if (take && a.preset && a.status[row] < 0) take = false;  // the host has ruled on this row
+        }
+        uint32_t nb = 0;
+        uint64_t first = 0, n = 0;
+        const uint8_t *src = a.blobs;
+        if (take) {
+            a.row_flag[row] = 1;
+            src = a.blobs + (a.blob_off[row] - a.blob_base);
+            n = a.blob_size[row];
+            const uint64_t fcs_want = a.usize[row];
+            bool ok = n >= 9 && n < 0xFFFF0000ull && (src[0] | (src[1] << 8) | (src[2] << 16) | ((uint32_t)src[3] << 24)) == 0xFD2FB528u;
+            uint64_t pos = 5;
+            if (ok) {
+                const uint32_t fhd = src[4];
+                const uint32_t fcs_flag = fhd >> 6, single = (fhd >> 5) & 1, did_flag = fhd & 3;
+                const uint32_t fcs_bytes = fcs_flag == 0 ? single : (1u << fcs_flag);
+                ok = !(fhd & 8) && !((fhd >> 2) & 1) && did_flag == 0 && fcs_bytes != 0;  // a checksum trailer is the serial decoder's
+                if (ok) {
+                    if (!single) pos++;
+                    ok = pos + fcs_bytes <= n;
+                    uint64_t fcs = 0;
+                    for (uint32_t i = 0; ok && i < fcs_bytes; i++) fcs |= (uint64_t)src[pos + i] << (8 * i);
+                    if (fcs_bytes == 2) fcs += 256;
+                    pos += fcs_bytes;
+                    ok = ok && fcs == fcs_want && fcs < 0xFFFFFFFFull && a.out_off[row] + fcs <= a.out_cap;
+                }
+            }
+            first = pos;
+            uint32_t k = 0;
+            bool last = false;
+            while (ok && !last) {
+                if (pos + 3 > n) { ok = false; break; }
+                const uint32_t bh = src[pos] | (src[pos + 1] << 8) | (src[pos + 2] << 16);
+                const uint32_t type = (bh >> 1) & 3, size = bh >> 3;
+                const uint64_t step = 3 + (type == 1 ? 1 : size);
+                if (type == 3 || size > BLOCK_MAX || pos + step > n) { ok = false; break; }
+                pos += step;
+                last = bh & 1;
+                k++;
+            }
+            ok = ok && pos == n;
+            nb = ok ? k : 0;
+        }
+        const uint32_t base = wave_alloc32(&a.ctr[1], nb, lane);
+        if (nb && base + nb > a.item_cap) nb = 0;  // out of item slots: the serial decoder keeps the frame
+        if (nb) {
+            uint64_t pos = first;
+            for (uint32_t k = 0; k < nb; k++) {
+                const uint32_t bh = src[pos] | (src[pos + 1] << 8) | (src[pos + 2] << 16);
+                a.items[base + k].src = (uint32_t)pos;
+                a.prep[base + k].frame = t;
+                a.prep[base + k].k = k;
+                pos += 3 + (((bh >> 1) & 3) == 1 ? 1 : (bh >> 3));
+            }
+        }
+        if (t < n_slots) { a.cand_row[t] = take ? row : 0xFFFFFFFFu; a.cand_base[t] = base; a.cand_nb[t] = nb; }
+    }
+}
+
+__global__ __launch_bounds__(64) void k_bx_prep(BxArgs a) {
+    __shared__ BxScratch S;
+    const uint32_t lane = threadIdx.x;
+    const uint32_t n_items = a.ctr[1] < a.item_cap ? a.ctr[1] : a.item_cap;
+    for (uint32_t i0 = blockIdx.x * 64; i0 < n_items; i0 += gridDim.x * 64) {
+        const uint32_t slot = i0 + lane;
+        const bool on = slot < n_items;
+        bool huf = false, seq = false;
+        if (on) {
+            const BxPrep pr0 = a.prep[slot];
+            const uint32_t c = pr0.frame, k = pr0.k, base = slot - k, row = a.cand_row[c];
+            const uint8_t *const src = a.blobs + (a.blob_off[row] - a.blob_base);
+            const uint8_t *const blob_end = src + a.blob_size[row];
+            const uint32_t pos = a.items[slot].src;
+            const uint32_t bh = src[pos] | (src[pos + 1] << 8) | (src[pos + 2] << 16);
+            const uint32_t btype = (bh >> 1) & 3, bsize = bh >> 3;
+            const uint8_t *const bsrc = src + pos + 3;
+            FzItem it;
+            it.src = pos; it.out = 0; it.nseq = 0; it.lit_len = 0; it.seq_off = 0; it.lit_off = 0; it.lit_kind = 0; it.err = 0;
+            it.rep[0] = FZ_SYM; it.rep[1] = FZ_SYM | (1u << 26); it.rep[2] = FZ_SYM | (2u << 26); it.pad = 0;
+            BxPrep pr = pr0;
+            pr.n_streams = 0; pr.huf_off = 0; pr.huf_log = 0; pr.logs = 0; pr.bs_off = 0; pr.bs_len = 0;
+            pr.tab[0] = pr.tab[1] = pr.tab[2] = 0;
+            for (int j = 0; j < 4; j++) { pr.st_off[j] = 0; pr.st_len[j] = 0; }
+            int err = 0;
+            uint32_t why = 0;
+            if (btype != 2) {  // raw / RLE block: literals only
+                it.out = bsize; it.lit_len = bsize;
+                it.lit_kind = btype == 0 ? 0u : 1u;
+                it.lit_off = btype == 0 ? (uint64_t)pos + 3 : (uint64_t)bsrc[0];
+            } else {
+                LitHdr h;
+                err = fz_lit_header(bsrc, bsize, h);
+                uint32_t seq_pos = 0;
+                if (!err) {
+                    it.lit_len = h.regen;
+                    seq_pos = fz_lit_section_bytes(h);
+                    if (h.type == 0) { it.lit_kind = 0; it.lit_off = (uint64_t)pos + 3 + h.hdr; }
+                    else if (h.type == 1) { it.lit_kind = 1; it.lit_off = bsrc[h.hdr]; }
+                    else {
+                        it.lit_kind = 2;
+                        uint32_t p = h.hdr, remain = h.comp;
+                        if (h.type == 2) {
+                            uint32_t tu = 0;
+                            err = bx_read_tree(S, lane, a, bsrc + p, remain, blob_end, &tu, &pr.huf_log, &pr.huf_off);
+                            if (!err) { p += tu; remain -= tu; }
+                        } else {  // treeless: the tree of the nearest earlier block of the frame that carries a description (re-read)
+                            err = E_UNSUP; why = 1;
+                            for (uint32_t back = 1; back <= FZ_BACK && back <= k; back++) {
+                                const uint32_t pj = a.items[base + k - back].src;
+                                const uint32_t bj = src[pj] | (src[pj + 1] << 8) | (src[pj + 2] << 16);
+                                if (((bj >> 1) & 3) != 2) continue;
+                                LitHdr hj;
+                                if (fz_lit_header(src + pj + 3, bj >> 3, hj)) { err = E_CORRUPT; break; }
+                                if (hj.type == 2) {
+                                    uint32_t tu = 0;
+                                    err = bx_read_tree(S, lane, a, src + pj + 3 + hj.hdr, hj.comp, blob_end, &tu, &pr.huf_log, &pr.huf_off);
+                                    why = 0;
+                                    break;
+                                }
+                            }
+                        }
+                        if (!err) {
+                            const uint32_t regen = h.regen;
+                            if (h.streams == 1) { pr.st_off[0] = pos + 3 + p; pr.st_len[0] = remain; }
+                            else {
+                                const uint32_t seg = (regen + 3) / 4;
+                                if (remain < 6 || 3 * seg > regen) err = E_CORRUPT;
+                                else {
+                                    const uint32_t s1 = bsrc[p] | (bsrc[p + 1] << 8), s2 = bsrc[p + 2] | (bsrc[p + 3] << 8), s3 = bsrc[p + 4] | (bsrc[p + 5] << 8);
+                                    if (6 + s1 + s2 + s3 > remain) err = E_CORRUPT;
+                                    else {
+                                        const uint32_t o = pos + 3 + p + 6;
+                                        pr.st_off[0] = o; pr.st_len[0] = s1;
+                                        pr.st_off[1] = o + s1; pr.st_len[1] = s2;
+                                        pr.st_off[2] = o + s1 + s2; pr.st_len[2] = s3;
+                                        pr.st_off[3] = o + s1 + s2 + s3; pr.st_len[3] = remain - 6 - s1 - s2 - s3;
+                                    }
+                                }
+                            }
+                            pr.n_streams = err ? 0 : h.streams;
+                        }
+                        if (!err) {
+                            const uint64_t room = ((uint64_t)h.regen + 79) & ~15ull;
+                            const unsigned long long off = atomicAdd(&a.pool_used[0], (unsigned long long)room);
+                            if (off + room > a.lit_cap) { err = E_UNSUP; why = 2; }
+                            it.lit_off = off;
+                        }
+                    }
+                }
+                // ---- sequences: header, tables, where the bitstream is ----
+                if (!err) {
+                    if (seq_pos >= bsize) err = E_TRUNC;
+                    uint32_t miss = 0, nseq = 0, bits_at = 0, logs[3] = {0, 0, 0};
+                    const uint8_t *q = bsrc + seq_pos;
+                    const uint32_t qn = bsize - seq_pos;
+                    if (!err) err = bx_seq_tables(S, lane, a, q, qn, 7u, &miss, &nseq, &bits_at, pr.tab, logs);
+                    if (!err && nseq == 0 && bits_at != qn) err = E_CORRUPT;
+                    if (!err && nseq && miss) {
+                        for (uint32_t back = 1; back <= FZ_BACK && back <= k && miss && !err; back++) {
+                            const uint32_t pj = a.items[base + k - back].src;
+                            const uint32_t bj = src[pj] | (src[pj + 1] << 8) | (src[pj + 2] << 16);
+                            if (((bj >> 1) & 3) != 2) continue;
+                            const uint8_t *b = src + pj + 3;
+                            const uint32_t sz = bj >> 3;
+                            LitHdr hj;
+                            if (fz_lit_header(b, sz, hj)) { err = E_CORRUPT; break; }
+                            const uint32_t ls = fz_lit_section_bytes(hj);
+                            if (ls >= sz) { err = E_CORRUPT; break; }
+                            uint32_t m2 = 0, n2 = 0, at2 = 0;
+                            err = bx_seq_tables(S, lane, a, b + ls, sz - ls, miss, &m2, &n2, &at2, pr.tab, logs);
+                            if (!err && n2) miss = m2;
+                        }
+                        if (!err && miss) { err = E_UNSUP; why = 1; }
+                    }
+                    if (!err && nseq) {
+                        if (bits_at >= qn) err = E_TRUNC;
+                        else if (q[qn - 1] == 0) err = E_CORRUPT;
+                        else { pr.bs_off = pos + 3 + seq_pos + bits_at; pr.bs_len = qn - bits_at; }
+                    }
+                    if (!err && nseq) {
+                        const unsigned long long off = atomicAdd(&a.pool_used[1], (unsigned long long)nseq);
+                        if (off + nseq > a.seq_cap) { err = E_UNSUP; why = 2; }
+                        it.seq_off = off;
+                    }
+                    pr.logs = logs[0] | (logs[1] << 8) | (logs[2] << 16);
+                    it.nseq = err ? 0 : nseq;
+                    if (!err && nseq == 0) it.out = it.lit_len;
+                }
+            }
+            it.err = err;
+            if (err) { atomicAdd(&a.pool_used[3], 1ull); atomicAdd(&a.pool_used[4 + (why & 3)], 1ull); }  // statistics
+            a.items[slot] = it;
+            a.prep[slot] = pr;
+            huf = !err && pr.n_streams != 0;
+            seq = !err && it.nseq != 0;
+        }
+        {   // the block joins the lists of the two entropy kernels
+            const uint64_t hm = __ballot(huf), sm = __ballot(seq);
+            const uint64_t below = lane ? (~0ull >> (64 - lane)) : 0ull;
+            uint32_t hb = 0, sb = 0;
+            if (lane == 0 && hm) hb = atomicAdd(&a.ctr[2], (uint32_t)__popcll(hm));
+            if (lane == 0 && sm) sb = atomicAdd(&a.ctr[3], (uint32_t)__popcll(sm));
+            hb = rdlane_u(hb, 0); sb = rdlane_u(sb, 0);
+            if (huf) a.huf_list[hb + (uint32_t)__popcll(hm & below)] = slot;
+            if (seq) a.seq_list[sb + (uint32_t)__popcll(sm & below)] = slot;
+        }
+    }
+}
+
+// lane = Huffman stream; a wave takes 16 blocks of the list and keeps their decoding tables in LDS
+constexpr uint32_t BX_HUF_BLOCKS = 16, BX_HUF_LDS = BX_HUF_BLOCKS * 2048;  // u16 cells
+__global__ __launch_bounds__(64) void k_bx_huf(BxArgs a) {
+    __shared__ __attribute__((aligned(16))) uint16_t T[BX_HUF_LDS];
+    typedef __attribute__((address_space(3))) uint16_t lds16;
+    const uint32_t lane = threadIdx.x, j = lane >> 2, sidx = lane & 3;
+    const uint32_t n_list = a.ctr[2];
+    for (uint32_t g0 = blockIdx.x * BX_HUF_BLOCKS; g0 < n_list; g0 += gridDim.x * BX_HUF_BLOCKS) {
+        const bool on = g0 + j < n_list;
+        const uint32_t slot = on ? a.huf_list[g0 + j] : 0;
+        BxPrep pr;
+        pr.huf_log = 0; pr.huf_off = 0; pr.n_streams = 0; pr.frame = 0;
+        if (on) pr = a.prep[slot];
+        const uint32_t hlog = on ? pr.huf_log : 0;
+        // tables -> LDS, 16 bytes per lane per step (a table is a whole number of 16-byte granules in the pool)
+        __builtin_amdgcn_wave_barrier();
+        for (uint32_t b = 0; b < BX_HUF_BLOCKS; b++) {
+            const uint32_t cells = rdlane_u(on ? (1u << hlog) : 0u, 4 * b), off = rdlane_u(pr.huf_off, 4 * b);
+            for (uint32_t i = lane * 8; i < cells; i += 512) {
+                const uint4 v = *reinterpret_cast<const uint4 *>(a.huf_pool + off + i);
+                *reinterpret_cast<uint4 *>(&T[b * 2048 + i]) = v;
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        if (on && sidx < pr.n_streams) {
+            const uint32_t row = a.cand_row[pr.frame];
+            const uint8_t *const src = a.blobs + (a.blob_off[row] - a.blob_base);
+            const uint8_t *const blob_end = src + a.blob_size[row];
+            const FzItem it = a.items[slot];
+            const uint32_t regen = it.lit_len, seg = (regen + 3) / 4;
+            const uint32_t n_out = pr.n_streams == 1 ? regen : (sidx < 3 ? seg : regen - 3 * seg);
+            uint8_t *const dst = a.lit_pool + it.lit_off + (pr.n_streams == 1 ? 0 : sidx * seg);
+            const uint8_t *const p = src + pr.st_off[sidx];
+            const uint32_t n = pr.st_len[sidx];
+            const lds16 *const huf = (const lds16 *)&T[j * 2048];
+            int rc = 0;
+            BitR b;
+            if (!b.init(p, n, blob_end)) rc = E_CORRUPT;
+            else {
+                const uint32_t mask = (1u << hlog) - 1;
+                uint32_t i = 0;
+                int64_t pos = b.pos;
+                while (i + 4 <= n_out && pos >= 64) {  // four symbols (<= 44 bits) out of one 8-byte load, one 4-byte store
+                    const int64_t b0 = ((pos + 7) >> 3) - 8;
+                    uint64_t c;
+                    __builtin_memcpy(&c, p + b0, 8);
+                    int32_t avail = (int32_t)(pos - b0 * 8);
+                    uint32_t w = 0;
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        const uint32_t e = huf[(uint32_t)(c >> (avail - (int32_t)hlog)) & mask];
+                        w |= (e & 0xFFu) << (8 * q);
+                        avail -= (int32_t)(e >> 8);
+                    }
+                    pos = b0 * 8 + avail;
+                    __builtin_memcpy(dst + i, &w, 4);
+                    i += 4;
+                }
+                b.pos = pos;
+                b.refill();
+                for (; i < n_out; i++) {
+                    const uint32_t e = huf[b.peek(hlog)];
+                    dst[i] = (uint8_t)e;
+                    b.pos -= e >> 8;
+                }
+                if (b.pos != 0) rc = E_CORRUPT;
+            }
+            if (rc) a.items[slot].err = rc;
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// the n (<= 32) bits of the 128-bit little-endian value hi:lo that start at bit s (s + n <= 128)
+__device__ __forceinline__ uint32_t bx_ext(uint64_t lo, uint64_t hi, uint32_t s, uint32_t n) {
+    const uint64_t v = s >= 64 ? hi >> (s - 64) : (lo >> s) | ((hi << 1) << (63 - s));
+    return (uint32_t)v & (n >= 32 ? 0xFFFFFFFFu : (1u << n) - 1u);
+}
+__device__ __forceinline__ uint64_t bx_ext64(uint64_t lo, uint64_t hi, uint32_t s, uint32_t n) {  // n <= 63
+    const uint64_t v = s >= 64 ? hi >> (s - 64) : (lo >> s) | ((hi << 1) << (63 - s));
+    return v & ((1ull << n) - 1ull);
+}
+
+// lane = block: the FSE sequence bitstream -> records
+__global__ __launch_bounds__(64) void k_bx_fse(BxArgs a) {
+    __shared__ uint32_t s_llb[36], s_mlb[53];
+    const uint32_t lane = threadIdx.x;
+    if (lane < 36) s_llb[lane] = c_ll_base[lane];
+    if (lane < 53) s_mlb[lane] = c_ml_base[lane];
+    __builtin_amdgcn_wave_barrier();
+    const uint32_t n_list = a.ctr[3];
+    for (uint32_t g0 = blockIdx.x * 64; g0 < n_list; g0 += gridDim.x * 64) {
+        const bool on0 = g0 + lane < n_list;
+        const uint32_t slot = on0 ? a.seq_list[g0 + lane] : 0;
+        BxPrep pr;
+        pr.frame = 0; pr.k = 0; pr.logs = 0; pr.bs_off = 0; pr.bs_len = 0; pr.tab[0] = pr.tab[1] = pr.tab[2] = 0;
+        FzItem it;
+        it.nseq = 0; it.seq_off = 0; it.lit_len = 0;
+        if (on0) { pr = a.prep[slot]; it = a.items[slot]; }
+        const uint32_t nseq = on0 ? it.nseq : 0;
+        const uint32_t row = on0 ? a.cand_row[pr.frame] : 0;
+        const uint64_t foff = on0 ? a.blob_off[row] - a.blob_base : 0;  // the frame inside the blob region
+        const uint8_t *const bb = a.blobs + foff + pr.bs_off;           // first byte of the bitstream
+        const bool head_ok = foff + pr.bs_off >= 16;                    // 16 bytes in front of the stream can be read
+        const uint32_t *const tl = a.fse_pool + pr.tab[0], *const to = a.fse_pool + pr.tab[1], *const tm = a.fse_pool + pr.tab[2];
+        const uint32_t log_l = pr.logs & 255, log_o = (pr.logs >> 8) & 255, log_m = (pr.logs >> 16) & 255;
+        unsigned long long *const recs = a.seq_pool + it.seq_off;
+        // the 16 stream bytes that end at byte `bend` (bytes in front of the stream read as zero)
+        auto window = [&](int32_t bend, uint64_t &lo, uint64_t &hi) {
+            if (bend >= 16 || head_ok) {
+                __builtin_memcpy(&lo, bb + bend - 16, 8);
+                __builtin_memcpy(&hi, bb + bend - 8, 8);
+                if (bend < 16) {  // zero what lies in front of the stream
+                    const uint32_t z = 8u * (uint32_t)(16 - bend);  // bits, 8 .. 128
+                    if (z >= 64) { lo = 0; hi = z >= 128 ? 0 : (hi >> (z - 64)) << (z - 64); }
+                    else lo = (lo >> z) << z;
+                }
+            } else {
+                lo = 0; hi = 0;
+                for (int32_t k = 0; k < 16; k++) {
+                    const int32_t o = bend - 16 + k;
+                    const uint64_t byte = o >= 0 ? bb[o] : 0;
+                    if (k < 8) lo |= byte << (8 * k); else hi |= byte << (8 * (k - 8));
+                }
+            }
+        };
+        int err = 0;
+        int32_t left = 0;
+        uint32_t sl = 0, so = 0, sm = 0;
+        if (nseq) {
+            const uint32_t last = bb[pr.bs_len - 1];  // != 0 (k_bx_prep)
+            left = (int32_t)(pr.bs_len * 8) - (8 - hibit(last));
+            const uint32_t need = log_l + log_o + log_m;
+            if (left < (int32_t)need) err = E_CORRUPT;
+            else {
+                const int32_t bend = (left + 7) >> 3;
+                uint64_t lo, hi;
+                window(bend, lo, hi);
+                const uint32_t top = 128u - (uint32_t)(8 * bend - left);  // bit index just above the first unread bit
+                sl = bx_ext(lo, hi, top - log_l, log_l);
+                so = bx_ext(lo, hi, top - log_l - log_o, log_o);
+                sm = bx_ext(lo, hi, top - need, log_m);
+                left -= (int32_t)need;
+            }
+        }
+        const bool first_block = pr.k == 0;
+        uint32_t r0 = first_block ? 1u : FZ_SYM, r1 = first_block ? 4u : (FZ_SYM | (1u << 26)), r2 = first_block ? 8u : (FZ_SYM | (2u << 26));
+        uint32_t sum_ll = 0, sum_ml = 0;
+        uint32_t nmax = nseq;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) nmax = max(nmax, (uint32_t)__shfl_xor((int)nmax, d));
+        for (uint32_t i = 0; i < nmax; i++) {
+            if (i < nseq && !err) {
+                const uint32_t el = tl[sl], eo = to[so], em = tm[sm];
+                const int32_t bend = (left + 7) >> 3;
+                uint64_t lo, hi;
+                window(bend, lo, hi);
+                const uint32_t llb = (el >> 13) & 31, ofb = (eo >> 13) & 31, mlb = (em >> 13) & 31, need_v = llb + ofb + mlb;
+                const bool lastseq = i + 1 == nseq;
+                const uint32_t nbl = (el >> 9) & 15, nbo = (eo >> 9) & 15, nbm = (em >> 9) & 15, need_s = lastseq ? 0u : nbl + nbo + nbm;
+                if (ofb > 27) { err = E_UNSUP; }
+                else if (left < (int32_t)(need_v + need_s)) err = E_CORRUPT;
+                else {
+                    const uint32_t top = 128u - (uint32_t)(8 * bend - left);
+                    const uint64_t xv = bx_ext64(lo, hi, top - need_v, need_v);  // offset bits, match-length bits, literal-length bits
+                    const uint32_t ov = (1u << ofb) + (uint32_t)(xv >> (mlb + llb));
+                    const uint32_t ml = s_mlb[(em >> 18) & 63] + ((uint32_t)(xv >> llb) & ((1u << mlb) - 1u));
+                    const uint32_t ll = s_llb[(el >> 18) & 63] + ((uint32_t)xv & ((1u << llb) - 1u));
+                    if (!lastseq) {
+                        const uint32_t xs = bx_ext(lo, hi, top - need_v - need_s, need_s);  // LL, ML, OF state bits
+                        sl = (el & 511) + (xs >> (nbm + nbo));
+                        sm = (em & 511) + ((xs >> nbo) & ((1u << nbm) - 1u));
+                        so = (eo & 511) + (xs & ((1u << nbo) - 1u));
+                    }
+                    left -= (int32_t)(need_v + need_s);
+                    // repeat offsets (RFC 8878 3.1.1.5); a value with FZ_SYM set = "incoming entry k, minus d"
+                    uint32_t o;
+                    if (ov > 3) { o = ov - 3; r2 = r1; r1 = r0; r0 = o; }
+                    else {
+                        const uint32_t idx = ov - 1 + (ll == 0 ? 1u : 0u);
+                        if (idx == 0) o = r0;
+                        else {
+                            if (idx < 3) o = idx == 1 ? r1 : r2;
+                            else if (r0 & FZ_SYM) {
+                                o = r0 + 1;
+                                if ((o & 0x3FFFFFFu) == 0x3FFFFFFu) err = E_UNSUP;
+                            } else {
+                                o = r0 - 1;
+                                if (o == 0) err = E_CORRUPT;
+                            }
+                            if (idx > 1) r2 = r1;
+                            r1 = r0; r0 = o;
+                        }
+                    }
+                    sum_ll += ll; sum_ml += ml;
+                    if (sum_ll + sum_ml > BLOCK_MAX) err = E_UNSUP;
+                    recs[i] = (unsigned long long)ll | ((unsigned long long)ml << 17) | ((unsigned long long)o << 35);
+                }
+            }
+        }
+        if (on0) {
+            if (!err && nseq && left != 0) err = E_CORRUPT;
+            if (!err && sum_ll > it.lit_len) err = E_CORRUPT;
+            if (!err && it.lit_len + sum_ml > BLOCK_MAX) err = E_CORRUPT;
+            a.items[slot].out = it.lit_len + sum_ml;
+            a.items[slot].rep[0] = r0; a.items[slot].rep[1] = r1; a.items[slot].rep[2] = r2;
+            if (err) { a.items[slot].err = err; atomicAdd(&a.pool_used[3], 1ull); atomicAdd(&a.pool_used[4 + 3], 1ull); }
+        }
+    }
+}
+
+__device__ __forceinline__ FzArgs bx_as_fz(const BxArgs &a) {
+    FzArgs z{};
+    z.cand_row = a.cand_row; z.cand_fzbase = a.cand_base; z.cand_fzcap = nullptr; z.n_cand = 0;
+    z.it_cand = nullptr; z.total_items = 0; z.cand_nb = a.cand_nb; z.items = a.items;
+    z.blobs = a.blobs; z.blob_base = a.blob_base;
+    z.blob_off = a.blob_off; z.blob_size = a.blob_size; z.usize = a.usize; z.out_off = a.out_off; z.out_cap = a.out_cap;
+    z.out = a.out; z.row_flag = a.row_flag; z.status = a.status; z.preset = a.preset;
+    z.lit_pool = a.lit_pool; z.lit_cap = a.lit_cap; z.seq_pool = a.seq_pool; z.seq_cap = a.seq_cap;
+    z.pool_used = a.pool_used; z.cursor = nullptr; z.dbg = nullptr;
+    return z;
+}
+
+// wave = frame, frames dealt out by an atomic cursor (the slots are an upper bound, most runs use few of them)
+__global__ __launch_bounds__(64) void k_bx_exec(BxArgs a) {
+    __shared__ __attribute__((aligned(16))) uint8_t W[WIN_HIST + WIN_CAP + 64];
+    const uint32_t lane = threadIdx.x;
+    const uint32_t n_slots = a.ctr[0];
+    const FzArgs z = bx_as_fz(a);
+    for (;;) {
+        uint32_t c = 0;
+        if (lane == 0) c = atomicAdd(&a.ctr[4], 1u);
+        c = rdlane_u(c, 0);
+        if (c >= n_slots) break;
+        fz_exec_frame<false>(z, c, W, lane);
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+__global__ __launch_bounds__(64) void k_bx_finish(BxArgs a) {
+    const uint32_t lane = threadIdx.x;
+    const uint32_t n_slots = a.ctr[0];
+    for (uint32_t t0 = blockIdx.x * 64; t0 < n_slots; t0 += gridDim.x * 64) {
+        const uint32_t t = t0 + lane;
+        const uint32_t row = t < n_slots ? a.cand_row[t] : 0xFFFFFFFFu;
+        bool left = false;
+        if (row != 0xFFFFFFFFu) {
+            if (a.row_flag[row]) { a.status[row] = 1; left = true; }
+            else a.status[row] = 2;  // decoded: the second hash pass takes it
+        }
+        const uint64_t m = __ballot(left);
+        const uint64_t below = lane ? (~0ull >> (64 - lane)) : 0ull;
+        uint32_t b = 0;
+        if (lane == 0 && m) b = atomicAdd(a.pending2_count, (uint32_t)__popcll(m));
+        b = rdlane_u(b, 0);
+        if (left) a.pending2[b + (uint32_t)__popcll(m & below)] = row;
+    }
+}
+
+void launch_bx(const BxArgs &a, int cus, hipStream_t s) {
+    const uint32_t slots = a.slot_cap, lane_grid = std::min<uint32_t>((slots + 63) / 64, (uint32_t)cus * 8);
+    if (!slots) return;
+    hipLaunchKernelGGL(k_bx_scan, dim3(std::max(lane_grid, 1u)), dim3(64), 0, s, a);
+    hipLaunchKernelGGL(k_bx_prep, dim3(std::max(std::min<uint32_t>((a.item_cap + 63) / 64, (uint32_t)cus * 3), 1u)), dim3(64), 0, s, a);
+    hipLaunchKernelGGL(k_bx_huf, dim3(std::max(std::min<uint32_t>((a.item_cap + BX_HUF_BLOCKS - 1) / BX_HUF_BLOCKS, (uint32_t)cus * 2), 1u)), dim3(64), 0, s, a);
+    hipLaunchKernelGGL(k_bx_fse, dim3(std::max(std::min<uint32_t>((a.item_cap + 63) / 64, (uint32_t)cus * 8), 1u)), dim3(64), 0, s, a);
+    hipLaunchKernelGGL(k_bx_exec, dim3(std::max(std::min<uint32_t>(slots, (uint32_t)cus * 12), 1u)), dim3(64), 0, s, a);
+    hipLaunchKernelGGL(k_bx_finish, dim3(std::max(lane_grid, 1u)), dim3(64), 0, s, a);
+}
+
+// host: the three predefined tables (RFC 8878 3.1.1.3.2.2.1) as FSE pool cells, by the same spread as the device's
+void bx_predefined_tables(uint32_t cells[160]) {
+    static const int8_t ll_def[36] = {4, 3, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 1, 1, 1, 2, 2, 2, 2, 2, 2, 2, 2, 2, 3, 2, 1, 1, 1, 1, 1, -1, -1, -1, -1};
+    static const int8_t ml_def[53] = {1, 4, 3, 2, 2, 2, 2, 2, 2, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1,
+                                      1, 1, 1, 1, 1, 1, 1, 1, 1, 1, -1, -1, -1, -1, -1, -1, -1};
+    static const int8_t of_def[29] = {1, 1, 1, 1, 1, 1, 2, 2, 2, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, -1, -1, -1, -1, -1};
+    static const uint8_t ll_bits[36] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 3, 3, 4, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16};
+    static const uint8_t ml_bits[53] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 1,
+                                        1, 1, 2, 2, 3, 3, 4, 4, 5, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16};
+    auto build = [&](const int8_t *norm, int nsym, int log, int kind, uint32_t *t) {
+        const int size = 1 << log;
+        int high = size;
+        uint8_t sym_of[64];
+        uint16_t next[64];
+        for (int s = 0; s < nsym; s++) if (norm[s] == -1) { sym_of[--high] = (uint8_t)s; next[s] = 1; }
+        const int step = (size >> 1) + (size >> 3) + 3, mask = size - 1;
+        int pos = 0;
+        for (int s = 0; s < nsym; s++) {
+            if (norm[s] <= 0) continue;
+            next[s] = (uint16_t)norm[s];
+            for (int i = 0; i < norm[s]; i++) { sym_of[pos] = (uint8_t)s; do { pos = (pos + step) & mask; } while (pos >= high); }
+        }
+        for (int u = 0; u < size; u++) {
+            const uint32_t sym = sym_of[u], ns = next[sym]++;
+            uint32_t hb = 31; while (!(ns >> hb)) hb--;
+            const uint32_t nb = (uint32_t)log - hb;
+            const uint32_t ab = kind == K_LL ? ll_bits[sym] : (kind == K_ML ? ml_bits[sym] : sym);
+            t[u] = ((ns << nb) - (uint32_t)size) | (nb << 9) | (ab << 13) | (sym << 18);
+        }
+    };
+    build(ll_def, 36, 6, K_LL, cells + BX_PREDEF_LL);
+    build(of_def, 29, 5, K_OF, cells + BX_PREDEF_OF);
+    build(ml_def, 53, 6, K_ML, cells + BX_PREDEF_ML);
+}
 
 }  // namespace zn

@@ -863,12 +863,13 @@ __global__ __launch_bounds__(64) void k_scan_blocks(BlockScanArgs a) {
     if (lane == 0) a.row_flag[row] = ok ? 0u : 1u;
 }
 
-__global__ __launch_bounds__(64) void k_finish_blocks(BlockScanArgs a) {
+__global__ __launch_bounds__(64) void k_finish_blocks(BlockScanArgs a, int defer_flagged) {
     const uint32_t c = blockIdx.x * 64 + threadIdx.x;
     if (c >= a.n_cand) return;
     const uint32_t row = a.cand_row[c];
     if (a.status[row] < 0) return;  // host verdict stands
     if (a.row_flag[row]) {
+        if (defer_flagged) return;  // the batch path rules on it (k_bx_finish)
         a.status[row] = 1;  // handed to the general decoder, like a row the fused kernel gave up on
         a.pending[atomicAdd(a.pending_count, 1u)] = row;
     } else a.status[row] = 2;
@@ -893,8 +894,8 @@ void launch_compact_items(const uint8_t *item_done, uint32_t n_items, uint32_t *
 void launch_scan_blocks(const BlockScanArgs &a, hipStream_t s) {
     if (a.n_cand) hipLaunchKernelGGL(k_scan_blocks, dim3(a.n_cand), dim3(64), 0, s, a);
 }
-void launch_finish_blocks(const BlockScanArgs &a, hipStream_t s) {
-    if (a.n_cand) hipLaunchKernelGGL(k_finish_blocks, dim3((a.n_cand + 63) / 64), dim3(64), 0, s, a);
+void launch_finish_blocks(const BlockScanArgs &a, hipStream_t s, bool defer_flagged) {
+    if (a.n_cand) hipLaunchKernelGGL(k_finish_blocks, dim3((a.n_cand + 63) / 64), dim3(64), 0, s, a, defer_flagged ? 1 : 0);
 }
 
 int decode_grid_size(int device) {
