@@ -67,7 +67,7 @@ struct znippy_ctx {
     uint64_t fz_lit_cap = 0, fz_seq_cap = 0;
     // the batch path's table pools (zstd_batch.hip, k_bx_*): FSE decoding tables as 4-byte cells (the predefined ones at
     // the head), Huffman decoding tables as 2-byte cells
-    uint32_t *bx_fse_pool = nullptr;
+    uint16_t *bx_fse_pool = nullptr;
     uint16_t *bx_huf_pool = nullptr;
     uint64_t bx_fse_cap = 0, bx_huf_cap = 0;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
@@ -458,13 +458,13 @@ static int ensure_fz_pools(znippy_ctx *ctx, uint64_t content_bytes, uint32_t ite
 static int ensure_bx_pools(znippy_ctx *ctx, uint64_t content_bytes, uint32_t items) {
     constexpr uint64_t CAP = 16ull << 30;
     const uint64_t bytes = std::min<uint64_t>(content_bytes / 2 + 64ull * items + 4096, CAP);
-    const uint64_t fse = bytes / 4 + BX_POOL_FIRST, huf = bytes / 2;
+    const uint64_t fse = bytes / 2 + BX_POOL_FIRST, huf = bytes / 2;
     if (fse > ctx->bx_fse_cap) {
         (void)hipStreamSynchronize(ctx->stream);
         if (ctx->bx_fse_pool) (void)hipFree(ctx->bx_fse_pool);
         ctx->bx_fse_pool = nullptr; ctx->bx_fse_cap = 0;
-        if (hipMalloc(&ctx->bx_fse_pool, fse * 4) != hipSuccess) { (void)hipGetLastError(); ctx->bx_fse_pool = nullptr; return ZNIPPY_OK; }
-        uint32_t predef[BX_POOL_FIRST];
+        if (hipMalloc(&ctx->bx_fse_pool, fse * 2) != hipSuccess) { (void)hipGetLastError(); ctx->bx_fse_pool = nullptr; return ZNIPPY_OK; }
+        uint16_t predef[BX_POOL_FIRST];
         bx_predefined_tables(predef);
         if (hipMemcpy(ctx->bx_fse_pool, predef, sizeof predef, hipMemcpyHostToDevice) != hipSuccess) return ZNIPPY_E_HIP;
         ctx->bx_fse_cap = fse;
@@ -794,7 +794,7 @@ int znippy_rows_create(znippy_ctx *ctx, const uint64_t *blob_offset, const uint6
                 r->bx_item_cap = (uint32_t)cap;
                 if (tmalloc(ctx, &r->bx_cand_row, 4 * (size_t)r->bx_slots) != hipSuccess || tmalloc(ctx, &r->bx_cand_base, 4 * (size_t)r->bx_slots) != hipSuccess ||
                     tmalloc(ctx, &r->bx_cand_nb, 4 * (size_t)r->bx_slots) != hipSuccess || tmalloc(ctx, &r->bx_huf_list, 4 * (size_t)cap) != hipSuccess ||
-                    tmalloc(ctx, &r->bx_seq_list, 4 * (size_t)cap) != hipSuccess || tmalloc(ctx, &r->bx_items, sizeof(zn::FzItem) * (size_t)cap) != hipSuccess ||
+                    tmalloc(ctx, &r->bx_seq_list, 3 * 4 * (size_t)cap) != hipSuccess || tmalloc(ctx, &r->bx_items, sizeof(zn::FzItem) * (size_t)cap) != hipSuccess ||
                     tmalloc(ctx, &r->bx_prep, sizeof(zn::BxPrep) * (size_t)cap) != hipSuccess) {
                     znippy_rows_destroy(r);
                     return ZNIPPY_E_NOMEM;
@@ -1137,9 +1137,23 @@ int znippy_decode_verify_rows_async(znippy_ctx *ctx, znippy_rows *r, const void 
             x.fse_pool = ctx->bx_fse_pool; x.fse_cap = ctx->bx_fse_cap; x.huf_pool = ctx->bx_huf_pool; x.huf_cap = ctx->bx_huf_cap;
             x.pool_used = reinterpret_cast<unsigned long long *>(r->ctl + 256);
             x.pending2 = r->pending2; x.pending2_count = r->pending_count + 1;
-            ktime_begin(ctx, "zstd_batch");
-            launch_bx(x, ctx->cus, s);
-            ktime_end(ctx);
+            if (ctx->sw.ddbg) {  // diagnostic: where the previous run's table kernel spent its waves' time
+                static unsigned long long *dbg = nullptr;
+                if (!dbg) { (void)hipMalloc(&dbg, 512); (void)hipMemset(dbg, 0, 512); }
+                unsigned long long h[64];
+                (void)hipStreamSynchronize(s);
+                (void)hipMemcpy(h, dbg, 512, hipMemcpyDeviceToHost);
+                if (h[32]) fprintf(stderr, "[znippy ddbg] batch tables: wave passes=%llu  kcycles per pass: literals header + weights=%.1f sequences header=%.1f huffman table=%.1f sequence tables=%.1f\n", h[32],
+                                   h[33] / 1e3 / h[32], h[34] / 1e3 / h[32], h[35] / 1e3 / h[32], h[36] / 1e3 / h[32]);
+                (void)hipMemset(dbg, 0, 512);
+                x.dbg = dbg;
+            }
+            static const char *const bx_names[6] = {"zstd_batch_scan", "zstd_batch_tables", "zstd_batch_huffman", "zstd_batch_sequences", "zstd_batch_execute", "zstd_batch_finish"};
+            for (int st = 0; st < 6; st++) {
+                ktime_begin(ctx, bx_names[st]);
+                launch_bx_stage(x, ctx->cus, st, s);
+                ktime_end(ctx);
+            }
             a.list_a = nullptr; a.n_list_a = 0;
             a.pending = r->pending2; a.pending_count = r->pending_count + 1;
             a.cursor = r->cursor + 8;

@@ -214,13 +214,13 @@ struct BxPrep {            // per block item, written by k_bx_prep
     uint32_t huf_log;
     uint32_t st_off[4];    // streams: offset from the frame's first byte, bytes
     uint32_t st_len[4];
-    uint32_t tab[3];       // LL / OF / ML decoding table in the FSE pool (u32 cells)
+    uint32_t tab[3];       // LL / OF / ML decoding table in the FSE pool (2-byte cells, 16-byte aligned)
     uint32_t logs;         // log LL | log OF << 8 | log ML << 16
     uint32_t bs_off;       // sequences bitstream: offset from the frame's first byte
     uint32_t bs_len;       // bytes
 };
 constexpr uint32_t BX_PREDEF_LL = 0, BX_PREDEF_OF = 64, BX_PREDEF_ML = 96, BX_POOL_FIRST = 160;  // predefined tables at the head of the FSE pool
-// FSE pool cell: next:9 | nbits:4 << 9 | addbits:5 << 13 | symbol:6 << 18
+// FSE pool cell (2 bytes): symbol:6 | ns:10 << 6 (zstd_batch.hip)
 struct BxArgs {
     const uint32_t *list_a; uint32_t n_list_a;
     const uint32_t *pending; const uint32_t *pending_count;
@@ -235,17 +235,17 @@ struct BxArgs {
     uint32_t *cand_row, *cand_base, *cand_nb;  // per candidate slot (written by the scan)
     uint32_t slot_cap;
     FzItem *items; BxPrep *prep; uint32_t item_cap;
-    uint32_t *ctr;  // [0] slots, [1] items, [2] Huffman list, [3] sequence list, [4..7] work cursors (zeroed per run)
-    uint32_t *huf_list, *seq_list;
+    uint32_t *ctr;  // [0] slots, [1] items, [2] Huffman list, [3] [5] [6] sequence lists (64 / 32 / 16 blocks per wave), [4] execute cursor (zeroed per run)
+    uint32_t *huf_list, *seq_list;  // seq_list: three lists of item_cap entries
     uint8_t *lit_pool; uint64_t lit_cap;
     unsigned long long *seq_pool; uint64_t seq_cap;
-    uint32_t *fse_pool; uint64_t fse_cap;   // cells
+    uint16_t *fse_pool; uint64_t fse_cap;   // cells
     uint16_t *huf_pool; uint64_t huf_cap;   // cells
     unsigned long long *pool_used;  // [0] literal bytes [1] records [2] frames decoded [3] blocks given up [4..7] why [8] FSE cells [9] Huffman cells (zeroed per run)
     uint32_t *pending2, *pending2_count;  // what is left for the serial decoder
     unsigned long long *dbg;
 };
-void launch_bx(const BxArgs &a, int cus, hipStream_t s);
-void bx_predefined_tables(uint32_t cells[160]);  // host: the three predefined tables as pool cells
+void launch_bx_stage(const BxArgs &a, int cus, int stage, hipStream_t s);  // 0 scan, 1 prep, 2 huf, 3 fse, 4 exec, 5 finish
+void bx_predefined_tables(uint16_t cells[160]);  // host: the three predefined tables as pool cells
 
 }  // namespace zn

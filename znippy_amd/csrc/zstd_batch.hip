@@ -524,9 +524,9 @@ __global__ __launch_bounds__(128, 4) void k_fz_entropy(FzArgs a, const uint32_t 
 
 // One frame, executed by one wave: the blocks' records and literals come from the pools, W is the wave's LDS window.
 template <bool PROF>
-__device__ __forceinline__ void fz_exec_frame(const FzArgs &a, const uint32_t c, uint8_t *const W, const uint32_t lane) {
+__device__ __forceinline__ bool fz_exec_frame(const FzArgs &a, const uint32_t c, uint8_t *const W, const uint32_t lane) {  // true: the frame is decoded
     const uint32_t nb = a.cand_nb[c];
-    if (!nb) return;
+    if (!nb) return false;
     const uint32_t row = a.cand_row[c], base = a.cand_fzbase[c];
     const uint8_t *const src = a.blobs + (a.blob_off[row] - a.blob_base);
     uint8_t *const out = a.out + a.out_off[row];
@@ -540,11 +540,11 @@ __device__ __forceinline__ void fz_exec_frame(const FzArgs &a, const uint32_t c,
             seqs += a.items[base + i].nseq;
         }
         for (int d = 32; d >= 1; d >>= 1) { tot += __shfl_xor(tot, d); seqs += __shfl_xor(seqs, d); bad |= __shfl_xor(bad, d); }
-        if (bad || tot != fcs) return;
+        if (bad || tot != fcs) return false;
         // A frame of a few very long sequences (periodic or constant data: one 128 KiB match per block) is copy work, not
         // sequence work: the serial decoder's 1,024-thread variant moves it three times faster than one wave can
         // (16 x 8 MiB of periodic text: 0.72 ms against 2.2 ms here) — left to it.
-        if (seqs * 2048 < fcs) return;
+        if (seqs * 2048 < fcs) return false;
     }
     uint64_t opos = 0;  // output bytes already streamed to HBM
     uint32_t win_n = 0, hist_n = 0, r0 = 1, r1 = 4, r2 = 8;
@@ -697,16 +697,16 @@ linc = wave_incl_scan(linc); pinc = wave_incl_scan(pinc);
     }
 #undef FZ_T0
 #undef FZ_T1
-    if (!err && opos == fcs && lane == 0) {
-        a.row_flag[row] = 0;  // k_finish_blocks turns this into status 2 (hash me)
-        atomicAdd(&a.pool_used[2], 1ull);  // statistics: frames decoded by this path
-    }
+    const bool done = !err && opos == fcs;
+    if (done && lane == 0) a.row_flag[row] = 0;  // the finish kernels turn this into status 2 (hash me)
+    return done;
 }
 
 template <bool PROF>
 __global__ __launch_bounds__(64) void k_fz_exec(FzArgs a) {
     __shared__ __attribute__((aligned(16))) uint8_t W[WIN_HIST + WIN_CAP + 64];
-    if (blockIdx.x < a.n_cand) fz_exec_frame<PROF>(a, blockIdx.x, W, threadIdx.x);
+    if (blockIdx.x < a.n_cand && fz_exec_frame<PROF>(a, blockIdx.x, W, threadIdx.x) && threadIdx.x == 0)
+        atomicAdd(&a.pool_used[2], 1ull);  // statistics: frames decoded by this path
 }
 
 void launch_fz_scan(const FzArgs &a, uint32_t *work, uint32_t *work_count, hipStream_t s) {
@@ -747,7 +747,10 @@ void launch_fz_exec(const FzArgs &a, hipStream_t s) {
 struct BxScratch {  // per wave; [i * 64 + lane]: a lane's i-th entry (consecutive lanes, consecutive addresses)
     int16_t norm[64 * 64];
     uint16_t nxt[64 * 64];
-    uint16_t wtab[64 * 64];     // FSE table of the Huffman weights: weight:4 | nbits:3 << 4 | next:6 << 7
+    union {
+        uint16_t wtab[64 * 64];  // FSE table of the Huffman weights: weight:4 | nbits:3 << 4 | next:6 << 7
+        uint8_t sym[512 * 64];   // a sequence table under construction: the symbol of every cell
+    };
     uint8_t weights[256 * 64];
     uint16_t rank[16 * 64];
 };
@@ -848,38 +851,40 @@ __device__ __forceinline__ int bx_fse_spread(BxScratch &S, const uint32_t lane, 
     return pos == 0 ? 0 : E_CORRUPT;
 }
 
-__device__ __forceinline__ uint32_t bx_cell(uint32_t next, uint32_t nb, uint32_t addbits, uint32_t sym) {
-    return next | (nb << 9) | (addbits << 13) | (sym << 18);
-}
-__device__ __forceinline__ int bx_addbits(int kind, uint32_t sym, uint32_t *ab) {
-    if (kind == K_LL) { if (sym > 35) return E_CORRUPT; *ab = c_ll_bits[sym]; }
-    else if (kind == K_ML) { if (sym > 52) return E_CORRUPT; *ab = c_ml_bits[sym]; }
-    else { if (sym > 31) return E_CORRUPT; *ab = sym; }
-    return 0;
+// FSE pool cell (2 bytes): symbol:6 | ns:10 << 6, ns = the state counter the table construction hands the cell
+// (RFC 8878 4.1.1): the bits to read are log - hibit(ns), the next state's base is (ns << bits) - (1 << log); base value and
+// extra bits follow from the symbol.  Half the size of a cell that spells these out: 64 blocks' tables fit one wave's LDS.
+__device__ __forceinline__ int bx_check_sym(int kind, uint32_t sym) {
+    return sym > (kind == K_LL ? 35u : (kind == K_ML ? 52u : 31u)) ? E_CORRUPT : 0;
 }
 
-// One sequence table of one lane's block, from its counts (BX_NORM) into cells[0 .. 1 << log) of the FSE pool.
-__device__ int bx_build_seq_table(BxScratch &S, const uint32_t lane, int nsym, int log, int kind, uint32_t *cells) {
-    int rc = bx_fse_spread(S, lane, nsym, log, [&](uint32_t u, uint32_t sym) { cells[u] = sym; });
+// One sequence table of one lane's block, from its counts (BX_NORM) into cells[0 .. 1 << log) of the FSE pool (cells is
+// 16-byte aligned and has room for a multiple of 8 cells).
+__device__ int bx_build_seq_table(BxScratch &S, const uint32_t lane, int nsym, int log, int kind, uint16_t *cells) {
+    int rc = bx_fse_spread(S, lane, nsym, log, [&](uint32_t u, uint32_t sym) { S.sym[u * 64 + lane] = (uint8_t)sym; });
     if (rc) return rc;
+    for (int s_ = 0; s_ < nsym; s_++)
+        if (BX_NORM(s_) != 0 && bx_check_sym(kind, (uint32_t)s_)) return E_CORRUPT;
     const uint32_t size = 1u << log;
-    for (uint32_t u = 0; u < size; u++) {
-        const uint32_t sym = cells[u] & 63;  // this lane's own store (vector memory operations of a wave stay in order)
-        const uint32_t ns = BX_NXT(sym);
-        BX_NXT(sym) = (uint16_t)(ns + 1);
-        const uint32_t nb = (uint32_t)log - (uint32_t)hibit(ns);
-        uint32_t ab = 0;
-        rc = bx_addbits(kind, sym, &ab);
-        if (rc) return rc;
-        cells[u] = bx_cell((ns << nb) - size, nb, ab, sym);
+    for (uint32_t u0 = 0; u0 < size; u0 += 8) {  // (a table has at least 32 cells)
+        uint32_t w[4];
+#pragma unroll
+        for (uint32_t q = 0; q < 8; q++) {
+            const uint32_t sym = S.sym[(u0 + q) * 64 + lane];
+            const uint32_t ns = BX_NXT(sym);
+            BX_NXT(sym) = (uint16_t)(ns + 1);
+            const uint32_t c = sym | (ns << 6);
+            if (q & 1) w[q >> 1] |= c << 16; else w[q >> 1] = c;
+        }
+        *reinterpret_cast<uint4 *>(cells + u0) = make_uint4(w[0], w[1], w[2], w[3]);
     }
     return 0;
 }
 
-// Huffman tree description -> this lane's weights (BX_W) -> decoding table in the Huffman pool.
-// Returns 0 and sets *consumed (bytes of the description), *hlog, *hoff (first cell), or an error.
-__device__ int bx_read_tree(BxScratch &S, const uint32_t lane, const BxArgs &a, const uint8_t *src, uint32_t n, const uint8_t *blob_end,
-                            uint32_t *consumed, uint32_t *hlog, uint32_t *hoff) {
+// Huffman tree description -> this lane's weights (BX_W), checked; *consumed = bytes of the description, *hlog = the
+// table's log, *nsym_out = symbols (the implied last one included).
+__device__ int bx_read_weights(BxScratch &S, const uint32_t lane, const uint8_t *src, uint32_t n, const uint8_t *blob_end,
+                               uint32_t *consumed, uint32_t *hlog, uint32_t *nsym_out) {
     if (n < 1) return E_TRUNC;
     const uint32_t hb = src[0];
     uint32_t nw = 0;
@@ -962,10 +967,13 @@ __device__ int bx_read_tree(BxScratch &S, const uint32_t lane, const BxArgs &a, 
         }
         if (start != (1u << maxbits)) return E_CORRUPT;
     }
-    const uint32_t cells = 1u << maxbits, room = cells < 8 ? 8u : cells;  // 16-byte granules
-    const unsigned long long off = atomicAdd(&a.pool_used[9], (unsigned long long)room);
-    if (off + room > a.huf_cap) return E_UNSUP;
-    uint16_t *const t = a.huf_pool + off;
+    *hlog = maxbits;
+    *nsym_out = nsym;
+    return 0;
+}
+
+// the lane's weights and rank starts (bx_read_weights) -> the decoding table t[0 .. 1 << maxbits), t 16-byte aligned
+__device__ void bx_fill_huf(BxScratch &S, const uint32_t lane, uint32_t nsym, uint32_t maxbits, uint16_t *t) {
     for (uint32_t sym = 0; sym < nsym; sym++) {
         const uint32_t w = BX_W(sym);
         if (!w) continue;
@@ -976,18 +984,21 @@ __device__ int bx_read_tree(BxScratch &S, const uint32_t lane, const BxArgs &a, 
         if (len >= 8) {
             const uint4 v = make_uint4(e2, e2, e2, e2);
             for (uint32_t i = 0; i < len; i += 8) *reinterpret_cast<uint4 *>(t + st + i) = v;  // st is a multiple of len
-        } else for (uint32_t i = 0; i < len; i++) t[st + i] = (uint16_t)e;
+        } else if (len == 4) *reinterpret_cast<uint2 *>(t + st) = make_uint2(e2, e2);
+        else if (len == 2) *reinterpret_cast<uint32_t *>(t + st) = e2;
+        else t[st] = (uint16_t)e;
     }
-    *hlog = maxbits;
-    *hoff = (uint32_t)off;
-    return 0;
 }
 
-// Sequences_Section_Header of the section [q, q + n) of one lane's block: number of sequences, then the table
-// descriptions.  Kinds in `want` (bit 0 LL, 1 OF, 2 ML) that are described here get their table (tab[], logs[]); those in
-// Repeat_Mode come back in *missing.
-__device__ int bx_seq_tables(BxScratch &S, const uint32_t lane, const BxArgs &a, const uint8_t *q, uint32_t n, uint32_t want, uint32_t *missing,
-                             uint32_t *nseq_out, uint32_t *bits_at, uint32_t tab[3], uint32_t logs[3]) {
+// What the Sequences_Section_Header of the section [q, q + n) says about the kinds in `want` (bit 0 LL, 1 OF, 2 ML):
+// mode[k] 0 predefined, 1 RLE (sym[k]), 2 described at desc[k] (log[k]); kinds in Repeat_Mode come back in *missing.
+struct BxSeqHdr {
+    uint32_t mode[3], log[3], sym[3];
+    const uint8_t *desc[3];
+    uint32_t desc_n[3];
+};
+__device__ int bx_seq_locate(BxScratch &S, const uint32_t lane, const uint8_t *q, uint32_t n, uint32_t want, uint32_t *missing,
+                             uint32_t *nseq_out, uint32_t *bits_at, BxSeqHdr &H) {
     if (n < 1) return E_TRUNC;
     uint32_t p = 0, nseq = 0;
     const uint32_t b0 = q[0];
@@ -1008,32 +1019,22 @@ __device__ int bx_seq_tables(BxScratch &S, const uint32_t lane, const BxArgs &a,
         const bool wanted = (want >> k) & 1;
         const int kind = k == 0 ? K_LL : (k == 1 ? K_OF : K_ML);
         if (mode == 0) {
-            if (wanted) { tab[k] = k == 0 ? BX_PREDEF_LL : (k == 1 ? BX_PREDEF_OF : BX_PREDEF_ML); logs[k] = k == 1 ? 5 : 6; }
+            if (wanted) { H.mode[k] = 0; H.log[k] = k == 1 ? 5 : 6; }
         } else if (mode == 1) {
             if (p >= n) return E_TRUNC;
             if (wanted) {
                 const uint32_t sym = q[p];
-                uint32_t ab = 0;
-                const int rc = bx_addbits(kind, sym, &ab);
+                const int rc = bx_check_sym(kind, sym);
                 if (rc) return rc;
-                const unsigned long long off = atomicAdd(&a.pool_used[8], 1ull) + BX_POOL_FIRST;
-                if (off + 1 > a.fse_cap) return E_UNSUP;
-                a.fse_pool[off] = bx_cell(0, 0, ab, sym);
-                tab[k] = (uint32_t)off; logs[k] = 0;
+                H.mode[k] = 1; H.log[k] = 0; H.sym[k] = sym;
             }
             p++;
         } else if (mode == 2) {
             int nsym = 0, log = 0;
             uint32_t used = 0;
-            int rc = bx_read_ncount(S, lane, q + p, n - p, k == 1 ? 8 : 9, k == 0 ? 35 : (k == 1 ? 31 : 52), &nsym, &log, &used);
+            const int rc = bx_read_ncount(S, lane, q + p, n - p, k == 1 ? 8 : 9, k == 0 ? 35 : (k == 1 ? 31 : 52), &nsym, &log, &used);
             if (rc) return rc;
-            if (wanted) {
-                const unsigned long long off = atomicAdd(&a.pool_used[8], 1ull << log) + BX_POOL_FIRST;
-                if (off + (1ull << log) > a.fse_cap) return E_UNSUP;
-                rc = bx_build_seq_table(S, lane, nsym, log, kind, a.fse_pool + off);
-                if (rc) return rc;
-                tab[k] = (uint32_t)off; logs[k] = (uint32_t)log;
-            }
+            if (wanted) { H.mode[k] = 2; H.log[k] = (uint32_t)log; H.desc[k] = q + p; H.desc_n[k] = n - p; }
             p += used;
         } else if (wanted) miss |= 1u << k;
     }
@@ -1121,9 +1122,25 @@ __global__ __launch_bounds__(64) void k_bx_prep(BxArgs a) {
     for (uint32_t i0 = blockIdx.x * 64; i0 < n_items; i0 += gridDim.x * 64) {
         const uint32_t slot = i0 + lane;
         const bool on = slot < n_items;
-        bool huf = false, seq = false;
+        unsigned long long t_p = a.dbg ? __builtin_amdgcn_s_memtime() : 0;  // diagnostic (ZNIPPY_DDBG): where the wave's time goes
+#define PSTAMP(i) do { if (a.dbg) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); if (lane == 0) atomicAdd(&a.dbg[i], now_ - t_p); t_p = now_; } } while (0)
+        if (a.dbg && lane == 0) atomicAdd(&a.dbg[32], 1ull);
+        // ---- phase 1, lane = block: everything the headers say, and how much of each pool the block needs ----
+        FzItem it;
+        it.src = 0; it.out = 0; it.nseq = 0; it.lit_len = 0; it.seq_off = 0; it.lit_off = 0; it.lit_kind = 0; it.err = 0;
+        it.rep[0] = FZ_SYM; it.rep[1] = FZ_SYM | (1u << 26); it.rep[2] = FZ_SYM | (2u << 26); it.pad = 0;
+        BxPrep pr;
+        pr.frame = 0; pr.k = 0; pr.n_streams = 0; pr.huf_off = 0; pr.huf_log = 0; pr.logs = 0; pr.bs_off = 0; pr.bs_len = 0;
+        pr.tab[0] = pr.tab[1] = pr.tab[2] = 0;
+        for (int j = 0; j < 4; j++) { pr.st_off[j] = 0; pr.st_len[j] = 0; }
+        BxSeqHdr H;
+        for (int j = 0; j < 3; j++) { H.mode[j] = 0; H.log[j] = 0; H.sym[j] = 0; H.desc[j] = nullptr; H.desc_n[j] = 0; }
+        int err = 0;
+        uint32_t why = 0, hsyms = 0;
+        uint32_t need_lit = 0, need_seq = 0, need_fse = 0, need_huf = 0;
         if (on) {
             const BxPrep pr0 = a.prep[slot];
+            pr.frame = pr0.frame; pr.k = pr0.k;
             const uint32_t c = pr0.frame, k = pr0.k, base = slot - k, row = a.cand_row[c];
             const uint8_t *const src = a.blobs + (a.blob_off[row] - a.blob_base);
             const uint8_t *const blob_end = src + a.blob_size[row];
@@ -1131,15 +1148,7 @@ __global__ __launch_bounds__(64) void k_bx_prep(BxArgs a) {
             const uint32_t bh = src[pos] | (src[pos + 1] << 8) | (src[pos + 2] << 16);
             const uint32_t btype = (bh >> 1) & 3, bsize = bh >> 3;
             const uint8_t *const bsrc = src + pos + 3;
-            FzItem it;
-            it.src = pos; it.out = 0; it.nseq = 0; it.lit_len = 0; it.seq_off = 0; it.lit_off = 0; it.lit_kind = 0; it.err = 0;
-            it.rep[0] = FZ_SYM; it.rep[1] = FZ_SYM | (1u << 26); it.rep[2] = FZ_SYM | (2u << 26); it.pad = 0;
-            BxPrep pr = pr0;
-            pr.n_streams = 0; pr.huf_off = 0; pr.huf_log = 0; pr.logs = 0; pr.bs_off = 0; pr.bs_len = 0;
-            pr.tab[0] = pr.tab[1] = pr.tab[2] = 0;
-            for (int j = 0; j < 4; j++) { pr.st_off[j] = 0; pr.st_len[j] = 0; }
-            int err = 0;
-            uint32_t why = 0;
+            it.src = pos;
             if (btype != 2) {  // raw / RLE block: literals only
                 it.out = bsize; it.lit_len = bsize;
                 it.lit_kind = btype == 0 ? 0u : 1u;
@@ -1158,7 +1167,7 @@ __global__ __launch_bounds__(64) void k_bx_prep(BxArgs a) {
                         uint32_t p = h.hdr, remain = h.comp;
                         if (h.type == 2) {
                             uint32_t tu = 0;
-                            err = bx_read_tree(S, lane, a, bsrc + p, remain, blob_end, &tu, &pr.huf_log, &pr.huf_off);
+                            err = bx_read_weights(S, lane, bsrc + p, remain, blob_end, &tu, &pr.huf_log, &hsyms);
                             if (!err) { p += tu; remain -= tu; }
                         } else {  // treeless: the tree of the nearest earlier block of the frame that carries a description (re-read)
                             err = E_UNSUP; why = 1;
@@ -1170,7 +1179,7 @@ __global__ __launch_bounds__(64) void k_bx_prep(BxArgs a) {
                                 if (fz_lit_header(src + pj + 3, bj >> 3, hj)) { err = E_CORRUPT; break; }
                                 if (hj.type == 2) {
                                     uint32_t tu = 0;
-                                    err = bx_read_tree(S, lane, a, src + pj + 3 + hj.hdr, hj.comp, blob_end, &tu, &pr.huf_log, &pr.huf_off);
+                                    err = bx_read_weights(S, lane, src + pj + 3 + hj.hdr, hj.comp, blob_end, &tu, &pr.huf_log, &hsyms);
                                     why = 0;
                                     break;
                                 }
@@ -1197,20 +1206,19 @@ __global__ __launch_bounds__(64) void k_bx_prep(BxArgs a) {
                             pr.n_streams = err ? 0 : h.streams;
                         }
                         if (!err) {
-                            const uint64_t room = ((uint64_t)h.regen + 79) & ~15ull;
-                            const unsigned long long off = atomicAdd(&a.pool_used[0], (unsigned long long)room);
-                            if (off + room > a.lit_cap) { err = E_UNSUP; why = 2; }
-                            it.lit_off = off;
+                            need_lit = (h.regen + 79) & ~15u;
+                            need_huf = (1u << pr.huf_log) < 8 ? 8u : 1u << pr.huf_log;  // 16-byte granules
                         }
                     }
                 }
-                // ---- sequences: header, tables, where the bitstream is ----
+                PSTAMP(33);
+                // ---- sequences: header, where the table descriptions and the bitstream are ----
                 if (!err) {
                     if (seq_pos >= bsize) err = E_TRUNC;
-                    uint32_t miss = 0, nseq = 0, bits_at = 0, logs[3] = {0, 0, 0};
+                    uint32_t miss = 0, nseq = 0, bits_at = 0;
                     const uint8_t *q = bsrc + seq_pos;
                     const uint32_t qn = bsize - seq_pos;
-                    if (!err) err = bx_seq_tables(S, lane, a, q, qn, 7u, &miss, &nseq, &bits_at, pr.tab, logs);
+                    if (!err) err = bx_seq_locate(S, lane, q, qn, 7u, &miss, &nseq, &bits_at, H);
                     if (!err && nseq == 0 && bits_at != qn) err = E_CORRUPT;
                     if (!err && nseq && miss) {
                         for (uint32_t back = 1; back <= FZ_BACK && back <= k && miss && !err; back++) {
@@ -1224,7 +1232,7 @@ __global__ __launch_bounds__(64) void k_bx_prep(BxArgs a) {
                             const uint32_t ls = fz_lit_section_bytes(hj);
                             if (ls >= sz) { err = E_CORRUPT; break; }
                             uint32_t m2 = 0, n2 = 0, at2 = 0;
-                            err = bx_seq_tables(S, lane, a, b + ls, sz - ls, miss, &m2, &n2, &at2, pr.tab, logs);
+                            err = bx_seq_locate(S, lane, b + ls, sz - ls, miss, &m2, &n2, &at2, H);
                             if (!err && n2) miss = m2;
                         }
                         if (!err && miss) { err = E_UNSUP; why = 1; }
@@ -1235,31 +1243,76 @@ __global__ __launch_bounds__(64) void k_bx_prep(BxArgs a) {
                         else { pr.bs_off = pos + 3 + seq_pos + bits_at; pr.bs_len = qn - bits_at; }
                     }
                     if (!err && nseq) {
-                        const unsigned long long off = atomicAdd(&a.pool_used[1], (unsigned long long)nseq);
-                        if (off + nseq > a.seq_cap) { err = E_UNSUP; why = 2; }
-                        it.seq_off = off;
+                        need_seq = (nseq + 7) & ~7u;  // records leave the sequence kernel eight at a time
+                        for (int j = 0; j < 3; j++) need_fse += H.mode[j] == 0 ? 0u : ((1u << H.log[j]) < 8 ? 8u : 1u << H.log[j]);
                     }
-                    pr.logs = logs[0] | (logs[1] << 8) | (logs[2] << 16);
+                    pr.logs = H.log[0] | (H.log[1] << 8) | (H.log[2] << 16);
                     it.nseq = err ? 0 : nseq;
                     if (!err && nseq == 0) it.out = it.lit_len;
                 }
             }
+            if (err) { need_lit = need_seq = need_fse = need_huf = 0; }
+        }
+        PSTAMP(34);
+        // ---- pool space: one atomic per wave and pool (all lanes, converged) ----
+        const uint64_t o_lit = wave_alloc64(&a.pool_used[0], need_lit, lane), o_seq = wave_alloc64(&a.pool_used[1], need_seq, lane);
+        const uint64_t o_fse = wave_alloc64(&a.pool_used[8], need_fse, lane) + BX_POOL_FIRST, o_huf = wave_alloc64(&a.pool_used[9], need_huf, lane);
+        // ---- phase 2, lane = block: the decoding tables ----
+        bool huf = false, seq = false;
+        uint32_t cls = 0;
+        if (on) {
+            if (!err && (o_lit + need_lit > a.lit_cap || o_seq + need_seq > a.seq_cap || o_fse + need_fse > a.fse_cap || o_huf + need_huf > a.huf_cap)) { err = E_UNSUP; why = 2; }
+            if (!err && need_huf) {
+                pr.huf_off = (uint32_t)o_huf;
+                bx_fill_huf(S, lane, hsyms, pr.huf_log, a.huf_pool + o_huf);
+            }
+            if (!err && need_lit) it.lit_off = o_lit;
+            PSTAMP(35);
+            if (!err && it.nseq) {
+                it.seq_off = o_seq;
+                uint32_t at = (uint32_t)o_fse;
+                for (int j = 0; j < 3 && !err; j++) {
+                    const int kind = j == 0 ? K_LL : (j == 1 ? K_OF : K_ML);
+                    if (H.mode[j] == 0) pr.tab[j] = j == 0 ? BX_PREDEF_LL : (j == 1 ? BX_PREDEF_OF : BX_PREDEF_ML);
+                    else if (H.mode[j] == 1) { a.fse_pool[at] = (uint16_t)(H.sym[j] | (1u << 6)); pr.tab[j] = at; at += 8; }  // one cell: log 0, ns = 1 -> no bits, next state 0
+                    else {
+                        int nsym = 0, log = 0;
+                        uint32_t used = 0;
+                        err = bx_read_ncount(S, lane, H.desc[j], H.desc_n[j], j == 1 ? 8 : 9, j == 0 ? 35 : (j == 1 ? 31 : 52), &nsym, &log, &used);
+                        if (!err) err = bx_build_seq_table(S, lane, nsym, log, kind, a.fse_pool + at);
+                        pr.tab[j] = at; at += 1u << log;
+                    }
+                }
+                if (err) it.nseq = 0;
+            }
+            PSTAMP(36);
             it.err = err;
             if (err) { atomicAdd(&a.pool_used[3], 1ull); atomicAdd(&a.pool_used[4 + (why & 3)], 1ull); }  // statistics
             a.items[slot] = it;
             a.prep[slot] = pr;
             huf = !err && pr.n_streams != 0;
             seq = !err && it.nseq != 0;
+            {   // the wave shape of the sequence kernel by the size of the three tables: 64 / 32 / 16 blocks per wave
+                uint32_t cells = 0;
+                for (int q = 0; q < 3; q++) { const uint32_t c = 1u << ((pr.logs >> (8 * q)) & 255); cells += c < 8 ? 8u : c; }
+                cls = cells <= 384 ? 0u : (cells <= 768 ? 1u : 2u);
+            }
         }
         {   // the block joins the lists of the two entropy kernels
-            const uint64_t hm = __ballot(huf), sm = __ballot(seq);
+            const uint64_t hm = __ballot(huf);
             const uint64_t below = lane ? (~0ull >> (64 - lane)) : 0ull;
-            uint32_t hb = 0, sb = 0;
+            uint32_t hb = 0;
             if (lane == 0 && hm) hb = atomicAdd(&a.ctr[2], (uint32_t)__popcll(hm));
-            if (lane == 0 && sm) sb = atomicAdd(&a.ctr[3], (uint32_t)__popcll(sm));
-            hb = rdlane_u(hb, 0); sb = rdlane_u(sb, 0);
+            hb = rdlane_u(hb, 0);
             if (huf) a.huf_list[hb + (uint32_t)__popcll(hm & below)] = slot;
-            if (seq) a.seq_list[sb + (uint32_t)__popcll(sm & below)] = slot;
+            for (uint32_t q = 0; q < 3; q++) {
+                const bool mine = seq && cls == q;
+                const uint64_t sm = __ballot(mine);
+                uint32_t sb = 0;
+                if (lane == 0 && sm) sb = atomicAdd(&a.ctr[q == 0 ? 3 : 4 + q], (uint32_t)__popcll(sm));
+                sb = rdlane_u(sb, 0);
+                if (mine) a.seq_list[(size_t)q * a.item_cap + sb + (uint32_t)__popcll(sm & below)] = slot;
+            }
         }
     }
 }
@@ -1340,25 +1393,31 @@ __global__ __launch_bounds__(64) void k_bx_huf(BxArgs a) {
 
 // the n (<= 32) bits of the 128-bit little-endian value hi:lo that start at bit s (s + n <= 128)
 __device__ __forceinline__ uint32_t bx_ext(uint64_t lo, uint64_t hi, uint32_t s, uint32_t n) {
-    const uint64_t v = s >= 64 ? hi >> (s - 64) : (lo >> s) | ((hi << 1) << (63 - s));
+    const uint64_t v = s >= 64 ? hi >> (s & 63) : (lo >> s) | ((hi << 1) << (63 - s));
     return (uint32_t)v & (n >= 32 ? 0xFFFFFFFFu : (1u << n) - 1u);
 }
 __device__ __forceinline__ uint64_t bx_ext64(uint64_t lo, uint64_t hi, uint32_t s, uint32_t n) {  // n <= 63
-    const uint64_t v = s >= 64 ? hi >> (s - 64) : (lo >> s) | ((hi << 1) << (63 - s));
+    const uint64_t v = s >= 64 ? hi >> (s & 63) : (lo >> s) | ((hi << 1) << (63 - s));
     return v & ((1ull << n) - 1ull);
 }
 
-// lane = block: the FSE sequence bitstream -> records
-__global__ __launch_bounds__(64) void k_bx_fse(BxArgs a) {
-    __shared__ uint32_t s_llb[36], s_mlb[53];
+// lane = block: the FSE sequence bitstream -> records.  LANES blocks per wave, by the size of their three tables (the
+// tables live in the wave's LDS, every lane's in a region of its own: a lookup is a ds_read, not a gather from the pool).
+// A lane keeps 16 bytes of its stream in registers and reloads them when fewer than 64 unread bits are left in them
+// (a sequence takes 85 at most, 10-20 on text: one load per 3-6 sequences, issued beside the table reads).
+__global__ __launch_bounds__(64) void k_bx_fse(BxArgs a, const uint32_t *list, const uint32_t *n_list_p, const uint32_t LANES) {
+    const uint32_t CELLS = LANES == 64 ? 384 : (LANES == 32 ? 768 : 1280), STRIDE = 2 * CELLS + 16;
+    __shared__ __attribute__((aligned(16))) uint8_t T[64 * (2 * 384 + 16)];  // = the largest of the three shapes
+    __shared__ uint32_t s_ll[64], s_ml[64];  // base value | extra bits << 24, by symbol
     const uint32_t lane = threadIdx.x;
-    if (lane < 36) s_llb[lane] = c_ll_base[lane];
-    if (lane < 53) s_mlb[lane] = c_ml_base[lane];
+    s_ll[lane] = lane < 36 ? c_ll_base[lane] | ((uint32_t)c_ll_bits[lane] << 24) : 0u;
+    s_ml[lane] = lane < 53 ? c_ml_base[lane] | ((uint32_t)c_ml_bits[lane] << 24) : 0u;
     __builtin_amdgcn_wave_barrier();
-    const uint32_t n_list = a.ctr[3];
-    for (uint32_t g0 = blockIdx.x * 64; g0 < n_list; g0 += gridDim.x * 64) {
-        const bool on0 = g0 + lane < n_list;
-        const uint32_t slot = on0 ? a.seq_list[g0 + lane] : 0;
+    const uint32_t n_list = *n_list_p;
+    lds8 *const my = (lds8 *)T + (lane < LANES ? lane : 0) * STRIDE;
+    for (uint32_t g0 = blockIdx.x * LANES; g0 < n_list; g0 += gridDim.x * LANES) {
+        const bool on0 = lane < LANES && g0 + lane < n_list;
+        const uint32_t slot = on0 ? list[g0 + lane] : 0;
         BxPrep pr;
         pr.frame = 0; pr.k = 0; pr.logs = 0; pr.bs_off = 0; pr.bs_len = 0; pr.tab[0] = pr.tab[1] = pr.tab[2] = 0;
         FzItem it;
@@ -1369,11 +1428,22 @@ __global__ __launch_bounds__(64) void k_bx_fse(BxArgs a) {
         const uint64_t foff = on0 ? a.blob_off[row] - a.blob_base : 0;  // the frame inside the blob region
         const uint8_t *const bb = a.blobs + foff + pr.bs_off;           // first byte of the bitstream
         const bool head_ok = foff + pr.bs_off >= 16;                    // 16 bytes in front of the stream can be read
-        const uint32_t *const tl = a.fse_pool + pr.tab[0], *const to = a.fse_pool + pr.tab[1], *const tm = a.fse_pool + pr.tab[2];
         const uint32_t log_l = pr.logs & 255, log_o = (pr.logs >> 8) & 255, log_m = (pr.logs >> 16) & 255;
+        const uint32_t c_l = (1u << log_l) < 8 ? 8u : 1u << log_l, c_o = (1u << log_o) < 8 ? 8u : 1u << log_o, c_m = (1u << log_m) < 8 ? 8u : 1u << log_m;
+        // this lane's tables -> its LDS region [LL | OF | ML], 16 bytes per step
+        __builtin_amdgcn_wave_barrier();
+        if (on0) {
+            const uint16_t *const gl = a.fse_pool + pr.tab[0], *const go = a.fse_pool + pr.tab[1], *const gm = a.fse_pool + pr.tab[2];
+            for (uint32_t i = 0; i < c_l; i += 8) { const uint4 v = *reinterpret_cast<const uint4 *>(gl + i); LDS_CP(my + 2 * i, &v, 16); }
+            for (uint32_t i = 0; i < c_o; i += 8) { const uint4 v = *reinterpret_cast<const uint4 *>(go + i); LDS_CP(my + 2 * (c_l + i), &v, 16); }
+            for (uint32_t i = 0; i < c_m; i += 8) { const uint4 v = *reinterpret_cast<const uint4 *>(gm + i); LDS_CP(my + 2 * (c_l + c_o + i), &v, 16); }
+        }
+        const lds8 *const tl = my, *const to = my + 2 * c_l, *const tm = my + 2 * (c_l + c_o);
         unsigned long long *const recs = a.seq_pool + it.seq_off;
         // the 16 stream bytes that end at byte `bend` (bytes in front of the stream read as zero)
-        auto window = [&](int32_t bend, uint64_t &lo, uint64_t &hi) {
+        uint64_t lo = 0, hi = 0;
+        int32_t wend = 0;  // the window holds stream bytes [wend - 16, wend)
+        auto window = [&](int32_t bend) {
             if (bend >= 16 || head_ok) {
                 __builtin_memcpy(&lo, bb + bend - 16, 8);
                 __builtin_memcpy(&hi, bb + bend - 8, 8);
@@ -1390,6 +1460,7 @@ __global__ __launch_bounds__(64) void k_bx_fse(BxArgs a) {
                     if (k < 8) lo |= byte << (8 * k); else hi |= byte << (8 * (k - 8));
                 }
             }
+            wend = bend;
         };
         int err = 0;
         int32_t left = 0;
@@ -1400,10 +1471,8 @@ __global__ __launch_bounds__(64) void k_bx_fse(BxArgs a) {
             const uint32_t need = log_l + log_o + log_m;
             if (left < (int32_t)need) err = E_CORRUPT;
             else {
-                const int32_t bend = (left + 7) >> 3;
-                uint64_t lo, hi;
-                window(bend, lo, hi);
-                const uint32_t top = 128u - (uint32_t)(8 * bend - left);  // bit index just above the first unread bit
+                window((left + 7) >> 3);
+                const uint32_t top = 128u - (uint32_t)(8 * wend - left);  // bit index just above the first unread bit
                 sl = bx_ext(lo, hi, top - log_l, log_l);
                 so = bx_ext(lo, hi, top - log_l - log_o, log_o);
                 sm = bx_ext(lo, hi, top - need, log_m);
@@ -1416,28 +1485,34 @@ __global__ __launch_bounds__(64) void k_bx_fse(BxArgs a) {
         uint32_t nmax = nseq;
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) nmax = max(nmax, (uint32_t)__shfl_xor((int)nmax, d));
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
         for (uint32_t i = 0; i < nmax; i++) {
             if (i < nseq && !err) {
-                const uint32_t el = tl[sl], eo = to[so], em = tm[sm];
-                const int32_t bend = (left + 7) >> 3;
-                uint64_t lo, hi;
-                window(bend, lo, hi);
-                const uint32_t llb = (el >> 13) & 31, ofb = (eo >> 13) & 31, mlb = (em >> 13) & 31, need_v = llb + ofb + mlb;
+                if (128 - (8 * wend - left) < 64) window((left + 7) >> 3);  // fewer than 64 unread bits in the registers
+                typedef __attribute__((address_space(3))) uint16_t lds16;
+                const uint32_t cl = *(const lds16 *)(tl + 2 * sl), co = *(const lds16 *)(to + 2 * so), cm = *(const lds16 *)(tm + 2 * sm);
+                const uint32_t sy_l = cl & 63u, sy_o = co & 63u, sy_m = cm & 63u;
+                const uint32_t ns_l = cl >> 6, ns_o = co >> 6, ns_m = cm >> 6;
+                const uint32_t vl = s_ll[sy_l], vm = s_ml[sy_m];
+                const uint32_t llb = vl >> 24, mlb = vm >> 24, ofb = sy_o, need_v = llb + ofb + mlb;
                 const bool lastseq = i + 1 == nseq;
-                const uint32_t nbl = (el >> 9) & 15, nbo = (eo >> 9) & 15, nbm = (em >> 9) & 15, need_s = lastseq ? 0u : nbl + nbo + nbm;
-                if (ofb > 27) { err = E_UNSUP; }
+                const uint32_t nbl = log_l - (uint32_t)hibit(ns_l), nbo = log_o - (uint32_t)hibit(ns_o), nbm = log_m - (uint32_t)hibit(ns_m);
+                const uint32_t need_s = lastseq ? 0u : nbl + nbo + nbm;
+                if (ofb > 27) err = E_UNSUP;
                 else if (left < (int32_t)(need_v + need_s)) err = E_CORRUPT;
                 else {
-                    const uint32_t top = 128u - (uint32_t)(8 * bend - left);
+                    if (128 - (8 * wend - left) < (int32_t)(need_v + need_s)) window((left + 7) >> 3);  // a long sequence
+                    const uint32_t top = 128u - (uint32_t)(8 * wend - left);
                     const uint64_t xv = bx_ext64(lo, hi, top - need_v, need_v);  // offset bits, match-length bits, literal-length bits
                     const uint32_t ov = (1u << ofb) + (uint32_t)(xv >> (mlb + llb));
-                    const uint32_t ml = s_mlb[(em >> 18) & 63] + ((uint32_t)(xv >> llb) & ((1u << mlb) - 1u));
-                    const uint32_t ll = s_llb[(el >> 18) & 63] + ((uint32_t)xv & ((1u << llb) - 1u));
+                    const uint32_t ml = (vm & 0xFFFFFFu) + ((uint32_t)(xv >> llb) & ((1u << mlb) - 1u));
+                    const uint32_t ll = (vl & 0xFFFFFFu) + ((uint32_t)xv & ((1u << llb) - 1u));
                     if (!lastseq) {
                         const uint32_t xs = bx_ext(lo, hi, top - need_v - need_s, need_s);  // LL, ML, OF state bits
-                        sl = (el & 511) + (xs >> (nbm + nbo));
-                        sm = (em & 511) + ((xs >> nbo) & ((1u << nbm) - 1u));
-                        so = (eo & 511) + (xs & ((1u << nbo) - 1u));
+                        sl = (ns_l << nbl) - (1u << log_l) + (xs >> (nbm + nbo));
+                        sm = (ns_m << nbm) - (1u << log_m) + ((xs >> nbo) & ((1u << nbm) - 1u));
+                        so = (ns_o << nbo) - (1u << log_o) + (xs & ((1u << nbo) - 1u));
                     }
                     left -= (int32_t)(need_v + need_s);
                     // repeat offsets (RFC 8878 3.1.1.5); a value with FZ_SYM set = "incoming entry k, minus d"
@@ -1494,15 +1569,19 @@ __global__ __launch_bounds__(64) void k_bx_exec(BxArgs a) {
     const uint32_t lane = threadIdx.x;
     const uint32_t n_slots = a.ctr[0];
     const FzArgs z = bx_as_fz(a);
-    for (;;) {
-        uint32_t c = 0;
-        if (lane == 0) c = atomicAdd(&a.ctr[4], 1u);
-        c = rdlane_u(c, 0);
-        if (c >= n_slots) break;
-        fz_exec_frame<false>(z, c, W, lane);
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_wave_barrier();
+    uint32_t n_done = 0;
+    for (;;) {  // four slots per atomic: one cursor word takes ~88 additions per microsecond
+        uint32_t c0 = 0;
+        if (lane == 0) c0 = atomicAdd(&a.ctr[4], 4u);
+        c0 = rdlane_u(c0, 0);
+        if (c0 >= n_slots) break;
+        for (uint32_t c = c0; c < c0 + 4 && c < n_slots; c++) {
+            if (fz_exec_frame<false>(z, c, W, lane)) n_done++;
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+        }
     }
+    if (lane == 0 && n_done) atomicAdd(&a.pool_used[2], (unsigned long long)n_done);  // statistics: frames decoded by this path
 }
 
 __global__ __launch_bounds__(64) void k_bx_finish(BxArgs a) {
@@ -1525,27 +1604,32 @@ __global__ __launch_bounds__(64) void k_bx_finish(BxArgs a) {
     }
 }
 
-void launch_bx(const BxArgs &a, int cus, hipStream_t s) {
-    const uint32_t slots = a.slot_cap, lane_grid = std::min<uint32_t>((slots + 63) / 64, (uint32_t)cus * 8);
+// stage 0..5 = scan, prep, huf, fse, exec, finish (launched one by one so that each can be timed)
+void launch_bx_stage(const BxArgs &a, int cus, int stage, hipStream_t s) {
+    const uint32_t slots = a.slot_cap, lane_grid = std::max(std::min<uint32_t>((slots + 63) / 64, (uint32_t)cus * 8), 1u);
     if (!slots) return;
-    hipLaunchKernelGGL(k_bx_scan, dim3(std::max(lane_grid, 1u)), dim3(64), 0, s, a);
-    hipLaunchKernelGGL(k_bx_prep, dim3(std::max(std::min<uint32_t>((a.item_cap + 63) / 64, (uint32_t)cus * 3), 1u)), dim3(64), 0, s, a);
-    hipLaunchKernelGGL(k_bx_huf, dim3(std::max(std::min<uint32_t>((a.item_cap + BX_HUF_BLOCKS - 1) / BX_HUF_BLOCKS, (uint32_t)cus * 2), 1u)), dim3(64), 0, s, a);
-    hipLaunchKernelGGL(k_bx_fse, dim3(std::max(std::min<uint32_t>((a.item_cap + 63) / 64, (uint32_t)cus * 8), 1u)), dim3(64), 0, s, a);
-    hipLaunchKernelGGL(k_bx_exec, dim3(std::max(std::min<uint32_t>(slots, (uint32_t)cus * 12), 1u)), dim3(64), 0, s, a);
-    hipLaunchKernelGGL(k_bx_finish, dim3(std::max(lane_grid, 1u)), dim3(64), 0, s, a);
+    auto cap = [&](uint32_t want, uint32_t per_cu) { return dim3(std::max(std::min<uint32_t>(want, (uint32_t)cus * per_cu), 1u)); };
+    switch (stage) {
+    case 0: hipLaunchKernelGGL(k_bx_scan, dim3(lane_grid), dim3(64), 0, s, a); break;
+    case 1: hipLaunchKernelGGL(k_bx_prep, cap((a.item_cap + 63) / 64, 3), dim3(64), 0, s, a); break;
+    case 2: hipLaunchKernelGGL(k_bx_huf, cap((a.item_cap + BX_HUF_BLOCKS - 1) / BX_HUF_BLOCKS, 2), dim3(64), 0, s, a); break;
+    case 3:
+        hipLaunchKernelGGL(k_bx_fse, cap((a.item_cap + 63) / 64, 3), dim3(64), 0, s, a, a.seq_list, a.ctr + 3, 64u);
+        hipLaunchKernelGGL(k_bx_fse, cap((a.item_cap + 31) / 32, 3), dim3(64), 0, s, a, a.seq_list + a.item_cap, a.ctr + 5, 32u);
+        hipLaunchKernelGGL(k_bx_fse, cap((a.item_cap + 15) / 16, 3), dim3(64), 0, s, a, a.seq_list + 2 * (size_t)a.item_cap, a.ctr + 6, 16u);
+        break;
+    case 4: hipLaunchKernelGGL(k_bx_exec, cap(slots, 12), dim3(64), 0, s, a); break;
+    default: hipLaunchKernelGGL(k_bx_finish, dim3(lane_grid), dim3(64), 0, s, a); break;
+    }
 }
 
 // host: the three predefined tables (RFC 8878 3.1.1.3.2.2.1) as FSE pool cells, by the same spread as the device's
-void bx_predefined_tables(uint32_t cells[160]) {
+void bx_predefined_tables(uint16_t cells[160]) {
     static const int8_t ll_def[36] = {4, 3, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 1, 1, 1, 2, 2, 2, 2, 2, 2, 2, 2, 2, 3, 2, 1, 1, 1, 1, 1, -1, -1, -1, -1};
     static const int8_t ml_def[53] = {1, 4, 3, 2, 2, 2, 2, 2, 2, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1,
                                       1, 1, 1, 1, 1, 1, 1, 1, 1, 1, -1, -1, -1, -1, -1, -1, -1};
     static const int8_t of_def[29] = {1, 1, 1, 1, 1, 1, 2, 2, 2, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, -1, -1, -1, -1, -1};
-    static const uint8_t ll_bits[36] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 3, 3, 4, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16};
-    static const uint8_t ml_bits[53] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 1,
-                                        1, 1, 2, 2, 3, 3, 4, 4, 5, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16};
-    auto build = [&](const int8_t *norm, int nsym, int log, int kind, uint32_t *t) {
+    auto build = [&](const int8_t *norm, int nsym, int log, int kind, uint16_t *t) {
         const int size = 1 << log;
         int high = size;
         uint8_t sym_of[64];
@@ -1560,10 +1644,9 @@ void bx_predefined_tables(uint32_t cells[160]) {
         }
         for (int u = 0; u < size; u++) {
             const uint32_t sym = sym_of[u], ns = next[sym]++;
-            uint32_t hb = 31; while (!(ns >> hb)) hb--;
-            const uint32_t nb = (uint32_t)log - hb;
-            const uint32_t ab = kind == K_LL ? ll_bits[sym] : (kind == K_ML ? ml_bits[sym] : sym);
-            t[u] = ((ns << nb) - (uint32_t)size) | (nb << 9) | (ab << 13) | (sym << 18);
+            uint32_t hb = 31; while (!(ns >> hb)) hb--;  // (kept: documents that the bits to read are log - hb)
+            (void)hb; (void)kind;
+            t[u] = (uint16_t)(sym | (ns << 6));
         }
     };
     build(ll_def, 36, 6, K_LL, cells + BX_PREDEF_LL);
