@@ -1403,18 +1403,24 @@ __device__ __forceinline__ uint64_t bx_ext64(uint64_t lo, uint64_t hi, uint32_t 
 
 // lane = block: the FSE sequence bitstream -> records.  LANES blocks per wave, by the size of their three tables (the
 // tables live in the wave's LDS, every lane's in a region of its own: a lookup is a ds_read, not a gather from the pool).
-// A lane keeps 16 bytes of its stream in registers and reloads them when fewer than 64 unread bits are left in them
-// (a sequence takes 85 at most, 10-20 on text: one load per 3-6 sequences, issued beside the table reads).
+// The stream reaches a lane through a 64-byte LDS buffer of its own, refilled every four sequences by loads that were
+// issued four sequences earlier (all lanes at the same point of the loop: a lane that reloaded whenever it ran dry would
+// make its whole wave wait out a memory round trip at nearly every step — vmcnt is in order, behind the record stores
+// too); a lane whose sequences are so long that the buffer runs out before the next refill reloads on the spot.  Records
+// leave eight at a time, 64 contiguous bytes per lane.
 __global__ __launch_bounds__(64) void k_bx_fse(BxArgs a, const uint32_t *list, const uint32_t *n_list_p, const uint32_t LANES) {
-    const uint32_t CELLS = LANES == 64 ? 384 : (LANES == 32 ? 768 : 1280), STRIDE = 2 * CELLS + 16;
-    __shared__ __attribute__((aligned(16))) uint8_t T[64 * (2 * 384 + 16)];  // = the largest of the three shapes
+    const uint32_t CELLS = LANES == 64 ? 384 : (LANES == 32 ? 768 : 1280), STRIDE = 2 * CELLS;
+    __shared__ __attribute__((aligned(16))) uint8_t T[64 * 2 * 384];  // = the largest of the three shapes
+    __shared__ __attribute__((aligned(16))) uint8_t BUF[64 * 64];
     __shared__ uint32_t s_ll[64], s_ml[64];  // base value | extra bits << 24, by symbol
+    typedef __attribute__((address_space(3))) uint16_t lds16;
     const uint32_t lane = threadIdx.x;
     s_ll[lane] = lane < 36 ? c_ll_base[lane] | ((uint32_t)c_ll_bits[lane] << 24) : 0u;
     s_ml[lane] = lane < 53 ? c_ml_base[lane] | ((uint32_t)c_ml_bits[lane] << 24) : 0u;
     __builtin_amdgcn_wave_barrier();
     const uint32_t n_list = *n_list_p;
     lds8 *const my = (lds8 *)T + (lane < LANES ? lane : 0) * STRIDE;
+    lds8 *const buf = (lds8 *)BUF + lane * 64;
     for (uint32_t g0 = blockIdx.x * LANES; g0 < n_list; g0 += gridDim.x * LANES) {
         const bool on0 = lane < LANES && g0 + lane < n_list;
         const uint32_t slot = on0 ? list[g0 + lane] : 0;
@@ -1427,7 +1433,6 @@ __global__ __launch_bounds__(64) void k_bx_fse(BxArgs a, const uint32_t *list, c
         const uint32_t row = on0 ? a.cand_row[pr.frame] : 0;
         const uint64_t foff = on0 ? a.blob_off[row] - a.blob_base : 0;  // the frame inside the blob region
         const uint8_t *const bb = a.blobs + foff + pr.bs_off;           // first byte of the bitstream
-        const bool head_ok = foff + pr.bs_off >= 16;                    // 16 bytes in front of the stream can be read
         const uint32_t log_l = pr.logs & 255, log_o = (pr.logs >> 8) & 255, log_m = (pr.logs >> 16) & 255;
         const uint32_t c_l = (1u << log_l) < 8 ? 8u : 1u << log_l, c_o = (1u << log_o) < 8 ? 8u : 1u << log_o, c_m = (1u << log_m) < 8 ? 8u : 1u << log_m;
         // this lane's tables -> its LDS region [LL | OF | ML], 16 bytes per step
@@ -1440,27 +1445,27 @@ __global__ __launch_bounds__(64) void k_bx_fse(BxArgs a, const uint32_t *list, c
         }
         const lds8 *const tl = my, *const to = my + 2 * c_l, *const tm = my + 2 * (c_l + c_o);
         unsigned long long *const recs = a.seq_pool + it.seq_off;
-        // the 16 stream bytes that end at byte `bend` (bytes in front of the stream read as zero)
-        uint64_t lo = 0, hi = 0;
-        int32_t wend = 0;  // the window holds stream bytes [wend - 16, wend)
-        auto window = [&](int32_t bend) {
-            if (bend >= 16 || head_ok) {
-                __builtin_memcpy(&lo, bb + bend - 16, 8);
-                __builtin_memcpy(&hi, bb + bend - 8, 8);
-                if (bend < 16) {  // zero what lies in front of the stream
-                    const uint32_t z = 8u * (uint32_t)(16 - bend);  // bits, 8 .. 128
-                    if (z >= 64) { lo = 0; hi = z >= 128 ? 0 : (hi >> (z - 64)) << (z - 64); }
-                    else lo = (lo >> z) << z;
-                }
-            } else {
-                lo = 0; hi = 0;
-                for (int32_t k = 0; k < 16; k++) {
-                    const int32_t o = bend - 16 + k;
-                    const uint64_t byte = o >= 0 ? bb[o] : 0;
-                    if (k < 8) lo |= byte << (8 * k); else hi |= byte << (8 * (k - 8));
-                }
+        // the lane's buffer holds stream bytes [bufhi - 64, bufhi); pv = the bytes [pendhi - 64, pendhi) on their way
+        int32_t bufhi = 0, pendhi = 0;
+        uint4 pv0 = make_uint4(0, 0, 0, 0), pv1 = pv0, pv2 = pv0, pv3 = pv0;
+        auto fetch = [&](int32_t hi_byte) {  // issue the loads of the 64 bytes that end at stream byte hi_byte
+            pendhi = hi_byte;
+            const uint8_t *g = bb + hi_byte - 64;
+            __builtin_memcpy(&pv0, g, 16); __builtin_memcpy(&pv1, g + 16, 16); __builtin_memcpy(&pv2, g + 32, 16); __builtin_memcpy(&pv3, g + 48, 16);
+        };
+        auto commit = [&]() {  // the fetched bytes become the buffer
+            LDS_CP(buf, &pv0, 16); LDS_CP(buf + 16, &pv1, 16); LDS_CP(buf + 32, &pv2, 16); LDS_CP(buf + 48, &pv3, 16);
+            bufhi = pendhi;
+        };
+        // the 128 bits of the 16 stream bytes that end at byte `bend` (v = those bytes out of the buffer; bytes in front of the
+        // stream read as zero)
+        auto bits128 = [&](const uint4 v, const int32_t bend, uint64_t &lo, uint64_t &hi) {
+            lo = (uint64_t)v.x | ((uint64_t)v.y << 32); hi = (uint64_t)v.z | ((uint64_t)v.w << 32);
+            if (bend < 16) {  // (the last sequences of a block)
+                const uint32_t z = 8u * (uint32_t)(16 - bend);  // bits, 8 .. 128
+                if (z >= 64) { lo = 0; hi = z >= 128 ? 0 : (hi >> (z - 64)) << (z - 64); }
+                else lo = (lo >> z) << z;
             }
-            wend = bend;
         };
         int err = 0;
         int32_t left = 0;
@@ -1470,9 +1475,15 @@ __global__ __launch_bounds__(64) void k_bx_fse(BxArgs a, const uint32_t *list, c
             left = (int32_t)(pr.bs_len * 8) - (8 - hibit(last));
             const uint32_t need = log_l + log_o + log_m;
             if (left < (int32_t)need) err = E_CORRUPT;
+            else if (foff + pr.bs_off < 64) err = E_UNSUP;  // the blob region starts less than 64 bytes in front of the stream (its first frame, if tiny): the serial decoder's
             else {
-                window((left + 7) >> 3);
-                const uint32_t top = 128u - (uint32_t)(8 * wend - left);  // bit index just above the first unread bit
+                const int32_t bend = (left + 7) >> 3;
+                fetch(bend); commit();
+                uint4 v;
+                LDS_LD(&v, buf + 48, 16);
+                uint64_t lo, hi;
+                bits128(v, bend, lo, hi);
+                const uint32_t top = 128u - (uint32_t)(8 * bend - left);  // bit index just above the first unread bit
                 sl = bx_ext(lo, hi, top - log_l, log_l);
                 so = bx_ext(lo, hi, top - log_l - log_o, log_o);
                 sm = bx_ext(lo, hi, top - need, log_m);
@@ -1487,14 +1498,22 @@ __global__ __launch_bounds__(64) void k_bx_fse(BxArgs a, const uint32_t *list, c
         for (int d = 32; d >= 1; d >>= 1) nmax = max(nmax, (uint32_t)__shfl_xor((int)nmax, d));
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_wave_barrier();
-        for (uint32_t i = 0; i < nmax; i++) {
-            if (i < nseq && !err) {
-                if (128 - (8 * wend - left) < 64) window((left + 7) >> 3);  // fewer than 64 unread bits in the registers
-                typedef __attribute__((address_space(3))) uint16_t lds16;
+        bool have_pending = false;
+        const uint32_t size_l = 1u << log_l, size_o = 1u << log_o, size_m = 1u << log_m;
+        // one sequence of this lane's block -> its record (0 for a lane that has none left)
+        auto step = [&](const uint32_t i) -> unsigned long long {
+            unsigned long long rec = 0;
+            if (i < nseq && err == 0) {
+                const int32_t bend = (left + 7) >> 3;
+                if (bufhi - bend > 48) { fetch(bend); commit(); }  // the buffer ran out (long sequences): reload on the spot
+                uint4 v;
+                LDS_LD(&v, buf + (48 - (bufhi - bend)), 16);
                 const uint32_t cl = *(const lds16 *)(tl + 2 * sl), co = *(const lds16 *)(to + 2 * so), cm = *(const lds16 *)(tm + 2 * sm);
                 const uint32_t sy_l = cl & 63u, sy_o = co & 63u, sy_m = cm & 63u;
-                const uint32_t ns_l = cl >> 6, ns_o = co >> 6, ns_m = cm >> 6;
                 const uint32_t vl = s_ll[sy_l], vm = s_ml[sy_m];
+                const uint32_t ns_l = cl >> 6, ns_o = co >> 6, ns_m = cm >> 6;
+                uint64_t lo, hi;
+                bits128(v, bend, lo, hi);
                 const uint32_t llb = vl >> 24, mlb = vm >> 24, ofb = sy_o, need_v = llb + ofb + mlb;
                 const bool lastseq = i + 1 == nseq;
                 const uint32_t nbl = log_l - (uint32_t)hibit(ns_l), nbo = log_o - (uint32_t)hibit(ns_o), nbm = log_m - (uint32_t)hibit(ns_m);
@@ -1502,17 +1521,16 @@ __global__ __launch_bounds__(64) void k_bx_fse(BxArgs a, const uint32_t *list, c
                 if (ofb > 27) err = E_UNSUP;
                 else if (left < (int32_t)(need_v + need_s)) err = E_CORRUPT;
                 else {
-                    if (128 - (8 * wend - left) < (int32_t)(need_v + need_s)) window((left + 7) >> 3);  // a long sequence
-                    const uint32_t top = 128u - (uint32_t)(8 * wend - left);
+                    const uint32_t top = 128u - (uint32_t)(8 * bend - left);  // >= 121 >= need_v + need_s
                     const uint64_t xv = bx_ext64(lo, hi, top - need_v, need_v);  // offset bits, match-length bits, literal-length bits
                     const uint32_t ov = (1u << ofb) + (uint32_t)(xv >> (mlb + llb));
                     const uint32_t ml = (vm & 0xFFFFFFu) + ((uint32_t)(xv >> llb) & ((1u << mlb) - 1u));
                     const uint32_t ll = (vl & 0xFFFFFFu) + ((uint32_t)xv & ((1u << llb) - 1u));
                     if (!lastseq) {
                         const uint32_t xs = bx_ext(lo, hi, top - need_v - need_s, need_s);  // LL, ML, OF state bits
-                        sl = (ns_l << nbl) - (1u << log_l) + (xs >> (nbm + nbo));
-                        sm = (ns_m << nbm) - (1u << log_m) + ((xs >> nbo) & ((1u << nbm) - 1u));
-                        so = (ns_o << nbo) - (1u << log_o) + (xs & ((1u << nbo) - 1u));
+                        sl = (ns_l << nbl) - size_l + (xs >> (nbm + nbo));
+                        sm = (ns_m << nbm) - size_m + ((xs >> nbo) & ((1u << nbm) - 1u));
+                        so = (ns_o << nbo) - size_o + (xs & ((1u << nbo) - 1u));
                     }
                     left -= (int32_t)(need_v + need_s);
                     // repeat offsets (RFC 8878 3.1.1.5); a value with FZ_SYM set = "incoming entry k, minus d"
@@ -1536,8 +1554,27 @@ __global__ __launch_bounds__(64) void k_bx_fse(BxArgs a, const uint32_t *list, c
                     }
                     sum_ll += ll; sum_ml += ml;
                     if (sum_ll + sum_ml > BLOCK_MAX) err = E_UNSUP;
-                    recs[i] = (unsigned long long)ll | ((unsigned long long)ml << 17) | ((unsigned long long)o << 35);
+                    rec = (unsigned long long)ll | ((unsigned long long)ml << 17) | ((unsigned long long)o << 35);
                 }
+            }
+            return rec;
+        };
+        auto refill = [&](const uint32_t i) {  // every four sequences, all lanes: last time's bytes in, the next ones on their way
+            if (have_pending) commit();
+            if (i < nseq && err == 0) fetch((left + 7) >> 3);
+            have_pending = true;
+        };
+        for (uint32_t i0 = 0; i0 < nmax; i0 += 8) {
+            refill(i0);
+            const unsigned long long q0 = step(i0), q1 = step(i0 + 1), q2 = step(i0 + 2), q3 = step(i0 + 3);
+            refill(i0 + 4);
+            const unsigned long long q4 = step(i0 + 4), q5 = step(i0 + 5), q6 = step(i0 + 6), q7 = step(i0 + 7);
+            if (i0 < nseq) {  // the block's record space is a multiple of eight
+                uint4 *const d = reinterpret_cast<uint4 *>(recs + i0);
+                d[0] = make_uint4((uint32_t)q0, (uint32_t)(q0 >> 32), (uint32_t)q1, (uint32_t)(q1 >> 32));
+                d[1] = make_uint4((uint32_t)q2, (uint32_t)(q2 >> 32), (uint32_t)q3, (uint32_t)(q3 >> 32));
+                d[2] = make_uint4((uint32_t)q4, (uint32_t)(q4 >> 32), (uint32_t)q5, (uint32_t)(q5 >> 32));
+                d[3] = make_uint4((uint32_t)q6, (uint32_t)(q6 >> 32), (uint32_t)q7, (uint32_t)(q7 >> 32));
             }
         }
         if (on0) {
