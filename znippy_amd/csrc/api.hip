@@ -794,7 +794,7 @@ int znippy_rows_create(znippy_ctx *ctx, const uint64_t *blob_offset, const uint6
                 r->bx_item_cap = (uint32_t)cap;
                 if (tmalloc(ctx, &r->bx_cand_row, 4 * (size_t)r->bx_slots) != hipSuccess || tmalloc(ctx, &r->bx_cand_base, 4 * (size_t)r->bx_slots) != hipSuccess ||
                     tmalloc(ctx, &r->bx_cand_nb, 4 * (size_t)r->bx_slots) != hipSuccess || tmalloc(ctx, &r->bx_huf_list, 4 * (size_t)cap) != hipSuccess ||
-                    tmalloc(ctx, &r->bx_seq_list, 3 * 4 * (size_t)cap) != hipSuccess || tmalloc(ctx, &r->bx_items, sizeof(zn::FzItem) * (size_t)cap) != hipSuccess ||
+                    tmalloc(ctx, &r->bx_seq_list, 4 * 4 * (size_t)cap) != hipSuccess || tmalloc(ctx, &r->bx_items, sizeof(zn::FzItem) * (size_t)cap) != hipSuccess ||
                     tmalloc(ctx, &r->bx_prep, sizeof(zn::BxPrep) * (size_t)cap) != hipSuccess) {
                     znippy_rows_destroy(r);
                     return ZNIPPY_E_NOMEM;
@@ -1148,12 +1148,26 @@ int znippy_decode_verify_rows_async(znippy_ctx *ctx, znippy_rows *r, const void 
                 (void)hipMemset(dbg, 0, 512);
                 x.dbg = dbg;
             }
-            static const char *const bx_names[6] = {"zstd_batch_scan", "zstd_batch_tables", "zstd_batch_huffman", "zstd_batch_sequences", "zstd_batch_execute", "zstd_batch_finish"};
-            for (int st = 0; st < 6; st++) {
-                ktime_begin(ctx, bx_names[st]);
-                launch_bx_stage(x, ctx->cus, st, s);
-                ktime_end(ctx);
-            }
+            static const char *const bx_names[7] = {"zstd_batch_scan", "zstd_batch_tables", "zstd_batch_huffman", "zstd_batch_sequences", "zstd_batch_execute", "zstd_batch_finish",
+                                                    "zstd_batch_sequences_long"};
+            auto stage = [&](int st, hipStream_t on) {
+                ktime_begin(ctx, bx_names[st], on);
+                launch_bx_stage(x, ctx->cus, st, on);
+                ktime_end(ctx, on);
+            };
+            stage(0, s);
+            stage(1, s);
+            // the long chains (blocks of >= BX_BIG_SEQ sequences, a wave each) run on the auxiliary stream beside the Huffman
+            // streams and the lane-per-block sequence kernel: each is a few hundred long-lived waves at most
+            HIPCHK(ctx, hipEventRecord(ctx->ev_fork, s));
+            HIPCHK(ctx, hipStreamWaitEvent(ctx->aux, ctx->ev_fork, 0));
+            stage(6, ctx->aux);
+            HIPCHK(ctx, hipEventRecord(ctx->ev_join, ctx->aux));
+            stage(2, s);
+            stage(3, s);
+            HIPCHK(ctx, hipStreamWaitEvent(s, ctx->ev_join, 0));
+            stage(4, s);
+            stage(5, s);
             a.list_a = nullptr; a.n_list_a = 0;
             a.pending = r->pending2; a.pending_count = r->pending_count + 1;
             a.cursor = r->cursor + 8;

@@ -219,6 +219,7 @@ struct BxPrep {            // per block item, written by k_bx_prep
     uint32_t bs_off;       // sequences bitstream: offset from the frame's first byte
     uint32_t bs_len;       // bytes
 };
+constexpr uint32_t BX_BIG_SEQ = 2048;  // blocks of this many sequences get a wave of their own in the sequence stage
 constexpr uint32_t BX_PREDEF_LL = 0, BX_PREDEF_OF = 64, BX_PREDEF_ML = 96, BX_POOL_FIRST = 160;  // predefined tables at the head of the FSE pool
 // FSE pool cell (2 bytes): symbol:6 | ns:10 << 6 (zstd_batch.hip)
 struct BxArgs {
@@ -235,8 +236,8 @@ struct BxArgs {
     uint32_t *cand_row, *cand_base, *cand_nb;  // per candidate slot (written by the scan)
     uint32_t slot_cap;
     FzItem *items; BxPrep *prep; uint32_t item_cap;
-    uint32_t *ctr;  // [0] slots, [1] items, [2] Huffman list, [3] [5] [6] sequence lists (64 / 32 / 16 blocks per wave), [4] execute cursor (zeroed per run)
-    uint32_t *huf_list, *seq_list;  // seq_list: three lists of item_cap entries
+    uint32_t *ctr;  // [0] slots, [1] items, [2] Huffman list, [3] [5] [6] [7] sequence lists (64 / 32 / 16 / 1 blocks per wave), [4] execute cursor, [8] cursor of the wave-per-block list (zeroed per run)
+    uint32_t *huf_list, *seq_list;  // seq_list: four lists of item_cap entries (64 / 32 / 16 blocks per wave, wave per block)
     uint8_t *lit_pool; uint64_t lit_cap;
     unsigned long long *seq_pool; uint64_t seq_cap;
     uint16_t *fse_pool; uint64_t fse_cap;   // cells
@@ -245,7 +246,7 @@ struct BxArgs {
     uint32_t *pending2, *pending2_count;  // what is left for the serial decoder
     unsigned long long *dbg;
 };
-void launch_bx_stage(const BxArgs &a, int cus, int stage, hipStream_t s);  // 0 scan, 1 prep, 2 huf, 3 fse, 4 exec, 5 finish
+void launch_bx_stage(const BxArgs &a, int cus, int stage, hipStream_t s);  // 0 scan, 1 prep, 2 huf, 3 fse (lane = block), 4 exec, 5 finish, 6 fse (wave = block)
 void bx_predefined_tables(uint16_t cells[160]);  // host: the three predefined tables as pool cells
 
 }  // namespace zn

@@ -174,6 +174,137 @@ __device__ int fz_seq_tables(FzShared &S, FzTmp &T, const uint8_t *q, uint32_t n
 }
 
 
+// The sequences bitstream of ONE block by ONE wave -> records (k_fz_entropy, and the batch path's blocks of many sequences).
+// tl2 / to2 / tm2: the block's decoding tables in LDS as {next:16 | nbits:8 << 16 | extra bits:8 << 24, base value}; sl / so /
+// sm: the initial states, left: unread bits.  Repeat offsets are resolved against a symbolic incoming history (FZ_SYM).
+__device__ __forceinline__ int fz_wave_sequences(const uint2 *const tl2, const uint2 *const to2, const uint2 *const tm2, const uint8_t *const bbase,
+                                                 const uint8_t *const blob_end, int32_t left, uint32_t sl, uint32_t so, uint32_t sm, const uint32_t nseq,
+                                                 unsigned long long *const recs, const uint32_t lane, uint32_t *sum_ll_out, uint32_t *sum_ml_out,
+                                                 uint32_t rep_out[3], uint32_t *why) {
+    uint64_t wq = 0;
+    int32_t wbits = INT32_MAX;  // bit position of the end of the window's first 8 bytes (none loaded yet)
+    uint32_t sum_ll = 0, sum_ml = 0;
+    uint32_t r0 = FZ_SYM, r1 = FZ_SYM | (1u << 26), r2 = FZ_SYM | (2u << 26);
+    int err = 0;
+    for (uint32_t g0 = 0; g0 < nseq && !err; g0 += 64) {
+        const uint32_t cnt = nseq - g0 < 64 ? nseq - g0 : 64;
+        uint32_t my_so = 0, my_sm = 0, my_sl = 0, my_leftu = 0, max_ofb = 0;
+        int32_t margin = 0;
+        // ---- A ----
+        // (the block's last sequence takes no state bits: it is handled behind the loop, which so has no such case;
+        // verdicts are a running min / max, not branches: one way out of the loop keeps its state in place — with
+        // early exits the compiler copied every loop-carried register twice per trip — and a stream that has gone
+        // wrong only moves `left` below zero and reads zero bytes in front of the stream)
+        const bool has_last = g0 + cnt == nseq;
+        const uint32_t cnt_a = has_last ? cnt - 1 : cnt;
+        for (uint32_t g = 0; g < cnt_a; g++) {
+            const uint32_t vo_ = to2[so].x, vm_ = tm2[sm].x, vl_ = tl2[sl].x;  // three LDS reads in flight together ...
+            const uint32_t eox = uni(vo_), emx = uni(vm_), elx = uni(vl_);    // ... before the first is waited for (next:16 | nbits:8 | addbits:8)
+            const uint32_t ofb = eox >> 24, need_v = ofb + (emx >> 24) + (elx >> 24);
+            const uint32_t nbl = (elx >> 16) & 0xFF, nbm = (emx >> 16) & 0xFF, nbo = (eox >> 16) & 0xFF, need_s = nbl + nbm + nbo;
+            max_ofb = max(max_ofb, ofb);
+            margin = min(margin, left - (int32_t)(need_v + need_s));  // below zero: the stream ends before a sequence does
+            wrlane4_u(my_so, my_sm, my_sl, my_leftu, so, sm, sl, (uint32_t)left, g);
+            // the 64 stream bits that end where the state bits end, straight out of the window: `off` is their first
+            // bit counted from the window's
+            const int32_t pos0 = left - (int32_t)need_v, pos = pos0 < 0 ? 0 : pos0;
+            int32_t off = pos - wbits;
+            if (off < 0) {
+                const int32_t nb0 = ((((pos + 7) >> 3) - 504) & ~7), wbase = nb0 < -8 ? -8 : nb0;  // bytes in front of the stream read as zero
+                const int32_t o8 = wbase + 8 * (int32_t)lane;
+                wq = o8 < 0 ? 0ull : load8_guard(bbase + o8, blob_end);
+                wbits = 8 * wbase + 64;
+                off = pos - wbits;
+            }
+            const uint32_t j = uni((uint32_t)off >> 6), r = uni((uint32_t)off & 63);
+            const uint64_t q0 = rdlane64_u(wq, j), q1 = rdlane64_u(wq, j + 1);
+            const uint64_t v64 = (q0 >> r) | ((q1 << 1) << (63 - r));
+            const uint32_t xs = (uint32_t)((v64 >> 1) >> (63 - need_s));  // its top need_s (<= 27) bits
+            sl = (elx & 0xFFFF) + (xs >> (nbm + nbo));
+            sm = (emx & 0xFFFF) + ((xs >> nbo) & ((1u << nbm) - 1u));
+            so = (eox & 0xFFFF) + (xs & ((1u << nbo) - 1u));
+            left -= (int32_t)(need_v + need_s);
+        }
+        if (has_last) {
+            const uint32_t vo_ = to2[so].x, vm_ = tm2[sm].x, vl_ = tl2[sl].x;
+            const uint32_t eox = uni(vo_), emx = uni(vm_), elx = uni(vl_);
+            const uint32_t ofb = eox >> 24, need_v = ofb + (emx >> 24) + (elx >> 24);
+            max_ofb = max(max_ofb, ofb);
+            margin = min(margin, left - (int32_t)need_v);
+            wrlane4_u(my_so, my_sm, my_sl, my_leftu, so, sm, sl, (uint32_t)left, cnt - 1);
+            left -= (int32_t)need_v;
+        }
+        if (margin < 0) { err = E_CORRUPT; break; }
+        if (max_ofb > 27) { err = E_UNSUP; *why = 3; break; }
+        // ---- B ----
+        const bool on = lane < cnt;
+        uint32_t ov = 4, ml = 0, ll = 0;
+        if (on) {
+            const uint2 eo = to2[my_so], em = tm2[my_sm], el = tl2[my_sl];
+            const uint32_t ofb = eo.x >> 24, mlb = em.x >> 24, llb = el.x >> 24, need_v = ofb + mlb + llb;
+            const int32_t my_left = (int32_t)my_leftu, bend = (my_left + 7) >> 3;
+            uint64_t lo8 = 0, hi8 = 0;  // stream bytes [bend - 16, bend - 8) and [bend - 8, bend); zero in front of the stream
+            if (bend >= 16) {
+                __builtin_memcpy(&lo8, bbase + bend - 16, 8);
+                __builtin_memcpy(&hi8, bbase + bend - 8, 8);
+            } else {
+                for (int32_t k = 0; k < 16; k++) {
+                    const int32_t o = bend - 16 + k;
+                    const uint64_t byte = o >= 0 ? bbase[o] : 0;
+                    if (k < 8) lo8 |= byte << (8 * k); else hi8 |= byte << (8 * (k - 8));
+                }
+            }
+            const uint32_t al = (uint32_t)(8 * bend - my_left);
+            const uint64_t H = (hi8 << al) | ((lo8 >> 1) >> (63 - al));  // the lane's position is bit 64 now
+            const uint64_t xv = (H >> 1) >> (63 - need_v);                 // the top need_v (<= 59) bits
+            ov = eo.y + (uint32_t)(xv >> (mlb + llb));
+            ml = em.y + ((uint32_t)(xv >> llb) & ((1u << mlb) - 1u));
+            ll = el.y + ((uint32_t)xv & ((1u << llb) - 1u));
+        }
+        {
+            uint32_t a_ll = ll, a_ml = ml;
+#pragma unroll
+            for (int dd = 32; dd >= 1; dd >>= 1) { a_ll += __shfl_xor(a_ll, dd); a_ml += __shfl_xor(a_ml, dd); }
+            sum_ll += a_ll; sum_ml += a_ml;
+        }
+        if (sum_ll + sum_ml > BLOCK_MAX) { err = E_UNSUP; *why = 3; break; }
+        // repeat offsets (RFC 8878 3.1.1.5), against the symbolic incoming history
+        uint32_t o_mine = ov - 3;
+        if (__ballot(on && ov <= 3) == 0ull && cnt >= 3) {
+            r0 = rdlane_u(o_mine, cnt - 1); r1 = rdlane_u(o_mine, cnt - 2); r2 = rdlane_u(o_mine, cnt - 3);
+        } else {
+            for (uint32_t j = 0; j < cnt; j++) {
+                const uint32_t ovj = rdlane_u(ov, j), llj = rdlane_u(ll, j);
+                uint32_t o;
+                if (ovj > 3) { o = ovj - 3; r2 = r1; r1 = r0; r0 = o; }
+                else {
+                    const uint32_t idx = ovj - 1 + (llj == 0 ? 1u : 0u);
+                    if (idx == 0) o = r0;
+                    else {
+                        if (idx < 3) o = idx == 1 ? r1 : r2;
+                        else if (r0 & FZ_SYM) {  // incoming entry minus one more
+                            o = r0 + 1;
+                            if ((o & 0x3FFFFFFu) == 0x3FFFFFFu) { err = E_UNSUP; *why = 3; break; }
+                        } else {
+                            o = r0 - 1;
+                            if (o == 0) { err = E_CORRUPT; break; }
+                        }
+                        if (idx > 1) r2 = r1;
+                        r1 = r0; r0 = o;
+                    }
+                }
+                if (lane == j) o_mine = o;
+            }
+            if (err) break;
+        }
+        if (on) recs[g0 + lane] = (unsigned long long)ll | ((unsigned long long)ml << 17) | ((unsigned long long)o_mine << 35);
+    }
+    if (!err && left != 0) err = E_CORRUPT;
+    *sum_ll_out = sum_ll; *sum_ml_out = sum_ml;
+    rep_out[0] = r0; rep_out[1] = r1; rep_out[2] = r2;
+    return err;
+}
+
 // (held to 128 VGPRs — 165 unbounded, same speed alone: the kernel has to fit into the quarter of the register file the
 // general decoder leaves it, api.hip gen_share)
 __global__ __launch_bounds__(128, 4) void k_fz_entropy(FzArgs a, const uint32_t *work, const uint32_t *work_count) {
@@ -374,129 +505,12 @@ __global__ __launch_bounds__(128, 4) void k_fz_entropy(FzArgs a, const uint32_t 
                     //   B  the rest, 64 sequences at a time with lane = sequence: table entries again, 16 bytes of the stream
                     //      ending at the lane's position, the three values, the sums; then the repeat-offset rules in order
                     //      (scalar, only for groups that use a repeat code) and one coalesced store of the records.
-                    uint64_t wq = 0;
-                    int32_t wbits = INT32_MAX;  // bit position of the end of the window's first 8 bytes (none loaded yet)
-                    uint32_t sl = uni(S.st_ll), so = uni(S.st_of), sm = uni(S.st_ml);
-                    const uint2 *const tl2 = reinterpret_cast<const uint2 *>(tl), *const to2 = reinterpret_cast<const uint2 *>(to),
-                                *const tm2 = reinterpret_cast<const uint2 *>(tm);
-                    unsigned long long *const recs = a.seq_pool + uni64(S.seq_off);
-                    uint32_t sum_ll = 0, sum_ml = 0;
-                    uint32_t r0 = FZ_SYM, r1 = FZ_SYM | (1u << 26), r2 = FZ_SYM | (2u << 26);
-                    int err = 0;
-                    for (uint32_t g0 = 0; g0 < nseq && !err; g0 += 64) {
-                        const uint32_t cnt = nseq - g0 < 64 ? nseq - g0 : 64;
-                        uint32_t my_so = 0, my_sm = 0, my_sl = 0, my_leftu = 0, max_ofb = 0;
-                        int32_t margin = 0;
-                        // ---- A ----
-                        // (the block's last sequence takes no state bits: it is handled behind the loop, which so has no such case;
-                        // verdicts are a running min / max, not branches: one way out of the loop keeps its state in place — with
-                        // early exits the compiler copied every loop-carried register twice per trip — and a stream that has gone
-                        // wrong only moves `left` below zero and reads zero bytes in front of the stream)
-                        const bool has_last = g0 + cnt == nseq;
-                        const uint32_t cnt_a = has_last ? cnt - 1 : cnt;
-                        for (uint32_t g = 0; g < cnt_a; g++) {
-                            const uint32_t vo_ = to2[so].x, vm_ = tm2[sm].x, vl_ = tl2[sl].x;  // three LDS reads in flight together ...
-                            const uint32_t eox = uni(vo_), emx = uni(vm_), elx = uni(vl_);    // ... before the first is waited for (next:16 | nbits:8 | addbits:8)
-                            const uint32_t ofb = eox >> 24, need_v = ofb + (emx >> 24) + (elx >> 24);
-                            const uint32_t nbl = (elx >> 16) & 0xFF, nbm = (emx >> 16) & 0xFF, nbo = (eox >> 16) & 0xFF, need_s = nbl + nbm + nbo;
-                            max_ofb = max(max_ofb, ofb);
-                            margin = min(margin, left - (int32_t)(need_v + need_s));  // below zero: the stream ends before a sequence does
-                            wrlane4_u(my_so, my_sm, my_sl, my_leftu, so, sm, sl, (uint32_t)left, g);
-                            // the 64 stream bits that end where the state bits end, straight out of the window: `off` is their first
-                            // bit counted from the window's
-                            const int32_t pos0 = left - (int32_t)need_v, pos = pos0 < 0 ? 0 : pos0;
-                            int32_t off = pos - wbits;
-                            if (off < 0) {
-                                const int32_t nb0 = ((((pos + 7) >> 3) - 504) & ~7), wbase = nb0 < -8 ? -8 : nb0;  // bytes in front of the stream read as zero
-                                const int32_t o8 = wbase + 8 * (int32_t)lane;
-                                wq = o8 < 0 ? 0ull : load8_guard(bbase + o8, blob_end);
-                                wbits = 8 * wbase + 64;
-                                off = pos - wbits;
-                            }
-                            const uint32_t j = uni((uint32_t)off >> 6), r = uni((uint32_t)off & 63);
-                            const uint64_t q0 = rdlane64_u(wq, j), q1 = rdlane64_u(wq, j + 1);
-                            const uint64_t v64 = (q0 >> r) | ((q1 << 1) << (63 - r));
-                            const uint32_t xs = (uint32_t)((v64 >> 1) >> (63 - need_s));  // its top need_s (<= 27) bits
-                            sl = (elx & 0xFFFF) + (xs >> (nbm + nbo));
-                            sm = (emx & 0xFFFF) + ((xs >> nbo) & ((1u << nbm) - 1u));
-                            so = (eox & 0xFFFF) + (xs & ((1u << nbo) - 1u));
-                            left -= (int32_t)(need_v + need_s);
-                        }
-                        if (has_last) {
-                            const uint32_t vo_ = to2[so].x, vm_ = tm2[sm].x, vl_ = tl2[sl].x;
-                            const uint32_t eox = uni(vo_), emx = uni(vm_), elx = uni(vl_);
-                            const uint32_t ofb = eox >> 24, need_v = ofb + (emx >> 24) + (elx >> 24);
-                            max_ofb = max(max_ofb, ofb);
-                            margin = min(margin, left - (int32_t)need_v);
-                            wrlane4_u(my_so, my_sm, my_sl, my_leftu, so, sm, sl, (uint32_t)left, cnt - 1);
-                            left -= (int32_t)need_v;
-                        }
-                        if (margin < 0) { err = E_CORRUPT; break; }
-                        if (max_ofb > 27) { err = E_UNSUP; if (lane == 0) S.why = 3; break; }
-                        // ---- B ----
-                        const bool on = lane < cnt;
-                        uint32_t ov = 4, ml = 0, ll = 0;
-                        if (on) {
-                            const uint2 eo = to2[my_so], em = tm2[my_sm], el = tl2[my_sl];
-                            const uint32_t ofb = eo.x >> 24, mlb = em.x >> 24, llb = el.x >> 24, need_v = ofb + mlb + llb;
-                            const int32_t my_left = (int32_t)my_leftu, bend = (my_left + 7) >> 3;
-                            uint64_t lo8 = 0, hi8 = 0;  // stream bytes [bend - 16, bend - 8) and [bend - 8, bend); zero in front of the stream
-                            if (bend >= 16) {
-                                __builtin_memcpy(&lo8, bbase + bend - 16, 8);
-                                __builtin_memcpy(&hi8, bbase + bend - 8, 8);
-                            } else {
-                                for (int32_t k = 0; k < 16; k++) {
-                                    const int32_t o = bend - 16 + k;
-                                    const uint64_t byte = o >= 0 ? bbase[o] : 0;
-                                    if (k < 8) lo8 |= byte << (8 * k); else hi8 |= byte << (8 * (k - 8));
-                                }
-                            }
-                            const uint32_t al = (uint32_t)(8 * bend - my_left);
-                            const uint64_t H = (hi8 << al) | ((lo8 >> 1) >> (63 - al));  // the lane's position is bit 64 now
-                            const uint64_t xv = (H >> 1) >> (63 - need_v);                 // the top need_v (<= 59) bits
-                            ov = eo.y + (uint32_t)(xv >> (mlb + llb));
-                            ml = em.y + ((uint32_t)(xv >> llb) & ((1u << mlb) - 1u));
-                            ll = el.y + ((uint32_t)xv & ((1u << llb) - 1u));
-                        }
-                        {
-                            uint32_t a_ll = ll, a_ml = ml;
-#pragma unroll
-                            for (int dd = 32; dd >= 1; dd >>= 1) { a_ll += __shfl_xor(a_ll, dd); a_ml += __shfl_xor(a_ml, dd); }
-                            sum_ll += a_ll; sum_ml += a_ml;
-                        }
-                        if (sum_ll + sum_ml > BLOCK_MAX) { err = E_UNSUP; if (lane == 0) S.why = 3; break; }
-                        // repeat offsets (RFC 8878 3.1.1.5), against the symbolic incoming history
-                        uint32_t o_mine = ov - 3;
-                        if (__ballot(on && ov <= 3) == 0ull && cnt >= 3) {
-                            r0 = rdlane_u(o_mine, cnt - 1); r1 = rdlane_u(o_mine, cnt - 2); r2 = rdlane_u(o_mine, cnt - 3);
-                        } else {
-                            for (uint32_t j = 0; j < cnt; j++) {
-                                const uint32_t ovj = rdlane_u(ov, j), llj = rdlane_u(ll, j);
-                                uint32_t o;
-                                if (ovj > 3) { o = ovj - 3; r2 = r1; r1 = r0; r0 = o; }
-                                else {
-                                    const uint32_t idx = ovj - 1 + (llj == 0 ? 1u : 0u);
-                                    if (idx == 0) o = r0;
-                                    else {
-                                        if (idx < 3) o = idx == 1 ? r1 : r2;
-                                        else if (r0 & FZ_SYM) {  // incoming entry minus one more
-                                            o = r0 + 1;
-                                            if ((o & 0x3FFFFFFu) == 0x3FFFFFFu) { err = E_UNSUP; if (lane == 0) S.why = 3; break; }
-                                        } else {
-                                            o = r0 - 1;
-                                            if (o == 0) { err = E_CORRUPT; break; }
-                                        }
-                                        if (idx > 1) r2 = r1;
-                                        r1 = r0; r0 = o;
-                                    }
-                                }
-                                if (lane == j) o_mine = o;
-                            }
-                            if (err) break;
-                        }
-                        if (on) recs[g0 + lane] = (unsigned long long)ll | ((unsigned long long)ml << 17) | ((unsigned long long)o_mine << 35);
-                    }
-                    if (!err && left != 0) err = E_CORRUPT;
+                    uint32_t sum_ll = 0, sum_ml = 0, rr[3] = {0, 0, 0}, why3 = 0;
+                    const int err = fz_wave_sequences(reinterpret_cast<const uint2 *>(tl), reinterpret_cast<const uint2 *>(to), reinterpret_cast<const uint2 *>(tm),
+                                                      bbase, blob_end, left, uni(S.st_ll), uni(S.st_of), uni(S.st_ml), nseq, a.seq_pool + uni64(S.seq_off), lane,
+                                                      &sum_ll, &sum_ml, rr, &why3);
+                    if (why3 && lane == 0) S.why = why3;
+                    const uint32_t r0 = rr[0], r1 = rr[1], r2 = rr[2];
                     ESTAMPZ(24);
                     if (lane == 0) {
                         S.sum_ll = sum_ll; S.sum_ml = sum_ml;
@@ -1296,6 +1310,7 @@ __global__ __launch_bounds__(64) void k_bx_prep(BxArgs a) {
                 uint32_t cells = 0;
                 for (int q = 0; q < 3; q++) { const uint32_t c = 1u << ((pr.logs >> (8 * q)) & 255); cells += c < 8 ? 8u : c; }
                 cls = cells <= 384 ? 0u : (cells <= 768 ? 1u : 2u);
+                if (it.nseq >= BX_BIG_SEQ) cls = 3;  // a long chain: a wave of its own (k_bx_fse_wave)
             }
         }
         {   // the block joins the lists of the two entropy kernels
@@ -1305,7 +1320,7 @@ __global__ __launch_bounds__(64) void k_bx_prep(BxArgs a) {
             if (lane == 0 && hm) hb = atomicAdd(&a.ctr[2], (uint32_t)__popcll(hm));
             hb = rdlane_u(hb, 0);
             if (huf) a.huf_list[hb + (uint32_t)__popcll(hm & below)] = slot;
-            for (uint32_t q = 0; q < 3; q++) {
+            for (uint32_t q = 0; q < 4; q++) {
                 const bool mine = seq && cls == q;
                 const uint64_t sm = __ballot(mine);
                 uint32_t sb = 0;
@@ -1399,6 +1414,62 @@ __device__ __forceinline__ uint32_t bx_ext(uint64_t lo, uint64_t hi, uint32_t s,
 __device__ __forceinline__ uint64_t bx_ext64(uint64_t lo, uint64_t hi, uint32_t s, uint32_t n) {  // n <= 63
     const uint64_t v = s >= 64 ? hi >> (s & 63) : (lo >> s) | ((hi << 1) << (63 - s));
     return v & ((1ull << n) - 1ull);
+}
+
+// wave = block, for the blocks of BX_BIG_SEQ sequences or more: a lane of k_bx_fse takes ~2,000 cycles per sequence (its
+// ~350 instructions on a SIMD of its own), the two-stage wave decoder (fz_wave_sequences) ~700 — and with few blocks in the
+// table, the longest chain is the kernel's time.
+__global__ __launch_bounds__(64) void k_bx_fse_wave(BxArgs a, const uint32_t *list, const uint32_t *n_list_p) {
+    __shared__ uint2 TL[512], TM[512], TO[256];
+    const uint32_t lane = threadIdx.x;
+    const uint32_t n_list = *n_list_p;
+    for (;;) {
+        uint32_t idx = 0;
+        if (lane == 0) idx = atomicAdd(&a.ctr[8], 1u);
+        idx = rdlane_u(idx, 0);
+        if (idx >= n_list) break;
+        const uint32_t slot = list[idx];
+        const BxPrep pr = a.prep[slot];
+        const FzItem it = a.items[slot];
+        const uint32_t row = a.cand_row[pr.frame];
+        const uint8_t *const src = a.blobs + (a.blob_off[row] - a.blob_base);
+        const uint8_t *const blob_end = src + a.blob_size[row];
+        __builtin_amdgcn_wave_barrier();
+        for (int k = 0; k < 3; k++) {  // pool cells -> the wave decoder's entries
+            const uint32_t log = (pr.logs >> (8 * k)) & 255, size = 1u << log;
+            const uint16_t *const cells = a.fse_pool + pr.tab[k];
+            uint2 *const t = k == 0 ? TL : (k == 1 ? TO : TM);
+            for (uint32_t u = lane; u < size; u += 64) {
+                const uint32_t c = cells[u], sym = c & 63u, ns = c >> 6;
+                const uint32_t nb = log - (uint32_t)hibit(ns | 1u);
+                uint32_t ab, base;
+                if (k == 0) { ab = c_ll_bits[sym > 35 ? 35 : sym]; base = c_ll_base[sym > 35 ? 35 : sym]; }
+                else if (k == 2) { ab = c_ml_bits[sym > 52 ? 52 : sym]; base = c_ml_base[sym > 52 ? 52 : sym]; }
+                else { ab = sym; base = 1u << (sym & 31); }
+                t[u] = make_uint2((((ns << nb) - size) & 0xFFFFu) | (nb << 16) | (ab << 24), base);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        const uint8_t *const bb = src + pr.bs_off;
+        BitR b;
+        int err = 0;
+        uint32_t sl = 0, so = 0, sm = 0;
+        if (!b.init(bb, pr.bs_len, blob_end)) err = E_CORRUPT;
+        else {
+            sl = b.read(pr.logs & 255); so = b.read((pr.logs >> 8) & 255); sm = b.read((pr.logs >> 16) & 255);
+            if (b.pos < 0) err = E_CORRUPT;
+        }
+        uint32_t sum_ll = 0, sum_ml = 0, rr[3] = {FZ_SYM, FZ_SYM | (1u << 26), FZ_SYM | (2u << 26)}, why = 0;
+        if (!err) err = fz_wave_sequences(TL, TO, TM, bb, blob_end, (int32_t)uni((uint32_t)b.pos), uni(sl), uni(so), uni(sm), uni(it.nseq),
+                                          a.seq_pool + uni64(it.seq_off), lane, &sum_ll, &sum_ml, rr, &why);
+        if (!err && sum_ll > it.lit_len) err = E_CORRUPT;
+        if (!err && it.lit_len + sum_ml > BLOCK_MAX) err = E_CORRUPT;
+        if (lane == 0) {
+            a.items[slot].out = it.lit_len + sum_ml;
+            a.items[slot].rep[0] = rr[0]; a.items[slot].rep[1] = rr[1]; a.items[slot].rep[2] = rr[2];
+            if (err) { a.items[slot].err = err; atomicAdd(&a.pool_used[3], 1ull); atomicAdd(&a.pool_used[4 + 3], 1ull); }
+        }
+    }
 }
 
 // lane = block: the FSE sequence bitstream -> records.  LANES blocks per wave, by the size of their three tables (the
@@ -1607,12 +1678,13 @@ __global__ __launch_bounds__(64) void k_bx_exec(BxArgs a) {
     const uint32_t n_slots = a.ctr[0];
     const FzArgs z = bx_as_fz(a);
     uint32_t n_done = 0;
-    for (;;) {  // four slots per atomic: one cursor word takes ~88 additions per microsecond
+    const uint32_t chunk = n_slots >= 32768 ? 4u : 1u;  // big tables: four slots per atomic (one cursor word takes ~88 additions per microsecond)
+    for (;;) {
         uint32_t c0 = 0;
-        if (lane == 0) c0 = atomicAdd(&a.ctr[4], 4u);
+        if (lane == 0) c0 = atomicAdd(&a.ctr[4], chunk);
         c0 = rdlane_u(c0, 0);
         if (c0 >= n_slots) break;
-        for (uint32_t c = c0; c < c0 + 4 && c < n_slots; c++) {
+        for (uint32_t c = c0; c < c0 + chunk && c < n_slots; c++) {
             if (fz_exec_frame<false>(z, c, W, lane)) n_done++;
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_wave_barrier();
@@ -1641,7 +1713,8 @@ __global__ __launch_bounds__(64) void k_bx_finish(BxArgs a) {
     }
 }
 
-// stage 0..5 = scan, prep, huf, fse, exec, finish (launched one by one so that each can be timed)
+// stage 0..5 = scan, prep, huf, fse (lane = block), exec, finish; 6 = fse (wave = block, the long chains: beside stages 2 and 3 on
+// another stream) — launched one by one so that each can be timed
 void launch_bx_stage(const BxArgs &a, int cus, int stage, hipStream_t s) {
     const uint32_t slots = a.slot_cap, lane_grid = std::max(std::min<uint32_t>((slots + 63) / 64, (uint32_t)cus * 8), 1u);
     if (!slots) return;
@@ -1655,6 +1728,7 @@ void launch_bx_stage(const BxArgs &a, int cus, int stage, hipStream_t s) {
         hipLaunchKernelGGL(k_bx_fse, cap((a.item_cap + 31) / 32, 3), dim3(64), 0, s, a, a.seq_list + a.item_cap, a.ctr + 5, 32u);
         hipLaunchKernelGGL(k_bx_fse, cap((a.item_cap + 15) / 16, 3), dim3(64), 0, s, a, a.seq_list + 2 * (size_t)a.item_cap, a.ctr + 6, 16u);
         break;
+    case 6: hipLaunchKernelGGL(k_bx_fse_wave, cap(a.item_cap, 12), dim3(64), 0, s, a, a.seq_list + 3 * (size_t)a.item_cap, a.ctr + 7); break;
     case 4: hipLaunchKernelGGL(k_bx_exec, cap(slots, 12), dim3(64), 0, s, a); break;
     default: hipLaunchKernelGGL(k_bx_finish, dim3(lane_grid), dim3(64), 0, s, a); break;
     }
