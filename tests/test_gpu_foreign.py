@@ -92,7 +92,7 @@ def test_real_text_frames_two_phase_only(gpu_ctx_fz_only, oracle, level):
     assert c["corrupt_rows"] == 0 and c["decode_errors"] == 0, (c, corrupt, status)
     assert c["verified_bytes"] == len(data)
     assert out.tobytes() == data
-    assert "zstd_foreign_entropy" in kt
+    assert "zstd_batch_sequences" in kt and "zstd_batch_execute" in kt
 
 
 @pytest.mark.parametrize("level", [1, 19])
@@ -139,24 +139,33 @@ def test_corrupt_foreign_frames_same_verdicts_as_serial(gpu_ctx, oracle):
 
 
 def test_two_phase_matches_serial_bytes(gpu_ctx, oracle):
-    """Same archive through a context with the two-phase path switched off (ZNIPPY_NO_FZ): identical bytes and counters."""
+    """Same archive through the batch path (lane = block), through the round-2 two-phase path (wave = block, ZNIPPY_NO_BX)
+    and through the serial decoder alone (ZNIPPY_NO_BX + ZNIPPY_NO_FZ): identical bytes and counters."""
     from znippy_amd import hip
     data = _py_corpus(3 << 20)
     entries = [data[:1_000_000], data[1_000_000:1_200_000], data[1_200_000:]]
     A = _archive(oracle, entries, 19)
     c1, _, s1, o1, kt1 = _run(gpu_ctx, A)
-    os.environ["ZNIPPY_NO_FZ"] = "1"
-    try:
-        ctx2 = hip.Context(0)
-    finally:
-        del os.environ["ZNIPPY_NO_FZ"]
-    try:
-        c2, _, s2, o2, kt2 = _run(ctx2, A)
-    finally:
-        ctx2.close()
-    assert c1 == c2 and (s1 == s2).all() and (o1 == o2).all()
+
+    def other(env):
+        for k in env:
+            os.environ[k] = "1"
+        try:
+            ctx2 = hip.Context(0)
+        finally:
+            for k in env:
+                del os.environ[k]
+        try:
+            return _run(ctx2, A)
+        finally:
+            ctx2.close()
+    c2, _, s2, o2, kt2 = other(["ZNIPPY_NO_BX"])
+    c3, _, s3, o3, kt3 = other(["ZNIPPY_NO_BX", "ZNIPPY_NO_FZ"])
+    assert c1 == c2 == c3 and (s1 == s2).all() and (s1 == s3).all() and (o1 == o2).all() and (o1 == o3).all()
     assert o1.tobytes() == data
-    assert "zstd_foreign_entropy" in kt1 and "zstd_foreign_entropy" not in kt2
+    assert "zstd_batch_execute" in kt1 and "zstd_foreign_entropy" not in kt1
+    assert "zstd_foreign_entropy" in kt2 and "zstd_batch_execute" not in kt2
+    assert "zstd_foreign_entropy" not in kt3 and "zstd_batch_execute" not in kt3
 
 
 def test_mutated_real_text_frames_agree_with_oracle(gpu_ctx, oracle):

@@ -93,6 +93,7 @@ struct znippy_ctx {
         // ZNIPPY_ROLES_MIN: small tiles from which the role-split persistent kernel takes the table (0 = never; below
         // a few CU-fillings a persistent grid only adds start-up latency)
         unsigned roles_min = 2048;
+        unsigned bx_big = BX_BIG_SEQ;  // ZNIPPY_BX_BIG
         int ktime = 2;  // per-kernel HIP events: 2 = every kernel, 1 = the dominant read kernels only, 0 = none
     } sw;
     int cus = 256;
@@ -111,7 +112,8 @@ static void read_switches(znippy_ctx *ctx) {
     ctx->sw.nohash = on("ZNIPPY_NOHASH");
     ctx->sw.no_roles = on("ZNIPPY_NO_ROLES");
     ctx->sw.no_fz = on("ZNIPPY_NO_FZ");
-    ctx->sw.no_bx = on("ZNIPPY_NO_BX");  // A/B: foreign frames through the round-2 paths (serial decoder + wave-per-block two-phase path)
+    ctx->sw.no_bx = on("ZNIPPY_NO_BX");
+    if (const char *e = getenv("ZNIPPY_BX_BIG")) ctx->sw.bx_big = (unsigned)atoi(e);  // A/B: foreign frames through the round-2 paths (serial decoder + wave-per-block two-phase path)
     if (const char *lv = getenv("ZNIPPY_LEVEL")) { const int v = atoi(lv); if (v >= 1 && v <= 22) ctx->level = v; }  // initial level of every context (tests, A/B runs)
     if (const char *gs = getenv("ZNIPPY_GEN_SHARE")) { const int v = atoi(gs); if (v >= 1 && v <= 4) ctx->gen_share = v; }  // A/B
     ctx->sw.fz_only = on("ZNIPPY_FZ_ONLY");  // test hook: no serial fallback behind the two-phase path (what it leaves shows up as corrupt rows)
@@ -1137,6 +1139,7 @@ int znippy_decode_verify_rows_async(znippy_ctx *ctx, znippy_rows *r, const void 
             x.fse_pool = ctx->bx_fse_pool; x.fse_cap = ctx->bx_fse_cap; x.huf_pool = ctx->bx_huf_pool; x.huf_cap = ctx->bx_huf_cap;
             x.pool_used = reinterpret_cast<unsigned long long *>(r->ctl + 256);
             x.pending2 = r->pending2; x.pending2_count = r->pending_count + 1;
+            x.big_seq = ctx->sw.bx_big;
             if (ctx->sw.ddbg) {  // diagnostic: where the previous run's table kernel spent its waves' time
                 static unsigned long long *dbg = nullptr;
                 if (!dbg) { (void)hipMalloc(&dbg, 512); (void)hipMemset(dbg, 0, 512); }

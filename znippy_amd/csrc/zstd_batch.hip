@@ -1310,7 +1310,9 @@ __global__ __launch_bounds__(64) void k_bx_prep(BxArgs a) {
                 uint32_t cells = 0;
                 for (int q = 0; q < 3; q++) { const uint32_t c = 1u << ((pr.logs >> (8 * q)) & 255); cells += c < 8 ? 8u : c; }
                 cls = cells <= 384 ? 0u : (cells <= 768 ? 1u : 2u);
-                if (it.nseq >= BX_BIG_SEQ) cls = 3;  // a long chain: a wave of its own (k_bx_fse_wave)
+                // a long chain gets a wave of its own (k_bx_fse_wave); so does a stream that starts within 64 bytes of the blob
+                // region's first byte (the lane kernel's buffer loads reach 64 bytes in front of the stream, the wave decoder's do not)
+                if (it.nseq >= a.big_seq || (a.blob_off[a.cand_row[pr.frame]] - a.blob_base) + pr.bs_off < 64) cls = 3;
             }
         }
         {   // the block joins the lists of the two entropy kernels
@@ -1546,7 +1548,7 @@ __global__ __launch_bounds__(64) void k_bx_fse(BxArgs a, const uint32_t *list, c
             left = (int32_t)(pr.bs_len * 8) - (8 - hibit(last));
             const uint32_t need = log_l + log_o + log_m;
             if (left < (int32_t)need) err = E_CORRUPT;
-            else if (foff + pr.bs_off < 64) err = E_UNSUP;  // the blob region starts less than 64 bytes in front of the stream (its first frame, if tiny): the serial decoder's
+            else if (foff + pr.bs_off < 64) err = E_UNSUP;  // (k_bx_prep sends such a block to k_bx_fse_wave: never taken)
             else {
                 const int32_t bend = (left + 7) >> 3;
                 fetch(bend); commit();
