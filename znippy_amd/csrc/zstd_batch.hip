@@ -558,7 +558,7 @@ __device__ __forceinline__ bool fz_exec_frame(const FzArgs &a, const uint32_t c,
         // A frame of a few very long sequences (periodic or constant data: one 128 KiB match per block) is copy work, not
         // sequence work: the serial decoder's 1,024-thread variant moves it three times faster than one wave can
         // (16 x 8 MiB of periodic text: 0.72 ms against 2.2 ms here) — left to it.
-        if (seqs * 2048 < fcs) return false;
+        if (fcs >= (1u << 20) && seqs * 2048 < fcs) return false;  // (a smaller frame is not worth a second launch's latency)
     }
     uint64_t opos = 0;  // output bytes already streamed to HBM
     uint32_t win_n = 0, hist_n = 0, r0 = 1, r1 = 4, r2 = 8;
