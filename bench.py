@@ -60,6 +60,7 @@ def main():
     ap.add_argument("--archive", choices=("libzstd19", "own"), default=None,
                     help="frames of the headline read leg (default: libzstd19 for c2, own otherwise)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-text-leg", action="store_true", help="skip the read_text_archive leg (non-periodic text frames)")
     args = ap.parse_args()
 
     import torch
@@ -144,6 +145,50 @@ def main():
     out_off = (src_off[r0:r1] - src_off[r0]).astype(np.uint64)
     d_out = torch.zeros(my_bytes + 64, dtype=torch.uint8, device="cuda")
     d_src_mine = d_src[int(src_off[r0]):int(src_off[r0]) + my_bytes]
+
+    def cpu_read_loop(A, rows, out_offsets, lens_, nbytes):
+        """The oracle's read loop (libzstd decode + scalar C BLAKE3 per row, decompress.rs:L135-190) on the host cores: best of
+        three passes over the same rows (the first pass pays thread start-up and page faults of the output buffer)."""
+        cores = len(os.sched_getaffinity(0))
+        threads = max(1, int(np.ceil(0.9 * cores)))  # common_config.rs:L34 rule on what we can see
+        host_blobs = A["d_blobs"].cpu().numpy()
+        bitmap = np.packbits(A["comp"].astype(bool), bitorder="little")
+        host_out = np.zeros(nbytes, dtype=np.uint8)
+        best = None
+        for _ in range(3):
+            t0 = time.perf_counter()
+            st, _c = O.decompress_rows(host_blobs, A["bo"], A["bs"], lens_, out_offsets, bitmap, A["ck"], 0, rows,
+                                       out=host_out, n_threads=threads, use_libzstd=O.have_libzstd())
+            dt = time.perf_counter() - t0
+            assert st["verified_bytes"] == nbytes
+            best = dt if best is None else min(best, dt)
+        return dict(value=round(nbytes / 2**20 / best, 1), unit="MB/s", cores=threads, kind="port",
+                    sample=f"all {rows} rows of the same archive, best of 3 passes: oracle read loop (libzstd decode + scalar C "
+                           f"BLAKE3, not SIMD), {threads} threads of {cores} visible cores")
+
+    def text_archive(rows, chunk):
+        """BASELINE configs[1]'s shape with REAL text in place of the 45-byte phrase: `rows` chunks of `chunk` bytes cut from
+        source text found in the image (seeded word soup where the image has none), libzstd level-19 frames — Huffman
+        literals, described FSE tables, ~800 sequences per chunk: nothing the periodic-shape recogniser can take.
+        4,096 distinct chunks, tiled; every row owns its own copy of its frame in the blob region."""
+        from concurrent.futures import ThreadPoolExecutor
+        distinct = min(rows, 4096)
+        raw = b"".join(workloads.image_corpus("text", distinct * chunk + (1 << 20), whole_files=False))
+        if len(raw) < distinct * chunk:
+            raw += gen.pseudo_text(distinct * chunk - len(raw), seed=11)
+        sl = [raw[i * chunk:(i + 1) * chunk] for i in range(distinct)]
+        with ThreadPoolExecutor(min(16, os.cpu_count() or 1)) as ex:  # (libzstd releases the GIL inside ctypes calls)
+            fr = list(ex.map(lambda x: workloads.libzstd_compress(x, 19), sl))
+        idx = np.arange(rows) % distinct
+        fl = np.array([len(f) for f in fr], np.uint64)
+        bs_ = fl[idx]
+        bo_ = np.concatenate([[0], np.cumsum(bs_)[:-1]]).astype(np.uint64)
+        blob = np.frombuffer(b"".join(fr[i] for i in idx) + bytes(64), dtype=np.uint8)
+        dig = np.stack([np.frombuffer(O.blake3(x), dtype=np.uint8) for x in sl])
+        src_t = torch.from_numpy(np.frombuffer(b"".join(sl), dtype=np.uint8).copy()).cuda().view(distinct, chunk)
+        return dict(d_blobs=torch.from_numpy(blob.copy()).cuda(), bo=bo_, bs=bs_, comp=np.ones(rows, np.uint8), ck=dig[idx],
+                    label=f"libzstd level-19 frames of real text chunks ({distinct} distinct, mean {float(fl.mean()):.0f} B per {chunk} B chunk)",
+                    src=src_t, idx=torch.from_numpy(idx).cuda(), distinct=distinct)
 
     def make_rows(a):
         t0 = time.perf_counter()
@@ -257,6 +302,20 @@ def main():
         assert c["corrupt_rows"] == 0 and c["decode_errors"] == 0 and c["verified_bytes"] == my_bytes, (k, c)
         assert torch.equal(d_out[:my_bytes], d_src_mine), f"decoded bytes differ from the source ({k})"
     head = legs[archive_kind]
+    text = None
+    if args.workload in ("c2", "c2small") and not args.no_text_leg:
+        text = text_archive(my_rows, int(lens[0]))
+        archives["text"] = text
+        tleg = ReadLeg(text)
+        d_out.zero_()
+        tleg.step(); tleg.drain()
+        c = tleg.last
+        assert c["corrupt_rows"] == 0 and c["decode_errors"] == 0 and c["verified_bytes"] == my_bytes, ("text", c)
+        got = d_out[:my_bytes].view(my_rows, int(lens[0]))
+        for lo_ in range(0, my_rows, text["distinct"]):  # every row's bytes against its chunk
+            hi_ = min(lo_ + text["distinct"], my_rows)
+            assert torch.equal(got[lo_:hi_], text["src"][:hi_ - lo_]), "decoded text rows differ from the source"
+        legs["text"] = tleg
     # Order of the legs: the secondary read leg (own-encoder archive) first, the headline leg after it.  Each leg has
     # exactly W warmup + K timed steps; whichever runs first comes straight out of the CPU-bound set-up and measures
     # ~4 % slow with W = 3 (the two archives decode at the same speed when their runs are interleaved in one process,
@@ -266,6 +325,7 @@ def main():
     if dt_own is None:
         dt_own, k_own = dt_read, k_read
     dt_write, k_write = timed(WriteLeg(), args.steps, args.warmup)
+    dt_text, k_text = timed(legs["text"], args.steps, args.warmup) if text is not None else (None, None)
     for k, leg in legs.items():  # every step of every read leg (warmup, timed, kernel-time collection) verified every byte
         assert leg.bad_steps == 0, f"{leg.bad_steps} steps of the {k} read leg did not verify"
 
@@ -321,19 +381,23 @@ def main():
                 roofline["valu"] = dict(error=str(e))
         cpu = None
         if not args.no_cpu_baseline and world == 1:
-            cores = len(os.sched_getaffinity(0))
-            threads = max(1, int(np.ceil(0.9 * cores)))  # common_config.rs:L34 rule on what we can see
-            host_blobs = A["d_blobs"].cpu().numpy()
-            bitmap = np.packbits(A["comp"].astype(bool), bitorder="little")
-            host_out = np.zeros(my_bytes, dtype=np.uint8)
-            t0 = time.perf_counter()
-            st, _ = O.decompress_rows(host_blobs, A["bo"], A["bs"], my_lens, out_off, bitmap, A["ck"], 0, my_rows,
-                                      out=host_out, n_threads=threads, use_libzstd=O.have_libzstd())
-            dt_cpu = time.perf_counter() - t0
-            assert st["verified_bytes"] == my_bytes
-            cpu = dict(value=round(my_bytes / 2**20 / dt_cpu, 1), unit="MB/s", cores=threads, kind="port",
-                       sample=f"all {my_rows} rows of the same archive once: oracle read loop (libzstd decode + scalar C "
-                              f"BLAKE3), {threads} threads of {cores} visible cores")
+            cpu = cpu_read_loop(A, my_rows, out_off, my_lens, my_bytes)
+        text_leg = None
+        if text is not None:
+            t_blob = int(text["bs"].sum())
+            t_alg = t_blob + my_bytes + 57 * my_rows  # every blob byte read, every output byte written, the index columns
+            t_ms = dt_text / args.steps * 1e3
+            stage = {k: v for k, v in k_text.items() if k.startswith("zstd_batch_")}
+            t_dom = max(stage, key=stage.get) if stage else None
+            text_leg = {"archive": text["label"], "MBps": round(mbps(dt_text), 1), "GBps": round(total_bytes / (dt_text / args.steps) / 1e9, 2),
+                        "ms_per_step": round(t_ms, 4), "blob_bytes_per_gpu": t_blob,
+                        "kernel_ms": {k: round(v, 4) for k, v in k_text.items()},
+                        "roofline": dict(bound="hbm", kernel=t_dom, achieved=round(t_alg / (t_ms * 1e-3) / 1e9, 1), peak=HBM_PEAK_GBS, unit="GB/s",
+                                         frac=round(t_alg / (t_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), traffic=None,
+                                         note="the leg is a chain of six kernels (scan, tables, Huffman streams, sequences, execute, hash): "
+                                              "achieved = algorithmic bytes / step time; `kernel` = the longest of them; limiter: serial "
+                                              "entropy chains (lane = block), not memory"),
+                        "cpu_baseline": cpu_read_loop(text, my_rows, out_off, my_lens, my_bytes) if (not args.no_cpu_baseline and world == 1) else None}
         line = {
             "metric": "decompress MB/s (uncompressed) + compress MB/s, 100k x 10KB archive",
             "value": round(mbps(dt_read), 1), "unit": "MB/s", "n_gpus": world, "steps": args.steps,
@@ -355,6 +419,7 @@ def main():
             "table_build_ms": {"row_table": round(head.table_ms[1], 3), "round_table": round(round_table_warm_ms, 3),
                                "row_table_first": round(head.table_ms[0], 3), "round_table_first": round(round_table_ms, 3),
                                "note": "host plan + H2D of the index columns / Rounds, outside the timed steps; *_first = the context's first table (its memory pools are created)"},
+            "read_text_archive": text_leg,
             "roofline": roofline, "cpu_baseline": cpu,
         }
         print(json.dumps(line))

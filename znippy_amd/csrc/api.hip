@@ -306,8 +306,14 @@ struct znippy_rows {
     uint32_t *cursor = nullptr;
     // pinned mirror of the counters, filled by the run's own D2H copy.  Two slots + one event each: run k uses slot
     // k & 1, so the counters of run k can be read while run k + 1 is already executing (znippy_rows_results_lagged)
-    uint64_t *h_counters = nullptr;
+    uint64_t *h_counters = nullptr;  // per slot 16 x u64: the counters, then the 16 hand-over counts (u32)
     size_t h_counters_cap = 0;
+    // Does the batch path have anything to do?  Its six launches cost ~0.1 ms even when every list is empty (the BASELINE
+    // archives: every row is taken by the fused kernels), so a table remembers what its last finished run found: -1 not
+    // known yet (launch it), 0 nothing handed over (the serial decoder alone stands behind the fused kernels, as a
+    // safety net), 1 something was.
+    int bx_hint = -1;
+    uint64_t hint_seq = 0;  // runs whose mirror has been looked at
     hipEvent_t ev_done[2] = {nullptr, nullptr};
     uint64_t run_seq = 0;  // async runs queued so far
     // Host copies of the columns a run is validated against (one pass per distinct (blob_base, blob_cap, out_cap)):
@@ -730,7 +736,7 @@ int znippy_rows_create(znippy_ctx *ctx, const uint64_t *blob_offset, const uint6
     r->ctl_bytes = znippy_rows::CTL_HEAD + std::max<size_t>(4 * (size_t)n, 16);
     if (tmalloc(ctx, &r->ctl, r->ctl_bytes) != hipSuccess ||
         tmalloc(ctx, &r->digests, std::max<size_t>(32 * (size_t)n, 32)) != hipSuccess ||
-        !(r->h_counters = (uint64_t *)pinned_take(ctx, 128, &r->h_counters_cap)) ||
+        !(r->h_counters = (uint64_t *)pinned_take(ctx, 256, &r->h_counters_cap)) ||
         !(r->ev_done[0] = event_take(ctx)) || !(r->ev_done[1] = event_take(ctx)) ||
         tmalloc(ctx, &r->corrupt, 8 * (size_t)r->corrupt_cap) != hipSuccess) {
         znippy_rows_destroy(r);
@@ -913,6 +919,13 @@ static int rows_validate(znippy_ctx *ctx, znippy_rows *r, uint64_t blob_base, ui
     return ZNIPPY_OK;
 }
 
+// what a finished run's mirror says about the batch path's work: rows the fused kernel handed over ([0]) + block
+// candidates left flagged ([5]) + the host's own list of big single-block rows
+static void rows_note_hint(znippy_rows *r, unsigned slot) {
+    const uint32_t *pc = reinterpret_cast<const uint32_t *>(r->h_counters + 16 * slot + 8);
+    r->bx_hint = (pc[0] || pc[1] || pc[5] || r->n_list_a) ? 1 : 0;  // ([1]: what went to the serial decoder)
+}
+
 int znippy_decode_verify_rows_async(znippy_ctx *ctx, znippy_rows *r, const void *d_blobs,
                                     uint64_t blob_base, void *d_out, uint64_t out_cap) {
     if (!ctx || !r || r->ctx != ctx) return ZNIPPY_E_INVAL;
@@ -928,7 +941,12 @@ int znippy_decode_verify_rows_async(znippy_ctx *ctx, znippy_rows *r, const void 
         if (!rc0) rc0 = ensure_bx_pools(ctx, r->bx_bytes, r->bx_item_cap);
         if (rc0) return rc0;
     }
-    const bool bx = r->bx_slots && ctx->fz_lit_pool && ctx->fz_seq_pool && ctx->bx_fse_pool && ctx->bx_huf_pool;
+    if (r->run_seq && r->bx_hint < 0 && r->n) {  // a run of this table has finished meanwhile?
+        const unsigned slot = (unsigned)((r->run_seq - 1) & 1);
+        if (hipEventQuery(r->ev_done[slot]) == hipSuccess) rows_note_hint(r, slot);
+        else (void)hipGetLastError();
+    }
+    const bool bx = r->bx_slots && ctx->fz_lit_pool && ctx->fz_seq_pool && ctx->bx_fse_pool && ctx->bx_huf_pool && r->bx_hint != 0;
     const int preset = r->n_bad ? 1 : 0;
     // counters, hand-over counts, work cursors and the status column: one stream operation
     if (preset) HIPCHK(ctx, hipMemcpyAsync(r->ctl, r->status_init, r->ctl_bytes, hipMemcpyDeviceToDevice, s));
@@ -1216,7 +1234,7 @@ int znippy_decode_verify_rows_async(znippy_ctx *ctx, znippy_rows *r, const void 
     ktime_end(ctx);
     {
         const unsigned slot = (unsigned)(r->run_seq & 1);
-        HIPCHK(ctx, hipMemcpyAsync(r->h_counters + 8 * slot, r->counters, 64, hipMemcpyDeviceToHost, s));
+        HIPCHK(ctx, hipMemcpyAsync(r->h_counters + 16 * slot, r->counters, 128, hipMemcpyDeviceToHost, s));
         HIPCHK(ctx, hipEventRecord(r->ev_done[slot], s));
         r->run_seq++;
     }
@@ -1233,7 +1251,8 @@ int znippy_rows_results_lagged(znippy_ctx *ctx, znippy_rows *r, unsigned lag, zn
     if (r->n) {
         const unsigned slot = (unsigned)((r->run_seq - 1 - lag) & 1);
         HIPCHK(ctx, hipEventSynchronize(r->ev_done[slot]));
-        memcpy(c, r->h_counters + 8 * slot, 64);
+        memcpy(c, r->h_counters + 16 * slot, 64);
+        rows_note_hint(r, slot);
     }
     counters->total_chunks = c[0]; counters->total_written_bytes = c[1]; counters->verified_bytes = c[2];
     counters->corrupt_bytes = c[3]; counters->corrupt_rows = c[4]; counters->decode_errors = c[5];
@@ -1246,7 +1265,10 @@ int znippy_rows_results(znippy_ctx *ctx, znippy_rows *r, znippy_verify_counters 
     HIPCHK(ctx, hipSetDevice(ctx->device));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     uint64_t c[8] = {0};
-    if (r->n && r->run_seq) memcpy(c, r->h_counters + 8 * ((r->run_seq - 1) & 1), 64);  // copied by the run itself (pinned)
+    if (r->n && r->run_seq) {
+        memcpy(c, r->h_counters + 16 * ((r->run_seq - 1) & 1), 64);  // copied by the run itself (pinned)
+        rows_note_hint(r, (unsigned)((r->run_seq - 1) & 1));
+    }
     if (counters) {
         counters->total_chunks = c[0]; counters->total_written_bytes = c[1]; counters->verified_bytes = c[2];
         counters->corrupt_bytes = c[3]; counters->corrupt_rows = c[4]; counters->decode_errors = c[5];

@@ -869,7 +869,7 @@ __global__ __launch_bounds__(64) void k_finish_blocks(BlockScanArgs a, int defer
     const uint32_t row = a.cand_row[c];
     if (a.status[row] < 0) return;  // host verdict stands
     if (a.row_flag[row]) {
-        if (defer_flagged) return;  // the batch path rules on it (k_bx_finish)
+        if (defer_flagged) { atomicAdd(a.pending_count + 4, 1u); return; }  // the batch path rules on it (k_bx_finish); counted for the table's hint
         a.status[row] = 1;  // handed to the general decoder, like a row the fused kernel gave up on
         a.pending[atomicAdd(a.pending_count, 1u)] = row;
     } else a.status[row] = 2;
