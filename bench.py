@@ -87,8 +87,8 @@ def main():
     from znippy_amd import hip
     from znippy_amd.sharding import split_rows
 
-    wl = workloads.build(args.workload, torch)
-    d_src, lens, skip = wl["d_src"], wl["lens"], wl["skip"]
+    lay = workloads.layout(args.workload)
+    lens, skip = lay["lens"], lay["skip"]
     n = len(lens)
     total_in = int(lens.sum())
     src_off = np.concatenate([[0], np.cumsum(lens)[:-1]]).astype(np.uint64)
@@ -104,13 +104,19 @@ def main():
         r0, r1 = 0, n
     my_rows = r1 - r0
     my_bytes = int(lens[r0:r1].sum())
+    # the staging buffer: the whole workload (weak scaling: every rank owns a copy), or this rank's share of it only
+    # (strong scaling: ONE workload, nobody builds bytes that belong to another rank's rows)
+    base = int(src_off[r0]) if my_rows else 0
+    wl = workloads.build(args.workload, torch, (base, base + my_bytes) if (args.scaling == "strong" and world > 1) else None)
+    d_src, base = wl["d_src"], wl["base"]
+    rel = (src_off - np.uint64(base)).astype(np.uint64)  # offsets into d_src (meaningful for this rank's rows)
 
     # ---- write side: this rank's Rounds over the resident staging buffer ----
     t0 = time.perf_counter()
-    rounds = hip.RoundTable(ctx, src_off[r0:r1], lens[r0:r1], None if skip is None else skip[r0:r1])
+    rounds = hip.RoundTable(ctx, rel[r0:r1], lens[r0:r1], None if skip is None else skip[r0:r1])
     round_table_ms = (time.perf_counter() - t0) * 1e3  # the context's first table: includes its device-memory pools
     t0 = time.perf_counter()
-    _rt2 = hip.RoundTable(ctx, src_off[r0:r1], lens[r0:r1], None if skip is None else skip[r0:r1])
+    _rt2 = hip.RoundTable(ctx, rel[r0:r1], lens[r0:r1], None if skip is None else skip[r0:r1])
     round_table_warm_ms = (time.perf_counter() - t0) * 1e3
     _rt2.close()
     d_blob = torch.zeros(rounds.blob_bound() + 64, dtype=torch.uint8, device="cuda")
@@ -119,7 +125,7 @@ def main():
     # parity spot checks against the oracle: digests and frames of a few rounds
     for i in sorted({0, my_rows // 2, my_rows - 1}):
         g = r0 + i
-        src_i = d_src[int(src_off[g]):int(src_off[g] + lens[g])].cpu().numpy()
+        src_i = d_src[int(rel[g]):int(rel[g] + lens[g])].cpu().numpy()
         assert enc["checksum"][i].tobytes() == O.blake3(src_i), "GPU write-side digest != oracle"
         f = d_blob[int(enc["blob_offset"][i]):int(enc["blob_offset"][i] + enc["blob_size"][i])].cpu().numpy()
         if enc["compressed"][i]:
@@ -144,7 +150,7 @@ def main():
     my_lens = lens[r0:r1]
     out_off = (src_off[r0:r1] - src_off[r0]).astype(np.uint64)
     d_out = torch.zeros(my_bytes + 64, dtype=torch.uint8, device="cuda")
-    d_src_mine = d_src[int(src_off[r0]):int(src_off[r0]) + my_bytes]
+    d_src_mine = d_src[int(rel[r0]):int(rel[r0]) + my_bytes] if my_rows else d_src[:0]
 
     def cpu_read_loop(A, rows, out_offsets, lens_, nbytes):
         """The oracle's read loop (libzstd decode + scalar C BLAKE3 per row, decompress.rs:L135-190) on the host cores: best of

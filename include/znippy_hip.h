@@ -47,6 +47,12 @@ typedef struct znippy_rounds znippy_rounds; /* write side: a batch of Rounds, de
 /* One context per worker/GPU (the analogue of one CompressCtx per thread, codec.rs:L8-28).
  * `hip_stream` may be NULL (the context then owns a non-blocking stream). */
 int znippy_ctx_create(int device, void *hip_stream, znippy_ctx **out);
+/* Lifetime rule: a table (znippy_rows, znippy_rounds) holds a reference to the context it was created on.
+ * znippy_ctx_destroy on a context that still has tables CLOSES it — every later call that takes this context, with or
+ * without a table, returns ZNIPPY_E_INVAL and touches nothing — and the context's memory and device resources are
+ * released when its last table is destroyed (znippy_rows_destroy / znippy_rounds_destroy are always safe to call, in
+ * any order relative to znippy_ctx_destroy).  Without tables it is released at once.  Calling it twice is harmless
+ * while tables keep it alive; after the release the pointer is dangling, as with any destroy call. */
 void znippy_ctx_destroy(znippy_ctx *ctx);
 /* CompressCtx::new(compression_level) (znippy-common/src/codec.rs:L16-28): the effort of every later encode call of
  * this context.  1..22; a new context starts at 19 (CONFIG.compression_level, common_config.rs:L37).  Two tiers:

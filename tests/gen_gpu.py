@@ -6,10 +6,12 @@ import torch
 import gen
 
 
-def text(size, device="cuda"):
+def text(size, device="cuda", start=0):
+    """bytes [start, start + size) of the cycled phrase"""
     phrase = torch.from_numpy(np.frombuffer(gen.PHRASE, dtype=np.uint8).copy()).to(device)
-    reps = size // len(gen.PHRASE) + 1
-    return phrase.repeat(reps)[:size].contiguous()
+    ph = start % len(gen.PHRASE)
+    reps = (size + ph) // len(gen.PHRASE) + 1
+    return phrase.repeat(reps)[ph:ph + size].contiguous()
 
 
 def binary(size, device="cuda"):
@@ -54,10 +56,25 @@ def _lcg(v0, size, inc, device="cuda"):
     return out
 
 
-def random_lcg(size, device="cuda"):
-    return _lcg(12345, size, 1, device)
+def _jump(v0, inc, steps):
+    """the LCG's state after `steps` steps from v0 (square-and-multiply on the affine map, host integers)"""
+    a, mask = 6364136223846793005, (1 << 64) - 1
+    A, Cc = 1, 0            # identity
+    pa, pc = a, inc         # one step
+    while steps:
+        if steps & 1:
+            A, Cc = (pa * A) & mask, (pa * Cc + pc) & mask
+        pa, pc = (pa * pa) & mask, (pa * pc + pc) & mask
+        steps >>= 1
+    return (A * v0 + Cc) & mask
 
 
-def incompressible(seed, size, device="cuda"):
+def random_lcg(size, device="cuda", start=0):
+    return _lcg(_jump(12345, 1, start), size, 1, device)
+
+
+def incompressible(seed, size, device="cuda", start=0):
+    """bytes [start, start + size) of the seed's stream"""
     v0 = (seed * 0x9E3779B97F4A7C15 + 1) & ((1 << 64) - 1)
-    return _lcg(v0, size, 1442695040888963407, device)
+    inc = 1442695040888963407
+    return _lcg(_jump(v0, inc, start), size, inc, device)

@@ -218,6 +218,41 @@ def test_tables_outliving_their_context_are_closed_with_it():
     gc.collect()
     ctx.close()  # idempotent
 
+def test_c_abi_tables_keep_a_destroyed_context_alive():
+    """The C ABI's lifetime rule (include/znippy_hip.h), straight through ctypes with no wrapper in between: a table holds
+    a reference to its context.  znippy_ctx_destroy with tables alive closes the context — every later call on it is
+    ZNIPPY_E_INVAL, never a use of freed memory — and the last znippy_rows_destroy / znippy_rounds_destroy releases it."""
+    import ctypes as C
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from znippy_amd import _lib
+    L = _lib.lib()
+    E_INVAL = -1
+    ctx = C.c_void_p()
+    assert L.znippy_ctx_create(0, None, C.byref(ctx)) == 0
+    u64 = lambda *v: (C.c_uint64 * len(v))(*v)
+    rows, rounds = C.c_void_p(), C.c_void_p()
+    ck = (C.c_uint8 * 32)()
+    assert L.znippy_rows_create(ctx, u64(0), u64(4), None, u64(4), u64(0), ck, 0, 1, C.byref(rows)) == 0
+    assert L.znippy_rounds_create(ctx, u64(0), u64(4), None, 1, C.byref(rounds)) == 0
+    L.znippy_ctx_destroy(ctx)                      # tables alive: the context is closed, not freed
+    d = torch.zeros(256, dtype=torch.uint8, device="cuda")
+    assert L.znippy_decode_verify_rows_async(ctx, rows, C.c_void_p(d.data_ptr()), 0, C.c_void_p(d.data_ptr() + 128), 64) == E_INVAL
+    dig = (C.c_uint8 * 32)()
+    assert L.znippy_hash_rounds(ctx, rounds, C.c_void_p(d.data_ptr()), dig) == E_INVAL
+    assert L.znippy_blake3(ctx, b"abc", 3, dig) == E_INVAL
+    more = C.c_void_p()
+    assert L.znippy_rows_create(ctx, u64(0), u64(4), None, u64(4), u64(0), ck, 0, 1, C.byref(more)) == E_INVAL
+    L.znippy_ctx_destroy(ctx)                      # idempotent while closing
+    L.znippy_rows_destroy(rows)
+    L.znippy_rounds_destroy(rounds)                # the last table: the context goes with it
+    ctx2 = C.c_void_p()                            # the device is fine afterwards
+    assert L.znippy_ctx_create(0, None, C.byref(ctx2)) == 0
+    assert L.znippy_blake3(ctx2, b"abc", 3, dig) == 0
+    assert bytes(dig).hex().startswith("6437b3ac38465133")
+    L.znippy_ctx_destroy(ctx2)
+
 
 @pytest.mark.parametrize("tiles", [
     ("......", "......", "......", "v.v..."), ("v.v...", "......", "......", "......"), ("vv....", "vvvvvv", "v.....", "vv.v.v"),

@@ -113,24 +113,35 @@ def test_world2_gloo_write_side_equals_single_process(tmp_path, oracle):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("scaling", ["weak", "strong"])
-def test_bench_n2_path_rehearsed_on_one_gpu(scaling):
+@pytest.mark.parametrize("scaling,workload", [("weak", "c2small"), ("strong", "c2small"), ("strong", "c5small")])
+def test_bench_n2_path_rehearsed_on_one_gpu(scaling, workload):
     """bench.py's N>1 code path (rendezvous, per-step counter all-reduce on its own stream, barrier + MAX-over-ranks
     timing, rank-0 JSON) with two ranks sharing the one card over gloo; the driver runs the real thing over RCCL.
-    weak: every rank owns a copy of the workload; strong: ONE archive, the row cursor split into per-rank ranges."""
+    weak: every rank owns a copy of the workload; strong: ONE archive, the row cursor split into per-rank ranges and
+    every rank builds only its own share of the staging buffer.  c5small = BASELINE configs[4]'s mixed archive (xml text
+    + stored jars, skewed sizes) at 1/16 of the files: the shape the driver's 8-rank run of `--workload c5 --scaling
+    strong` exercises."""
     import json
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, ZNIPPY_BENCH_BACKEND="gloo")
+    port = {"weak": 29533, "strong": 29534}[scaling] + (2 if workload == "c5small" else 0)
     p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-                        "--master-addr", "127.0.0.1", "--master-port", "29533" if scaling == "weak" else "29534",
+                        "--master-addr", "127.0.0.1", "--master-port", str(port),
                         os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
-                        "--workload", "c2small", "--scaling", scaling],
+                        "--workload", workload, "--scaling", scaling],
                        capture_output=True, text=True, timeout=600, env=env, cwd=root)
     assert p.returncode == 0, p.stderr[-2000:]
     line = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["scaling"] == scaling and line["value"] > 0
     assert line["config"]["parallelism"].endswith("x2") and line["cpu_baseline"] is None
-    assert abs(line["config"]["rows_per_gpu"] - (2000 if scaling == "weak" else 1000)) <= 1
-    assert "libzstd level-19" in line["config"]["archive"] and line["read_own_archive"]["MBps"] > 0
+    if workload == "c2small":
+        assert abs(line["config"]["rows_per_gpu"] - (2000 if scaling == "weak" else 1000)) <= 1
+        assert "libzstd level-19" in line["config"]["archive"] and line["read_own_archive"]["MBps"] > 0
+    else:
+        import workloads
+        lay = workloads.layout("c5small")
+        (a0, a1), _ = split_rows(lay["lens"], 2)
+        assert line["config"]["rows_per_gpu"] == a1 - a0                     # rank 0's range, balanced by bytes not rows
+        assert line["config"]["bytes_per_gpu"] == int(lay["lens"][a0:a1].sum()) < 0.6 * int(lay["lens"].sum())

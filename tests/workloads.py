@@ -10,52 +10,75 @@ SLICE = 8 << 20          # stream_packer.rs:L31
 SLOT = 200 << 20         # slot_packer.rs:L30 (BASELINE configs[2] calls these "Magazine slices")
 
 
-def c5_layout():
+def c5_layout(scale=1):
     """Synthetic stand-in for the 5 GB / 5k-file artifact repo: 3,500 .xml text files of 1-8 KiB
     (compress_dir_bench.rs:L45-68), 1,400 .jar of 100 KiB..2 MiB and 100 .jar of 20..69.5 MiB of incompressible
-    bytes (repro_crate.rs:L8-16; store path), stream chunking (8 MiB slices).  -> (xml sizes, jar sizes)"""
-    xml = [1024 + (i % 8) * 1024 for i in range(3500)]
-    jars = [100 * 1024 + (i % 20) * 100 * 1024 for i in range(1400)] + [(20 << 20) + i * (1 << 19) for i in range(100)]
+    bytes (repro_crate.rs:L8-16; store path), stream chunking (8 MiB slices).  -> (xml sizes, jar sizes).
+    scale > 1: 1/scale of the files, the big jars 1/8 of their size (multi-rank rehearsals: "c5small")."""
+    xml = [1024 + (i % 8) * 1024 for i in range(3500 // scale)]
+    big = (20 << 20) if scale == 1 else (20 << 20) // 8
+    jars = [100 * 1024 + (i % 20) * 100 * 1024 for i in range(1400 // scale)] + [big + i * (1 << 19) for i in range(max(100 // scale, 1))]
     return xml, jars
 
 
-def build(name, torch):
-    """-> dict(d_src, lens, skip, name): the Rounds of one configuration over a resident staging buffer."""
+def layout(name):
+    """-> dict(lens, skip, name, gen): the Rounds of one configuration; gen(torch, b0, b1) makes bytes [b0, b1) of the
+    staging buffer on the device (a rank of a strong-scaling run builds only its own share)."""
     if name in ("c2", "c2small"):
         n = 100_000 if name == "c2" else 2_000
-        chunk = np.frombuffer(gen.text(10 * 1024), dtype=np.uint8)
-        d_src = torch.from_numpy(np.tile(chunk, n)).cuda()
         label = ("100k x 10KiB text chunks (BASELINE configs[1])" if name == "c2"
                  else "2k x 10KiB text chunks (reduced; NOT the headline config)")
-        return dict(d_src=d_src, lens=np.full(n, 10240, np.uint64), skip=None, name=label)
-    if name == "c3":
+
+        def g(torch, b0, b1):  # every chunk is the same 10 KiB of the cycled phrase, restarted per chunk
+            chunk = torch.from_numpy(np.frombuffer(gen.text(10 * 1024), dtype=np.uint8).copy()).cuda()
+            c0, c1 = b0 // 10240, (b1 + 10239) // 10240
+            return chunk.repeat(max(c1 - c0, 1))[b0 - c0 * 10240:b0 - c0 * 10240 + (b1 - b0)].contiguous()
+        return dict(lens=np.full(n, 10240, np.uint64), skip=None, name=label, gen=g)
+    if name in ("c3", "c3slot"):
         size = 2 << 30
-        return dict(d_src=gen_gpu.text(size), lens=np.full(size // SLICE, SLICE, np.uint64), skip=None,
-                    name="single 2 GiB text file, 256 x 8 MiB slices (BASELINE configs[2] at the reference's slice size)")
-    if name == "c3slot":
-        size = 2 << 30
-        lens = np.array([SLOT] * (size // SLOT) + ([size % SLOT] if size % SLOT else []), dtype=np.uint64)
-        return dict(d_src=gen_gpu.text(size), lens=lens, skip=None,
-                    name="single 2 GiB text file, 11 slices of <= 200 MiB (BASELINE configs[2] as worded there)")
-    if name == "c5":
-        xml, jars = c5_layout()
+        if name == "c3":
+            lens = np.full(size // SLICE, SLICE, np.uint64)
+            label = "single 2 GiB text file, 256 x 8 MiB slices (BASELINE configs[2] at the reference's slice size)"
+        else:
+            lens = np.array([SLOT] * (size // SLOT) + ([size % SLOT] if size % SLOT else []), dtype=np.uint64)
+            label = "single 2 GiB text file, 11 slices of <= 200 MiB (BASELINE configs[2] as worded there)"
+        return dict(lens=lens, skip=None, name=label, gen=lambda torch, b0, b1: gen_gpu.text(b1 - b0, start=b0))
+    if name in ("c5", "c5small"):
+        xml, jars = c5_layout(1 if name == "c5" else 16)
         lens, skip = list(xml), [0] * len(xml)
         for j in jars:
             for o in range(0, j, SLICE):
                 lens.append(min(SLICE, j - o))
                 skip.append(1)
-        # jar bytes are consecutive cuts of one LCG stream
-        d_src = torch.cat([gen_gpu.text(sum(xml)), gen_gpu.incompressible(7, sum(jars))])
-        return dict(d_src=d_src, lens=np.array(lens, np.uint64), skip=np.array(skip, np.uint8),
-                    name="mixed artifact repo stand-in: 3,500 xml (1-8 KiB) + 1,500 jars (100 KiB-69.5 MiB, store path), %.2f GB"
-                         % ((sum(xml) + sum(jars)) / 1e9))
+        nx, nj = sum(xml), sum(jars)
+
+        def g(torch, b0, b1):  # [text of all xml files | ONE LCG stream cut into the jars]
+            parts = []
+            if b0 < nx:
+                parts.append(gen_gpu.text(min(b1, nx) - b0, start=b0))
+            if b1 > nx:
+                j0 = max(b0, nx) - nx
+                parts.append(gen_gpu.incompressible(7, b1 - nx - j0, start=j0))
+            return torch.cat(parts) if len(parts) > 1 else parts[0]
+        return dict(lens=np.array(lens, np.uint64), skip=np.array(skip, np.uint8), gen=g,
+                    name=("mixed artifact repo stand-in: %d xml (1-8 KiB) + %d jars (100 KiB-%.1f MiB, store path), %.2f GB"
+                          % (len(xml), len(jars), max(jars) / 2**20, (nx + nj) / 1e9)) + ("" if name == "c5" else " (reduced; NOT BASELINE's size)"))
     if name in ("c4store", "c4codec"):
         size = 500 << 20
         lens = np.array([SLICE] * (size // SLICE) + ([size % SLICE] if size % SLICE else []), dtype=np.uint64)
         skip = np.ones(len(lens), np.uint8) if name == "c4store" else None
-        return dict(d_src=gen_gpu.random_lcg(size), lens=lens, skip=skip,
+        return dict(lens=lens, skip=skip, gen=lambda torch, b0, b1: gen_gpu.random_lcg(b1 - b0, start=b0),
                     name="500 MiB LCG blob, 8 MiB slices, " + ("store path (random.jar)" if skip is not None else "codec path (random.bin)"))
     raise SystemExit(f"unknown workload {name}")
+
+
+def build(name, torch, byte_range=None):
+    """-> dict(d_src, lens, skip, name, base): the Rounds of one configuration over a resident staging buffer;
+    byte_range = (b0, b1): only those bytes of it are built (d_src[0] is byte b0 = base)."""
+    L = layout(name)
+    total = int(L["lens"].sum())
+    b0, b1 = byte_range if byte_range is not None else (0, total)
+    return dict(d_src=L["gen"](torch, int(b0), int(b1)), lens=L["lens"], skip=L["skip"], name=L["name"], base=int(b0))
 
 
 def libzstd_compress(data, level=19) -> bytes:

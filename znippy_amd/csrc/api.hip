@@ -97,6 +97,11 @@ struct znippy_ctx {
         int ktime = 2;  // per-kernel HIP events: 2 = every kernel, 1 = the dominant read kernels only, 0 = none
     } sw;
     int cus = 256;
+    // Lifetime (znippy_hip.h): tables hold a reference to their context.  znippy_ctx_destroy with tables still alive only
+    // closes the context (every call on it fails with ZNIPPY_E_INVAL from then on); its memory and device resources go
+    // when the last table is destroyed.
+    int live_tables = 0;
+    bool closing = false;
     unsigned long long *clk_buf = nullptr;  // diagnostic (ZNIPPY_DBG & 32768): shader cycles / 100 MHz ticks of one wave
 };
 
@@ -536,8 +541,21 @@ int znippy_ctx_create(int device, void *hip_stream, znippy_ctx **out) {
     return ZNIPPY_OK;
 }
 
+static void ctx_teardown(znippy_ctx *ctx);
 void znippy_ctx_destroy(znippy_ctx *ctx) {
-    if (!ctx) return;
+    if (!ctx || ctx->closing) return;
+    if (ctx->live_tables) {  // tables outlive the call: they keep the context's memory until the last of them is destroyed
+        (void)hipSetDevice(ctx->device);
+        (void)hipStreamSynchronize(ctx->stream);
+        ctx->closing = true;
+        return;
+    }
+    ctx_teardown(ctx);
+}
+static void table_released(znippy_ctx *ctx) {
+    if (--ctx->live_tables == 0 && ctx->closing) ctx_teardown(ctx);
+}
+static void ctx_teardown(znippy_ctx *ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     for (auto &k : ctx->ktimes) { (void)hipEventDestroy(k.t0); (void)hipEventDestroy(k.t1); }
@@ -567,6 +585,7 @@ void znippy_ctx_destroy(znippy_ctx *ctx) {
 const char *znippy_last_error(const znippy_ctx *ctx) { return ctx ? ctx->err.c_str() : "null context"; }
 
 int znippy_ctx_sync(znippy_ctx *ctx) {
+    if (ctx && ctx->closing) return ZNIPPY_E_INVAL;  // destroyed context kept alive by its tables
     if (!ctx) return ZNIPPY_E_INVAL;
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     if (ctx->copy) HIPCHK(ctx, hipStreamSynchronize(ctx->copy));
@@ -574,6 +593,7 @@ int znippy_ctx_sync(znippy_ctx *ctx) {
 }
 
 int znippy_last_kernel_times(znippy_ctx *ctx, const char **names, float *ms, int cap) {
+    if (ctx && ctx->closing) return ZNIPPY_E_INVAL;  // destroyed context kept alive by its tables
     if (!ctx) return 0;
     int n = std::min(cap, ctx->n_ktimes);
     for (int i = 0; i < n; i++) {
@@ -585,6 +605,7 @@ int znippy_last_kernel_times(znippy_ctx *ctx, const char **names, float *ms, int
 }
 
 int znippy_rows_foreign_stats(znippy_ctx *ctx, znippy_rows *r, uint64_t stats[8]) {
+    if (ctx && ctx->closing) return ZNIPPY_E_INVAL;  // destroyed context kept alive by its tables
     if (!ctx || !r || r->ctx != ctx || !stats) return ZNIPPY_E_INVAL;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
@@ -594,6 +615,7 @@ int znippy_rows_foreign_stats(znippy_ctx *ctx, znippy_rows *r, uint64_t stats[8]
 }
 
 int znippy_ctx_set_level(znippy_ctx *ctx, int level) {
+    if (ctx && ctx->closing) return ZNIPPY_E_INVAL;  // destroyed context kept alive by its tables
     if (!ctx || level < 1 || level > 22) return ZNIPPY_E_INVAL;
     ctx->level = level;
     return ZNIPPY_OK;
@@ -602,12 +624,14 @@ int znippy_ctx_set_level(znippy_ctx *ctx, int level) {
 int znippy_ctx_level(const znippy_ctx *ctx) { return ctx ? ctx->level : ZNIPPY_E_INVAL; }
 
 int znippy_ctx_set_kernel_timing(znippy_ctx *ctx, int level) {
+    if (ctx && ctx->closing) return ZNIPPY_E_INVAL;  // destroyed context kept alive by its tables
     if (!ctx || level < 0 || level > 2) return ZNIPPY_E_INVAL;
     ctx->sw.ktime = level;
     return ZNIPPY_OK;
 }
 
 int znippy_measure_blake3_pass_ns(znippy_ctx *ctx, float *ns_per_pass_per_simd, float *shader_ghz) {
+    if (ctx && ctx->closing) return ZNIPPY_E_INVAL;  // destroyed context kept alive by its tables
     if (!ctx || !ns_per_pass_per_simd) return ZNIPPY_E_INVAL;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
@@ -617,6 +641,7 @@ int znippy_measure_blake3_pass_ns(znippy_ctx *ctx, float *ns_per_pass_per_simd, 
 // Shader clock a read-side kernel held during the last run with ZNIPPY_DBG bit 32768 set: one wave's life in shader
 // cycles / in 100 MHz ticks (MI355X_MICROARCH.md, DVFS give-back (6)).  0 if nothing was recorded.
 int znippy_last_shader_ghz(znippy_ctx *ctx, float *ghz) {
+    if (ctx && ctx->closing) return ZNIPPY_E_INVAL;  // destroyed context kept alive by its tables
     if (!ctx || !ghz) return ZNIPPY_E_INVAL;
     *ghz = 0.f;
     if (!ctx->clk_buf) return ZNIPPY_OK;
@@ -688,19 +713,23 @@ void znippy_rows_destroy(znippy_rows *r) {
     }
     for (hipEvent_t e : r->ev_done) event_give(r->ctx, e);
     free_plan(r->ctx, r->plan);
+    znippy_ctx *const c = r->ctx;
     delete r;
+    table_released(c);
 }
 
 int znippy_rows_create(znippy_ctx *ctx, const uint64_t *blob_offset, const uint64_t *blob_size,
                        const uint8_t *compressed_bitmap, const uint64_t *uncompressed_size,
                        const uint64_t *out_offset, const uint8_t *checksum, uint64_t row_begin,
                        uint64_t row_end, znippy_rows **out) {
+    if (ctx && ctx->closing) return ZNIPPY_E_INVAL;  // destroyed context kept alive by its tables
     if (!ctx || !out || row_end < row_begin || !blob_offset || !blob_size || !uncompressed_size || !out_offset)
         return ZNIPPY_E_INVAL;
     if (row_end - row_begin >= 0xFFFFFFF0ull) return ZNIPPY_E_INVAL;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     znippy_rows *r = new znippy_rows();
     r->ctx = ctx;
+    ctx->live_tables++;
     r->row_begin = row_begin;
     r->n = (uint32_t)(row_end - row_begin);
     const uint32_t n = r->n;
@@ -928,6 +957,7 @@ static void rows_note_hint(znippy_rows *r, unsigned slot) {
 
 int znippy_decode_verify_rows_async(znippy_ctx *ctx, znippy_rows *r, const void *d_blobs,
                                     uint64_t blob_base, void *d_out, uint64_t out_cap) {
+    if (ctx && ctx->closing) return ZNIPPY_E_INVAL;  // destroyed context kept alive by its tables
     if (!ctx || !r || r->ctx != ctx) return ZNIPPY_E_INVAL;
     if (r->n && (!d_blobs || !d_out)) return ZNIPPY_E_INVAL;
     HIPCHK(ctx, hipSetDevice(ctx->device));
@@ -1197,24 +1227,35 @@ int znippy_decode_verify_rows_async(znippy_ctx *ctx, znippy_rows *r, const void 
                 launch_decode(a, std::min<int>(ctx->decode_grid, (int)r->n_compressed), r->wide_rows, s);
             ktime_end(ctx);
         } else {
-        ktime_begin(ctx, "zstd_decode_general");
-        // A full grid of this kernel (4 workgroups per CU at 128 VGPRs) is the whole register file: whatever the auxiliary
-        // stream launches then waits until workgroups run out of rows (kernel trace of the real-text table: the first
-        // auxiliary kernel sat 3.4 ms).  With candidates for the block / foreign-frame paths it leaves them a quarter.
-        const int gen_grid = r->n_cand ? ctx->decode_grid / 4 * ctx->gen_share : ctx->decode_grid;
-        launch_decode(a, std::min<int>(gen_grid, (int)r->n_compressed), r->wide_rows, s);
-        ktime_end(ctx);
-        if (r->n_cand) {  // join (block items and the foreign-frame path on the auxiliary stream), then what both gave up on
-            HIPCHK(ctx, hipStreamWaitEvent(s, ctx->ev_join, 0));
-            launch_finish_blocks(b, s, false);
-            a.list_a = nullptr; a.n_list_a = 0;
-            a.pending = r->pending2; a.pending_count = r->pending_count + 1;
-            a.cursor = r->cursor + 8;
-            ktime_begin(ctx, "zstd_decode_fallback");
-            if (!ctx->sw.fz_only)
-            launch_decode(a, std::min<int>(ctx->decode_grid, (int)r->n_cand), r->wide_rows, s);
+            // Round-2 flow (no batch path: ZNIPPY_NO_BX, no pools, or a table whose last run handed nothing over): the
+            // serial decoder takes the host's list and what the fused kernel hands over, beside the block items on the
+            // auxiliary stream — or behind them when nothing is expected (its launch then returns at once instead of
+            // waiting for CUs next to the block kernels: C3's 0.25 ms "general decoder" that only waited).
+            const bool behind = r->n_cand && r->bx_hint == 0;
+            if (behind) {
+                HIPCHK(ctx, hipStreamWaitEvent(s, ctx->ev_join, 0));
+                launch_finish_blocks(b, s, false);
+            }
+            ktime_begin(ctx, "zstd_decode_general");
+            // A full grid of this kernel (4 workgroups per CU at 128 VGPRs) is the whole register file: whatever the auxiliary
+            // stream launches then waits until workgroups run out of rows.  With candidates for the block / foreign-frame
+            // paths it leaves them a quarter.
+            const int gen_grid = r->n_cand && !behind ? ctx->decode_grid / 4 * ctx->gen_share : ctx->decode_grid;
+            launch_decode(a, std::min<int>(gen_grid, (int)r->n_compressed), r->wide_rows, s);
             ktime_end(ctx);
-        }
+            if (r->n_cand) {  // join (block items and the foreign-frame path on the auxiliary stream), then what both gave up on
+                if (!behind) {
+                    HIPCHK(ctx, hipStreamWaitEvent(s, ctx->ev_join, 0));
+                    launch_finish_blocks(b, s, false);
+                }
+                a.list_a = nullptr; a.n_list_a = 0;
+                a.pending = r->pending2; a.pending_count = r->pending_count + 1;
+                a.cursor = r->cursor + 8;
+                ktime_begin(ctx, "zstd_decode_fallback");
+                if (!ctx->sw.fz_only)
+                    launch_decode(a, std::min<int>(ctx->decode_grid, (int)r->n_cand), r->wide_rows, s);
+                ktime_end(ctx);
+            }
         }
     }
     // 3) second hash pass: slices of big rows + rows the general decoder finished
@@ -1246,6 +1287,7 @@ int znippy_decode_verify_rows_async(znippy_ctx *ctx, znippy_rows *r, const void 
 // keeps two runs in flight reads run k's counters while run k + 1 executes (the read loop reports after the loop,
 // not per row: decompress.rs:L195-221).
 int znippy_rows_results_lagged(znippy_ctx *ctx, znippy_rows *r, unsigned lag, znippy_verify_counters *counters) {
+    if (ctx && ctx->closing) return ZNIPPY_E_INVAL;  // destroyed context kept alive by its tables
     if (!ctx || !r || r->ctx != ctx || !counters || lag > 1 || r->run_seq <= lag) return ZNIPPY_E_INVAL;
     uint64_t c[8] = {0};
     if (r->n) {
@@ -1261,6 +1303,7 @@ int znippy_rows_results_lagged(znippy_ctx *ctx, znippy_rows *r, unsigned lag, zn
 
 int znippy_rows_results(znippy_ctx *ctx, znippy_rows *r, znippy_verify_counters *counters,
                         uint64_t *corrupt_rows, uint64_t corrupt_cap, int32_t *row_status) {
+    if (ctx && ctx->closing) return ZNIPPY_E_INVAL;  // destroyed context kept alive by its tables
     if (!ctx || !r) return ZNIPPY_E_INVAL;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
@@ -1292,12 +1335,14 @@ int znippy_decode_verify_rows(znippy_ctx *ctx, znippy_rows *rows, const void *d_
                               uint64_t blob_base, void *d_out, uint64_t out_cap,
                               znippy_verify_counters *counters, uint64_t *corrupt_rows,
                               uint64_t corrupt_cap, int32_t *row_status) {
+    if (ctx && ctx->closing) return ZNIPPY_E_INVAL;  // destroyed context kept alive by its tables
     int rc = znippy_decode_verify_rows_async(ctx, rows, d_blobs, blob_base, d_out, out_cap);
     if (rc) return rc;
     return znippy_rows_results(ctx, rows, counters, corrupt_rows, corrupt_cap, row_status);
 }
 
 int znippy_rows_digests(znippy_ctx *ctx, znippy_rows *r, uint8_t *digests) {
+    if (ctx && ctx->closing) return ZNIPPY_E_INVAL;  // destroyed context kept alive by its tables
     if (!ctx || !r || !digests) return ZNIPPY_E_INVAL;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
@@ -1332,15 +1377,19 @@ void znippy_rounds_destroy(znippy_rounds *r) {
     for (void *p : ptrs)
         tfree(r->ctx, p);
     free_plan(r->ctx, r->plan);
+    znippy_ctx *const c = r->ctx;
     delete r;
+    table_released(c);
 }
 
 int znippy_rounds_create(znippy_ctx *ctx, const uint64_t *src_offset, const uint64_t *len,
                          const uint8_t *skip, uint64_t n, znippy_rounds **out) {
+    if (ctx && ctx->closing) return ZNIPPY_E_INVAL;  // destroyed context kept alive by its tables
     if (!ctx || !out || (n && (!src_offset || !len)) || n >= 0xFFFFFFF0ull) return ZNIPPY_E_INVAL;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     znippy_rounds *r = new znippy_rounds();
     r->ctx = ctx;
+    ctx->live_tables++;
     r->n = (uint32_t)n;
     r->h_len.assign(len, len + n);
     r->h_off.assign(src_offset, src_offset + n);
@@ -1470,6 +1519,7 @@ static int hash_rounds_async(znippy_ctx *ctx, znippy_rounds *r, const void *d_sr
 }
 
 int znippy_hash_rounds(znippy_ctx *ctx, znippy_rounds *r, const void *d_src, uint8_t *digests) {
+    if (ctx && ctx->closing) return ZNIPPY_E_INVAL;  // destroyed context kept alive by its tables
     if (!ctx || !r || r->ctx != ctx || !digests || (r->n && !d_src)) return ZNIPPY_E_INVAL;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     ctx->n_ktimes = 0;
@@ -1500,6 +1550,7 @@ static int shim_reserve(znippy_ctx *ctx, size_t in_need, size_t out_need) {
 }
 
 int znippy_blake3(znippy_ctx *ctx, const void *src, size_t n, uint8_t out[32]) {
+    if (ctx && ctx->closing) return ZNIPPY_E_INVAL;  // destroyed context kept alive by its tables
     if (!ctx || !out || (n && !src)) return ZNIPPY_E_INVAL;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     int rc = shim_reserve(ctx, n, 0);
@@ -1515,6 +1566,7 @@ int znippy_blake3(znippy_ctx *ctx, const void *src, size_t n, uint8_t out[32]) {
 }
 
 int znippy_decompress(znippy_ctx *ctx, const void *frame, size_t n, void *dst, size_t cap, size_t *written) {
+    if (ctx && ctx->closing) return ZNIPPY_E_INVAL;  // destroyed context kept alive by its tables
     if (!ctx || !frame || !written || (cap && !dst)) return ZNIPPY_E_INVAL;
     uint64_t usize = 0;
     int rc = znippy_get_decompressed_size(frame, n, &usize);
@@ -1559,6 +1611,7 @@ __global__ __launch_bounds__(256) void k_results_out(uint4 *dst, const uint4 *sr
 // ---- write side ------------------------------------------------------------------------------------
 extern "C" int znippy_encode_hash_rounds_async(znippy_ctx *ctx, znippy_rounds *r, const void *d_src, void *d_blob_out,
                                                uint64_t blob_cap) {
+    if (ctx && ctx->closing) return ZNIPPY_E_INVAL;  // destroyed context kept alive by its tables
     if (!ctx || !r || r->ctx != ctx || (r->n && (!d_src || !d_blob_out))) return ZNIPPY_E_INVAL;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     hipStream_t s = ctx->stream;
@@ -1681,6 +1734,7 @@ extern "C" int znippy_encode_hash_rounds_async(znippy_ctx *ctx, znippy_rounds *r
 // that run's copy only.  Valid until two more encode calls have been queued on the table.
 extern "C" int znippy_rounds_results_lagged(znippy_ctx *ctx, znippy_rounds *r, unsigned lag, const uint64_t **blob_offset,
                                             const uint64_t **blob_size, const uint8_t **checksum, uint64_t *blob_bytes) {
+    if (ctx && ctx->closing) return ZNIPPY_E_INVAL;  // destroyed context kept alive by its tables
     if (!ctx || !r || r->ctx != ctx || lag > 1 || r->run_seq <= lag) return ZNIPPY_E_INVAL;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     const unsigned slot = (unsigned)((r->run_seq - 1 - lag) & 1);
@@ -1701,6 +1755,7 @@ extern "C" int znippy_rounds_results_lagged(znippy_ctx *ctx, znippy_rounds *r, u
 
 extern "C" int znippy_rounds_results(znippy_ctx *ctx, znippy_rounds *r, uint64_t *blob_offset, uint64_t *blob_size,
                                      uint8_t *checksum, uint8_t *compressed, uint64_t *blob_bytes) {
+    if (ctx && ctx->closing) return ZNIPPY_E_INVAL;  // destroyed context kept alive by its tables
     if (!ctx || !r || r->ctx != ctx) return ZNIPPY_E_INVAL;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     if (blob_bytes) *blob_bytes = 0;
@@ -1731,6 +1786,7 @@ extern "C" int znippy_rounds_results(znippy_ctx *ctx, znippy_rounds *r, uint64_t
 // on this table (compressed[] = !skip is known to the caller already).
 extern "C" int znippy_rounds_results_view(znippy_ctx *ctx, znippy_rounds *r, const uint64_t **blob_offset,
                                           const uint64_t **blob_size, const uint8_t **checksum, uint64_t *blob_bytes) {
+    if (ctx && ctx->closing) return ZNIPPY_E_INVAL;  // destroyed context kept alive by its tables
     int rc = znippy_rounds_results(ctx, r, nullptr, nullptr, nullptr, nullptr, blob_bytes);
     if (rc) return rc;
     const size_t n = r->n;
@@ -1743,12 +1799,14 @@ extern "C" int znippy_rounds_results_view(znippy_ctx *ctx, znippy_rounds *r, con
 extern "C" int znippy_encode_hash_rounds(znippy_ctx *ctx, znippy_rounds *rounds, const void *d_src, void *d_blob_out,
                                          uint64_t blob_cap, uint64_t *blob_offset, uint64_t *blob_size,
                                          uint8_t *checksum, uint8_t *compressed, uint64_t *blob_bytes) {
+    if (ctx && ctx->closing) return ZNIPPY_E_INVAL;  // destroyed context kept alive by its tables
     int rc = znippy_encode_hash_rounds_async(ctx, rounds, d_src, d_blob_out, blob_cap);
     if (rc) return rc;
     return znippy_rounds_results(ctx, rounds, blob_offset, blob_size, checksum, compressed, blob_bytes);
 }
 
 extern "C" int znippy_compress(znippy_ctx *ctx, const void *src, size_t n, void *dst, size_t cap, size_t *written) {
+    if (ctx && ctx->closing) return ZNIPPY_E_INVAL;  // destroyed context kept alive by its tables
     if (!ctx || !written || !dst || (n && !src)) return ZNIPPY_E_INVAL;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     const size_t bound = znippy_compress_bound(n);
