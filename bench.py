@@ -115,10 +115,16 @@ def main():
     t0 = time.perf_counter()
     rounds = hip.RoundTable(ctx, rel[r0:r1], lens[r0:r1], None if skip is None else skip[r0:r1])
     round_table_ms = (time.perf_counter() - t0) * 1e3  # the context's first table: includes its device-memory pools
-    t0 = time.perf_counter()
-    _rt2 = hip.RoundTable(ctx, rel[r0:r1], lens[r0:r1], None if skip is None else skip[r0:r1])
-    round_table_warm_ms = (time.perf_counter() - t0) * 1e3
-    _rt2.close()
+    # warm = what a context that has built and released a table of this shape before pays (its pools hold the buffers: the
+    # host pipelines build and drop one table per hand-off); best of three
+    round_table_warm_ms = None
+    for _ in range(4):
+        t0 = time.perf_counter()
+        _rt2 = hip.RoundTable(ctx, rel[r0:r1], lens[r0:r1], None if skip is None else skip[r0:r1])
+        dt_ = (time.perf_counter() - t0) * 1e3
+        _rt2.close()
+        if _ > 0:
+            round_table_warm_ms = dt_ if round_table_warm_ms is None else min(round_table_warm_ms, dt_)
     d_blob = torch.zeros(rounds.blob_bound() + 64, dtype=torch.uint8, device="cuda")
     enc = rounds.encode_hash(d_src, d_blob)
     enc = {k: (v.copy() if hasattr(v, "copy") else v) for k, v in enc.items()}
@@ -200,10 +206,15 @@ def main():
         t0 = time.perf_counter()
         rt = hip.RowTable(ctx, a["bo"], a["bs"], my_lens, out_off, np.packbits(a["comp"].astype(bool), bitorder="little"), a["ck"])
         first = (time.perf_counter() - t0) * 1e3
-        t0 = time.perf_counter()  # a second table of the same archive: what a context that has built one before pays
-        rt2 = hip.RowTable(ctx, a["bo"], a["bs"], my_lens, out_off, np.packbits(a["comp"].astype(bool), bitorder="little"), a["ck"])
-        warm = (time.perf_counter() - t0) * 1e3
-        rt2.close()
+        bm = np.packbits(a["comp"].astype(bool), bitorder="little")
+        warm = None  # further tables of the same archive, each released before the next: the pools hold the buffers; best of three
+        for k in range(4):
+            t0 = time.perf_counter()
+            rt2 = hip.RowTable(ctx, a["bo"], a["bs"], my_lens, out_off, bm, a["ck"])
+            dt_ = (time.perf_counter() - t0) * 1e3
+            rt2.close()
+            if k > 0:
+                warm = dt_ if warm is None else min(warm, dt_)
         return rt, (first, warm)
 
     def barrier():
@@ -332,6 +343,35 @@ def main():
         dt_own, k_own = dt_read, k_read
     dt_write, k_write = timed(WriteLeg(), args.steps, args.warmup)
     dt_text, k_text = timed(legs["text"], args.steps, args.warmup) if text is not None else (None, None)
+    # single shot (an archive is decoded once): table construction + ONE run + its results, blobs resident, index columns
+    # in host memory as the reader leaves them; best of three
+    def single_shot_read(a):
+        bm = np.packbits(a["comp"].astype(bool), bitorder="little")
+        best = None
+        for _ in range(3):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            rt_ = hip.RowTable(ctx, a["bo"], a["bs"], my_lens, out_off, bm, a["ck"])
+            c_, _corrupt, _status = rt_.decode_verify(a["d_blobs"], d_out)
+            dt_ = (time.perf_counter() - t0) * 1e3
+            rt_.close()
+            assert c_["corrupt_rows"] == 0 and c_["verified_bytes"] == my_bytes
+            best = dt_ if best is None else min(best, dt_)
+        return best
+
+    def single_shot_write():
+        best = None
+        for _ in range(3):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            rd_ = hip.RoundTable(ctx, rel[r0:r1], lens[r0:r1], None if skip is None else skip[r0:r1])
+            e_ = rd_.encode_hash(d_src, d_blob)
+            dt_ = (time.perf_counter() - t0) * 1e3
+            rd_.close()
+            assert int(e_["blob_size"].sum()) > 0
+            best = dt_ if best is None else min(best, dt_)
+        return best
+    ss_read, ss_write = single_shot_read(archives[archive_kind]), single_shot_write()
     for k, leg in legs.items():  # every step of every read leg (warmup, timed, kernel-time collection) verified every byte
         assert leg.bad_steps == 0, f"{leg.bad_steps} steps of the {k} read leg did not verify"
 
@@ -424,7 +464,9 @@ def main():
             "compress_kernel_ms": {k: round(v, 4) for k, v in k_write.items()},
             "table_build_ms": {"row_table": round(head.table_ms[1], 3), "round_table": round(round_table_warm_ms, 3),
                                "row_table_first": round(head.table_ms[0], 3), "round_table_first": round(round_table_ms, 3),
-                               "note": "host plan + H2D of the index columns / Rounds, outside the timed steps; *_first = the context's first table (its memory pools are created)"},
+                               "note": "host passes + H2D of the index columns / Rounds (the encoder plan is built on the device), outside the timed steps; best of three with the context's pools warm (a table of this shape was built and released before); *_first = the context's first table (its memory pools are created)"},
+            "single_shot_ms": {"read": round(ss_read, 3), "write": round(ss_write, 3),
+                               "note": "table construction + one run + its results (synchronous), blobs / staging buffer resident, index columns / Rounds in host memory; best of three"},
             "read_text_archive": text_leg,
             "roofline": roofline, "cpu_baseline": cpu,
         }

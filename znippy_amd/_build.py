@@ -9,7 +9,9 @@ SO = os.path.join(HERE, "libznippy_hip.so")
 
 
 def sources():
-    return sorted(glob.glob(os.path.join(CSRC, "*.hip"))) + sorted(glob.glob(os.path.join(CSRC, "host", "*.cpp")))
+    # *.hip: kernels + the C ABI; host/*.cpp: host code that uses the HIP runtime; host/*.cc: plain C++ (no device pass)
+    return (sorted(glob.glob(os.path.join(CSRC, "*.hip"))) + sorted(glob.glob(os.path.join(CSRC, "host", "*.cpp"))) +
+            sorted(glob.glob(os.path.join(CSRC, "host", "*.cc"))))
 
 
 def needs_build():
@@ -29,8 +31,11 @@ def build(force=False, verbose=False):
     procs = []
     for src in sources():
         obj = os.path.splitext(src)[0] + ".o"
-        cmd = [hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-c", src, "-o", obj,
-               "-Wall", "-Wno-unused-function"] + os.environ.get("ZN_CFLAGS", "").split()
+        if src.endswith(".cc"):
+            cmd = [hipcc, "-x", "c++", "-O3", "-std=c++17", "-fPIC", "-c", src, "-o", obj, "-Wall"]
+        else:
+            cmd = [hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-c", src, "-o", obj,
+                   "-Wall", "-Wno-unused-function"] + os.environ.get("ZN_CFLAGS", "").split()
         if verbose:
             print(" ".join(cmd))
         procs.append((subprocess.Popen(cmd), cmd))

@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <chrono>
 #include <string>
 #include <vector>
 #include <unordered_map>
@@ -21,6 +22,8 @@ void set_fused_abl(int v);
 }  // namespace zn
 
 using namespace zn;
+extern "C" void zn_rounds_totals(const uint64_t *len, const uint8_t *skip, size_t n, uint64_t out[8]);  // host/extents.cpp
+extern "C" void zn_rows_extents(const uint64_t *bo, const uint64_t *bs, const uint64_t *oo, const uint64_t *us, size_t n, uint64_t out[8]);  // host/extents.cpp
 
 #define HIPCHK(ctx, call)                                                                         \
     do {                                                                                          \
@@ -30,6 +33,24 @@ using namespace zn;
             return ZNIPPY_E_HIP;                                                                  \
         }                                                                                         \
     } while (0)
+
+// diagnostic (ZNIPPY_TDBG): wall time of the sections of a table constructor
+struct TDbg {
+    bool on;
+    const char *what;
+    std::chrono::steady_clock::time_point t;
+    std::string line;
+    TDbg(bool on_, const char *what_) : on(on_), what(what_), t(std::chrono::steady_clock::now()) {}
+    void mark(const char *name) {
+        if (!on) return;
+        const auto now = std::chrono::steady_clock::now();
+        char b[96];
+        snprintf(b, sizeof b, " %s=%.3f", name, std::chrono::duration<double, std::milli>(now - t).count());
+        line += b;
+        t = now;
+    }
+    ~TDbg() { if (on) fprintf(stderr, "[znippy tdbg] %s:%s ms\n", what, line.c_str()); }
+};
 
 struct KTime {
     const char *name;
@@ -89,7 +110,7 @@ struct znippy_ctx {
         int dbg = 0;             // ZNIPPY_DBG bit set (FusedArgs::dbg)
         unsigned lds_pad = 0;    // ZNIPPY_LDS_PAD
         bool no_block_items = false, no_fused_blocks = false, ddbg = false, edbg = false, no_fused_store = false,
-             nohash = false, no_roles = false, no_fz = false, fz_only = false, no_bx = false;
+             nohash = false, no_roles = false, no_fz = false, fz_only = false, no_bx = false, tdbg = false;
         // ZNIPPY_ROLES_MIN: small tiles from which the role-split persistent kernel takes the table (0 = never; below
         // a few CU-fillings a persistent grid only adds start-up latency)
         unsigned roles_min = 2048;
@@ -117,6 +138,7 @@ static void read_switches(znippy_ctx *ctx) {
     ctx->sw.nohash = on("ZNIPPY_NOHASH");
     ctx->sw.no_roles = on("ZNIPPY_NO_ROLES");
     ctx->sw.no_fz = on("ZNIPPY_NO_FZ");
+    ctx->sw.tdbg = on("ZNIPPY_TDBG");
     ctx->sw.no_bx = on("ZNIPPY_NO_BX");
     if (const char *e = getenv("ZNIPPY_BX_BIG")) ctx->sw.bx_big = (unsigned)atoi(e);  // A/B: foreign frames through the round-2 paths (serial decoder + wave-per-block two-phase path)
     if (const char *lv = getenv("ZNIPPY_LEVEL")) { const int v = atoi(lv); if (v >= 1 && v <= 22) ctx->level = v; }  // initial level of every context (tests, A/B runs)
@@ -218,7 +240,9 @@ struct PlanBuf {
 
 // Greedy tile plan over unit lengths: whole small units are packed until a wave's 64 lanes are
 // full; a unit with more than 64 leaves becomes ceil(leaves/64) slice tiles + one BigUnit.
-static void build_plan(const uint64_t *len, uint32_t n, PlanBuf &p) {
+template <class LenOf>
+static void build_plan(LenOf len_of, uint32_t n, PlanBuf &p) {
+    p.tiles.reserve((size_t)n / 4 + 16);
     uint32_t cur_first = 0, cur_units = 0, cur_leaves = 0;
     auto flush = [&]() {
         if (cur_units) p.tiles.push_back(Tile{cur_first, cur_units, 0, cur_leaves, 0, 0});
@@ -226,7 +250,8 @@ static void build_plan(const uint64_t *len, uint32_t n, PlanBuf &p) {
         cur_leaves = 0;
     };
     for (uint32_t u = 0; u < n; u++) {
-        uint64_t leaves64 = len[u] ? (len[u] + 1023) >> 10 : 1;
+        const uint64_t len_u = len_of(u);
+        uint64_t leaves64 = len_u ? (len_u + 1023) >> 10 : 1;
         if (leaves64 > 64) {
             flush();
             uint32_t n_cvs = (uint32_t)((leaves64 + 63) / 64);
@@ -245,6 +270,20 @@ static void build_plan(const uint64_t *len, uint32_t n, PlanBuf &p) {
             if (!cur_units) cur_first = u;
             cur_units++;
             cur_leaves += leaves;
+            // a run of units of this same size (archives of fixed-size chunks: every BASELINE config): whole tiles at once —
+            // exactly the tiles the unit-by-unit rule above would cut
+            if (cur_units == 1 && u + 1 < n && len_of(u + 1) == len_u) {
+                uint32_t v = u + 1;
+                while (v < n && len_of(v) == len_u) v++;
+                const uint32_t per = std::min<uint32_t>(64 / leaves, 64), run = v - u, full = run / per;
+                if (full >= 1) {
+                    for (uint32_t t = 0; t < full; t++) p.tiles.push_back(Tile{u + t * per, per, 0, per * leaves, 0, 0});
+                    cur_units = 0; cur_leaves = 0;
+                    const uint32_t rest = run - full * per;
+                    if (rest) { cur_first = u + full * per; cur_units = rest; cur_leaves = rest * leaves; }
+                    u = v - 1;
+                }
+            }
         }
     }
     flush();
@@ -299,7 +338,7 @@ struct znippy_rows {
     uint32_t n = 0;
     uint32_t n_compressed = 0;
     uint64_t *blob_off = nullptr, *blob_size = nullptr, *usize = nullptr, *out_off = nullptr;
-    uint8_t *compressed = nullptr, *checksum = nullptr;
+    uint8_t *compressed = nullptr, *checksum = nullptr, *d_bitmap = nullptr;
     // One allocation, cleared (or preset) by ONE stream operation per run: [counters 8 x u64][hand-over counts 16 x u32]
     // [work cursors 16 x u32][pad 64 B][status n x i32]
     uint8_t *ctl = nullptr;
@@ -324,6 +363,10 @@ struct znippy_rows {
     // Host copies of the columns a run is validated against (one pass per distinct (blob_base, blob_cap, out_cap)):
     // a row whose blob lies outside the blob region, or whose bytes would land outside the output region, gets its
     // status from the host (status_init) and no kernel touches it — a crafted index is an error code, not a fault.
+    // extents of the table's rows (one pass at creation): a run whose regions contain them has no bad row; otherwise the
+    // columns come back from the device for the per-row pass (h_*: filled then)
+    uint64_t ext_min_bo = 0, ext_max_bend = 0, ext_max_oend = 0;
+    bool ext_wrap = false;
     std::vector<uint64_t> h_blob_off, h_blob_size, h_len, h_out_off;
     uint64_t blob_cap = ~0ull;  // size of the caller's blob region (znippy_rows_set_blob_cap); ~0 = not declared
     uint64_t val_base = 0, val_bcap = 0, val_ocap = 0;
@@ -370,8 +413,8 @@ struct znippy_rounds {
     uint64_t *src_off = nullptr, *len = nullptr;
     uint8_t *skip = nullptr;
     uint32_t *digests = nullptr;
-    std::vector<uint64_t> h_len, h_off;
-    std::vector<uint8_t> h_skip;
+    std::vector<uint8_t> h_skip;  // empty: no round is a store-path round
+    void *plan_scratch[3] = {nullptr, nullptr, nullptr};  // per-round prefix sums of the plan kernels (freed with the table)
     uint64_t in_bytes = 0, enc_bytes = 0;  // all rounds / rounds that go through the encoder
     bool all_stored_aligned = false;       // every round is a skip round and every blob offset will be a multiple of 16
     uint64_t blob_bound = 0;
@@ -502,6 +545,82 @@ static int ensure_encoder(znippy_ctx *ctx) {
         return ZNIPPY_E_NOMEM;
     }
     return ZNIPPY_OK;
+}
+
+// rows: the bit column -> one byte per row, and a stored row's length = its blob (the reference hashes and writes the
+// blob bytes of a stored row and never looks at the index's uncompressed_size for it, decompress.rs:L143-166)
+__global__ void k_rows_fixup(const uint8_t *bitmap, uint64_t row_begin, uint32_t n, uint8_t *comp, uint64_t *usize, const uint64_t *blob_size) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t row = row_begin + i;
+    const uint8_t c = bitmap ? (bitmap[row >> 3] >> (row & 7)) & 1 : 1;
+    comp[i] = c;
+    if (!c) usize[i] = blob_size[i];
+}
+
+// ---- the encoder plan of a Round table, built on the device (znippy_rounds_create) ----
+// One item per output piece, in round order: an encoded round is ceil(len / 128 KiB) blocks (item.prov = the block's
+// provisional slot), a store-path round ceil(len / 64 KiB) pieces (item.prov = the piece's offset inside the round).
+struct RoundCount { uint32_t items, small, wide; uint64_t prov; };
+__device__ __forceinline__ RoundCount round_count(uint64_t L, uint32_t sk) {
+    RoundCount c;
+    if (sk) { c.items = (uint32_t)(L ? (L + SKIP_PIECE - 1) / SKIP_PIECE : 1); c.small = 0; c.wide = 0; c.prov = 0; return c; }
+    const uint32_t nb = (uint32_t)(L ? (L + BLOCK_BYTES - 1) / BLOCK_BYTES : 1);
+    const uint32_t tail = (uint32_t)(L - (uint64_t)(nb - 1) * BLOCK_BYTES), tw = tail > 16 * 1024 ? 1u : 0u;
+    c.items = nb; c.wide = nb - 1 + tw; c.small = 1 - tw;
+    c.prov = (uint64_t)(nb - 1) * enc_slot_bytes(BLOCK_BYTES) + enc_slot_bytes(tail);
+    return c;
+}
+// exclusive prefix sums of the four per-round counts: ONE workgroup, every thread a contiguous run of rounds
+__global__ __launch_bounds__(1024) void k_rounds_scan(const uint64_t *len, const uint8_t *skip, uint32_t n, uint32_t *first_item, uint32_t *small_at,
+                                                       uint32_t *wide_at, uint64_t *prov_at) {
+    __shared__ uint32_t s_i[1024], s_s[1024], s_w[1024];
+    __shared__ uint64_t s_p[1024];
+    const uint32_t t = threadIdx.x, per = (n + 1023) / 1024, lo = t * per, hi = lo + per < n ? lo + per : n;
+    uint32_t ai = 0, as = 0, aw = 0;
+    uint64_t ap = 0;
+    for (uint32_t i = lo; i < hi; i++) { const RoundCount c = round_count(len[i], skip ? skip[i] : 0); ai += c.items; as += c.small; aw += c.wide; ap += c.prov; }
+    s_i[t] = ai; s_s[t] = as; s_w[t] = aw; s_p[t] = ap;
+    __syncthreads();
+    for (uint32_t d = 1; d < 1024; d <<= 1) {  // inclusive scan over the threads' sums
+        uint32_t bi = 0, bs = 0, bw = 0; uint64_t bp = 0;
+        if (t >= d) { bi = s_i[t - d]; bs = s_s[t - d]; bw = s_w[t - d]; bp = s_p[t - d]; }
+        __syncthreads();
+        s_i[t] += bi; s_s[t] += bs; s_w[t] += bw; s_p[t] += bp;
+        __syncthreads();
+    }
+    ai = s_i[t] - ai; as = s_s[t] - as; aw = s_w[t] - aw; ap = s_p[t] - ap;  // exclusive: what lies in front of this thread's run
+    for (uint32_t i = lo; i < hi; i++) {
+        const RoundCount c = round_count(len[i], skip ? skip[i] : 0);
+        first_item[i] = ai; small_at[i] = as; wide_at[i] = aw; prov_at[i] = ap;
+        ai += c.items; as += c.small; aw += c.wide; ap += c.prov;
+    }
+}
+__global__ void k_rounds_fill(const uint64_t *len, const uint8_t *skip, uint32_t n, const uint32_t *first_item, const uint32_t *small_at,
+                              const uint32_t *wide_at, const uint64_t *prov_at, EncItem *items, uint32_t *plen, uint32_t *ord_small, uint32_t *ord_wide) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t L = len[i];
+    const uint32_t at = first_item[i];
+    if (skip && skip[i]) {
+        const uint32_t np = (uint32_t)(L ? (L + SKIP_PIECE - 1) / SKIP_PIECE : 1);
+        for (uint32_t k = 0; k < np; k++) {
+            const uint64_t o = (uint64_t)k * SKIP_PIECE;
+            items[at + k] = EncItem{i, k, np, ITEM_SKIP | (k == 0 ? ITEM_FIRST : 0u), o};
+            plen[at + k] = (uint32_t)(L - o < SKIP_PIECE ? L - o : SKIP_PIECE);
+        }
+        return;
+    }
+    const uint32_t nb = (uint32_t)(L ? (L + BLOCK_BYTES - 1) / BLOCK_BYTES : 1);
+    uint64_t prov = prov_at[i];
+    uint32_t so = small_at[i], wo = wide_at[i];
+    for (uint32_t k = 0; k < nb; k++) {
+        const uint32_t bl = (uint32_t)(L - (uint64_t)k * BLOCK_BYTES < BLOCK_BYTES ? L - (uint64_t)k * BLOCK_BYTES : BLOCK_BYTES);
+        if (bl > 16 * 1024) ord_wide[wo++] = at + k; else ord_small[so++] = at + k;
+        items[at + k] = EncItem{i, k, nb, k == 0 ? ITEM_FIRST : 0u, prov};
+        plen[at + k] = 0;
+        prov += enc_slot_bytes(bl);
+    }
 }
 
 extern "C" {
@@ -704,7 +823,7 @@ void znippy_rows_destroy(znippy_rows *r) {
                     r->ctl, r->digests, r->corrupt, r->list_a, r->pending,
                     r->cand_row, r->cand_base, r->cand_nblocks, r->fz_base, r->fz_cap, r->fz_it_cand, r->fz_nb, r->fz_work, r->fz_items, r->item_row, r->item_k, r->item_src, r->row_flag, r->pending2,
                     r->bt_tile, r->bt_item, r->tile_done, r->item_done, r->todo, r->status_init, r->slow_list,
-                    r->bx_cand_row, r->bx_cand_base, r->bx_cand_nb, r->bx_huf_list, r->bx_seq_list, r->bx_items, r->bx_prep};
+                    r->bx_cand_row, r->bx_cand_base, r->bx_cand_nb, r->bx_huf_list, r->bx_seq_list, r->bx_items, r->bx_prep, r->d_bitmap};
     for (void *p : ptrs)
         tfree(r->ctx, p);
     if (r->h_counters) {
@@ -727,40 +846,43 @@ int znippy_rows_create(znippy_ctx *ctx, const uint64_t *blob_offset, const uint6
         return ZNIPPY_E_INVAL;
     if (row_end - row_begin >= 0xFFFFFFF0ull) return ZNIPPY_E_INVAL;
     HIPCHK(ctx, hipSetDevice(ctx->device));
+    TDbg td(ctx->sw.tdbg, "rows_create");
     znippy_rows *r = new znippy_rows();
     r->ctx = ctx;
     ctx->live_tables++;
     r->row_begin = row_begin;
     r->n = (uint32_t)(row_end - row_begin);
     const uint32_t n = r->n;
-    std::vector<uint8_t> comp(n);
-    r->h_blob_off.assign(blob_offset + row_begin, blob_offset + row_end);
-    r->h_blob_size.assign(blob_size + row_begin, blob_size + row_end);
-    r->h_out_off.assign(out_offset + row_begin, out_offset + row_end);
-    r->h_len.assign(uncompressed_size + row_begin, uncompressed_size + row_end);
-    for (uint32_t i = 0; i < n; i++) {
-        uint64_t row = row_begin + i;
-        comp[i] = compressed_bitmap ? (compressed_bitmap[row >> 3] >> (row & 7)) & 1 : 1;
-        r->n_compressed += comp[i];
-        if (!comp[i] && (out_offset[row] & 15)) r->odd_out = true;
-        // a stored row IS its blob: the reference hashes and writes the blob bytes and never looks at the index's
-        // uncompressed_size for it (decompress.rs:L143-166: `&read_buf`), so neither does this table
-        if (!comp[i]) r->h_len[i] = r->h_blob_size[i];
+    const uint64_t *const bo_in = blob_offset + row_begin, *const bs_in = blob_size + row_begin, *const us_in = uncompressed_size + row_begin,
+                   *const oo_in = out_offset + row_begin;
+    bool allc = true;  // every row compressed (the usual archive): the per-row passes skip the bit column
+    if (compressed_bitmap) {
+        uint64_t row = row_begin;
+        for (; row < row_end && (row & 7); row++) allc &= (compressed_bitmap[row >> 3] >> (row & 7)) & 1;
+        for (; row + 8 <= row_end && allc; row += 8) allc &= compressed_bitmap[row >> 3] == 0xFF;
+        for (; row < row_end && allc; row++) allc &= (compressed_bitmap[row >> 3] >> (row & 7)) & 1;
     }
-    uncompressed_size = r->h_len.data() - row_begin;  // from here on: the effective lengths
+    auto comp_of = [&](uint32_t i) -> uint32_t { if (allc) return 1u; const uint64_t row = row_begin + i; return (compressed_bitmap[row >> 3] >> (row & 7)) & 1u; };
+    // a stored row IS its blob (see k_rows_fixup): its effective length is blob_size
+    auto len_of = [&](uint32_t i) -> uint64_t { return comp_of(i) ? us_in[i] : bs_in[i]; };
     int rc = ZNIPPY_OK;
-    if ((rc = dev_upload(ctx, &r->blob_off, blob_offset + row_begin, n)) ||
-        (rc = dev_upload(ctx, &r->blob_size, blob_size + row_begin, n)) ||
-        (rc = dev_upload(ctx, &r->usize, uncompressed_size + row_begin, n)) ||
-        (rc = dev_upload(ctx, &r->out_off, out_offset + row_begin, n)) ||
-        (rc = dev_upload(ctx, &r->compressed, comp.data(), n))) {
+    // the columns as they are (the device derives the byte-per-row flags and the stored rows' lengths)
+    uint8_t *&d_bitmap = r->d_bitmap;  // (kept until the table goes: k_rows_fixup reads it on the stream, uploads are not stream-ordered)
+    const uint64_t bm0 = row_begin >> 3, bm1 = (row_end + 7) >> 3;
+    if ((rc = dev_upload(ctx, &r->blob_off, bo_in, n)) || (rc = dev_upload(ctx, &r->blob_size, bs_in, n)) ||
+        (rc = dev_upload(ctx, &r->usize, us_in, n)) || (rc = dev_upload(ctx, &r->out_off, oo_in, n)) ||
+        (compressed_bitmap && (rc = dev_upload(ctx, &d_bitmap, compressed_bitmap + bm0, (size_t)(bm1 - bm0)))) ||
+        tmalloc(ctx, &r->compressed, std::max<size_t>(n, 16)) != hipSuccess) {
         znippy_rows_destroy(r);
-        return rc;
+        return rc ? rc : ZNIPPY_E_NOMEM;
     }
+    if (n) hipLaunchKernelGGL(k_rows_fixup, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, d_bitmap, row_begin - 8 * bm0, n, r->compressed, r->usize, r->blob_size);
+    td.mark("columns_h2d");
     if (checksum && (rc = dev_upload(ctx, &r->checksum, checksum + 32 * row_begin, (size_t)32 * n))) {
         znippy_rows_destroy(r);
         return rc;
     }
+    td.mark("checksum_h2d");
     r->corrupt_cap = std::max<uint32_t>(n, 1);
     r->ctl_bytes = znippy_rows::CTL_HEAD + std::max<size_t>(4 * (size_t)n, 16);
     if (tmalloc(ctx, &r->ctl, r->ctl_bytes) != hipSuccess ||
@@ -775,12 +897,15 @@ int znippy_rows_create(znippy_ctx *ctx, const uint64_t *blob_offset, const uint6
     r->pending_count = reinterpret_cast<uint32_t *>(r->ctl + 64);
     r->cursor = reinterpret_cast<uint32_t *>(r->ctl + 128);
     r->status = reinterpret_cast<int32_t *>(r->ctl + znippy_rows::CTL_HEAD);
+    td.mark("allocs");
     PlanBuf p;
-    build_plan(uncompressed_size + row_begin, n, p);
+    build_plan(len_of, n, p);
+    td.mark("plan");
     if ((rc = upload_plan(ctx, p, r->plan))) {
         znippy_rows_destroy(r);
         return rc;
     }
+    td.mark("plan_h2d");
     for (const Tile &t : p.tiles) r->n_small_tiles += t.n_units != 0;
     if (r->n_small_tiles && tmalloc(ctx, &r->slow_list, 4 * (size_t)p.tiles.size()) != hipSuccess) {
         znippy_rows_destroy(r);
@@ -790,29 +915,57 @@ int znippy_rows_create(znippy_ctx *ctx, const uint64_t *blob_offset, const uint6
     // item), the others go straight to the general decoder
     constexpr uint64_t BLK = 128 * 1024;
     std::vector<uint32_t> la, cand_row, cand_base, cand_nb, item_row, item_k, fz_base, fz_cap, fz_it_cand;
-    uint64_t big_bytes = 0, big_blob = 0, n_big = 0;
-    for (uint32_t i = 0; i < n; i++) {
-        const uint64_t us = uncompressed_size[row_begin + i];
-        if (!comp[i] || us <= 64 * 1024) continue;
-        big_bytes += us;
-        big_blob += blob_size[row_begin + i];
-        n_big++;
-        const uint64_t nb = (us + BLK - 1) / BLK;
-        if (nb >= 2 && us < 0xFFFFFFFFull && item_row.size() + nb < 0x7FFFFFFFull && !ctx->sw.no_block_items) {
-            cand_row.push_back(i);
-            cand_base.push_back((uint32_t)item_row.size());
-            cand_nb.push_back((uint32_t)nb);
-            for (uint32_t k = 0; k < nb; k++) { item_row.push_back(i); item_k.push_back(k); }
-            if (!ctx->sw.no_fz && ctx->sw.no_bx && fz_it_cand.size() + 2 * nb + 8 < 0x7FFFFFFFull) {
-                const uint32_t cap = (uint32_t)(2 * nb + 8);
-                fz_base.push_back((uint32_t)fz_it_cand.size());
-                fz_cap.push_back(cap);
-                fz_it_cand.insert(fz_it_cand.end(), cap, (uint32_t)cand_row.size() - 1);
-                r->fz_bytes += us;
-            } else { fz_base.push_back(0); fz_cap.push_back(0); }
-        } else la.push_back(i);
+    uint64_t big_bytes = 0, big_blob = 0, n_big = 0, nblk = 0;
+    // ONE pass over the caller's columns: the flags the runs need, the extents a run is validated against (rows_validate:
+    // a table whose extents fit the run's regions has no bad row — the per-row pass is for the others), and the big rows
+    bool scan_rows = true;
+    if (allc) {  // the vectorised pass; the row-by-row one below only if the table has big rows
+        uint64_t e[8];
+        zn_rows_extents(bo_in, bs_in, oo_in, us_in, n, e);
+        if (e[6] == 0) {
+            scan_rows = false;
+            r->ext_min_bo = e[0]; r->ext_max_bend = e[1]; r->ext_max_oend = e[2]; r->ext_wrap = e[3] != 0;
+            r->n_compressed = n; r->bx_bytes = e[4]; nblk = e[5];
+        }
+    }
+    if (scan_rows) {
+        uint64_t min_bo = ~0ull, max_bend = 0, max_oend = 0;
+        bool wrap = false;
+        for (uint32_t i = 0; i < n; i++) {
+            const uint32_t c = comp_of(i);
+            const uint64_t bo = bo_in[i], bs = bs_in[i], oo = oo_in[i], us = c ? us_in[i] : bs;
+            r->n_compressed += c;
+            if (!c && (oo & 15)) r->odd_out = true;
+            min_bo = std::min(min_bo, bo);
+            wrap |= bo + bs < bo || oo + us < oo;
+            max_bend = std::max(max_bend, bo + bs);
+            max_oend = std::max(max_oend, oo + us);
+            if (!c) continue;
+            nblk += us ? (us + BLK - 1) / BLK : 1;
+            r->bx_bytes += us;
+            if (us <= 64 * 1024) continue;
+            big_bytes += us;
+            big_blob += bs;
+            n_big++;
+            const uint64_t nb = (us + BLK - 1) / BLK;
+            if (nb >= 2 && us < 0xFFFFFFFFull && item_row.size() + nb < 0x7FFFFFFFull && !ctx->sw.no_block_items) {
+                cand_row.push_back(i);
+                cand_base.push_back((uint32_t)item_row.size());
+                cand_nb.push_back((uint32_t)nb);
+                for (uint32_t k = 0; k < nb; k++) { item_row.push_back(i); item_k.push_back(k); }
+                if (!ctx->sw.no_fz && ctx->sw.no_bx && fz_it_cand.size() + 2 * nb + 8 < 0x7FFFFFFFull) {
+                    const uint32_t cap = (uint32_t)(2 * nb + 8);
+                    fz_base.push_back((uint32_t)fz_it_cand.size());
+                    fz_cap.push_back(cap);
+                    fz_it_cand.insert(fz_it_cand.end(), cap, (uint32_t)cand_row.size() - 1);
+                    r->fz_bytes += us;
+                } else { fz_base.push_back(0); fz_cap.push_back(0); }
+            } else la.push_back(i);
+        }
+        r->ext_min_bo = min_bo; r->ext_max_bend = max_bend; r->ext_max_oend = max_oend; r->ext_wrap = wrap;
     }
     r->n_list_a = (uint32_t)la.size();
+    td.mark("big_rows");
     if (r->n_compressed) {
         // what the block-item path, the batch path and the serial decoder tell each other about a row, and the serial
         // decoder's list
@@ -822,9 +975,6 @@ int znippy_rows_create(znippy_ctx *ctx, const uint64_t *blob_offset, const uint6
             return ZNIPPY_E_NOMEM;
         }
         if (!ctx->sw.no_bx) {
-            uint64_t nblk = 0;
-            for (uint32_t i = 0; i < n; i++)
-                if (comp[i]) { const uint64_t us = uncompressed_size[row_begin + i]; nblk += us ? (us + BLK - 1) / BLK : 1; r->bx_bytes += us; }
             const uint64_t cap = nblk + nblk / 2 + 1024;  // a writer may split blocks: half as many again, shared by all frames
             if (cap < 0x7FFFFFFFull) {
                 r->bx_slots = r->n_compressed;
@@ -905,6 +1055,7 @@ int znippy_rows_create(znippy_ctx *ctx, const uint64_t *blob_offset, const uint6
         znippy_rows_destroy(r);
         return ZNIPPY_E_NOMEM;
     }
+    td.mark("rest");
     *out = r;
     return ZNIPPY_OK;
 }
@@ -922,7 +1073,16 @@ static int rows_validate(znippy_ctx *ctx, znippy_rows *r, uint64_t blob_base, ui
     std::vector<int32_t> init;
     uint32_t bad = 0;
     const uint64_t bcap = r->blob_cap;
-    for (uint32_t i = 0; i < r->n; i++) {
+    const bool fits = !r->ext_wrap && (r->n == 0 || (r->ext_min_bo >= blob_base && (bcap == ~0ull || r->ext_max_bend - blob_base <= bcap) && r->ext_max_oend <= out_cap));
+    if (!fits && r->h_blob_off.empty() && r->n) {  // the columns, for the per-row verdicts (the device copies hold the effective lengths)
+        r->h_blob_off.resize(r->n); r->h_blob_size.resize(r->n); r->h_len.resize(r->n); r->h_out_off.resize(r->n);
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        HIPCHK(ctx, hipMemcpy(r->h_blob_off.data(), r->blob_off, 8 * (size_t)r->n, hipMemcpyDeviceToHost));
+        HIPCHK(ctx, hipMemcpy(r->h_blob_size.data(), r->blob_size, 8 * (size_t)r->n, hipMemcpyDeviceToHost));
+        HIPCHK(ctx, hipMemcpy(r->h_len.data(), r->usize, 8 * (size_t)r->n, hipMemcpyDeviceToHost));
+        HIPCHK(ctx, hipMemcpy(r->h_out_off.data(), r->out_off, 8 * (size_t)r->n, hipMemcpyDeviceToHost));
+    }
+    for (uint32_t i = 0; i < (fits ? 0u : r->n); i++) {
         const uint64_t bo = r->h_blob_off[i], bs = r->h_blob_size[i], len = r->h_len[i], oo = r->h_out_off[i];
         int code = 0;
         if (bo < blob_base) code = ZNIPPY_E_CORRUPT;
@@ -1372,7 +1532,8 @@ void znippy_rounds_destroy(znippy_rounds *r) {
         event_give(r->ctx, r->ev_res[k]);
     }
     void *ptrs[] = {r->src_off, r->len, r->skip, r->res_m[0], r->res_m[1], r->items, r->piece_len, r->piece_len_init,
-                    r->piece_start, r->local_excl, r->block_tot, r->first_item, r->stored, r->order_small, r->order_wide, r->retry_list, r->retry_count};
+                    r->piece_start, r->local_excl, r->block_tot, r->first_item, r->stored, r->order_small, r->order_wide, r->retry_list, r->retry_count,
+                    r->plan_scratch[0], r->plan_scratch[1], r->plan_scratch[2]};
     pinned_give(r->ctx, r->h_stored, r->h_stored_cap);
     for (void *p : ptrs)
         tfree(r->ctx, p);
@@ -1391,24 +1552,23 @@ int znippy_rounds_create(znippy_ctx *ctx, const uint64_t *src_offset, const uint
     r->ctx = ctx;
     ctx->live_tables++;
     r->n = (uint32_t)n;
-    r->h_len.assign(len, len + n);
-    r->h_off.assign(src_offset, src_offset + n);
-    r->h_skip.assign(n, 0);
-    if (skip) r->h_skip.assign(skip, skip + n);
-    bool odd_len = false;
-    for (uint64_t i = 0; i < n; i++) {
-        r->blob_bound += r->h_skip[i] ? len[i] : znippy_compress_bound(len[i]);
-        r->in_bytes += len[i];
-        if (!r->h_skip[i]) r->enc_bytes += len[i];
-        if (i + 1 < n && (len[i] & 15)) odd_len = true;
-    }
-    r->all_stored_aligned = n > 0 && r->enc_bytes == 0 && !odd_len;
+    TDbg td(ctx->sw.tdbg, "rounds_create");
+    if (skip) r->h_skip.assign(skip, skip + n);  // (results: which rounds are stored; empty = none)
+    uint64_t tot[8];
+    zn_rounds_totals(len, skip, n, tot);  // sizes of the device arrays; the arrays themselves are filled on the device
+    r->blob_bound = tot[4]; r->in_bytes = tot[5]; r->enc_bytes = tot[6];
+    r->all_stored_aligned = n > 0 && r->enc_bytes == 0 && !tot[7];
+    if (tot[0] >= 0xFFFFFFF0ull) { znippy_rounds_destroy(r); return ZNIPPY_E_INVAL; }
+    r->n_items = (uint32_t)tot[0]; r->prov_bytes = tot[1]; r->n_small = (uint32_t)tot[2]; r->n_wide = (uint32_t)tot[3];
+    td.mark("totals");
     int rc;
     if ((rc = dev_upload(ctx, &r->src_off, src_offset, n)) || (rc = dev_upload(ctx, &r->len, len, n)) ||
-        (rc = dev_upload(ctx, &r->skip, r->h_skip.data(), n))) {
+        (skip ? (rc = dev_upload(ctx, &r->skip, skip, n)) : (tmalloc(ctx, &r->skip, std::max<size_t>(n, 16)) != hipSuccess ? (rc = ZNIPPY_E_NOMEM) : 0))) {
         znippy_rounds_destroy(r);
         return rc;
     }
+    if (!skip && n) HIPCHK(ctx, hipMemsetAsync(r->skip, 0, n, ctx->stream));
+    td.mark("columns_h2d");
     r->res_bytes = 16 + (size_t)n * (8 + 8 + 32);
     for (int k = 0; k < 2; k++)
         if (tmalloc(ctx, &r->res_m[k], r->res_bytes) != hipSuccess ||
@@ -1418,71 +1578,47 @@ int znippy_rounds_create(znippy_ctx *ctx, const uint64_t *src_offset, const uint
             return ZNIPPY_E_NOMEM;
         }
     rounds_select(r, 0);
+    td.mark("slabs");
     PlanBuf p;
-    build_plan(len, (uint32_t)n, p);
+    build_plan([&](uint32_t u) { return len[u]; }, (uint32_t)n, p);
     if ((rc = upload_plan(ctx, p, r->plan))) {
         znippy_rounds_destroy(r);
         return rc;
     }
-    // encoder plan: one item per output piece, in round order
-    std::vector<EncItem> items;
-    std::vector<uint32_t> plen, first_item(n, 0), ord_small, ord_wide;
-    for (uint64_t i = 0; i < n; i++) {
-        first_item[i] = (uint32_t)items.size();
-        if (r->h_skip[i]) {
-            uint64_t L = len[i];
-            uint32_t np = (uint32_t)std::max<uint64_t>(1, (L + SKIP_PIECE - 1) / SKIP_PIECE);
-            for (uint32_t k = 0; k < np; k++) {
-                uint64_t o = (uint64_t)k * SKIP_PIECE;
-                items.push_back(EncItem{(uint32_t)i, k, np, ITEM_SKIP | (k == 0 ? ITEM_FIRST : 0), o});
-                plen.push_back((uint32_t)std::min<uint64_t>(SKIP_PIECE, L - o));
-            }
-        } else {
-            uint64_t L = len[i];
-            uint32_t nb = (uint32_t)std::max<uint64_t>(1, (L + BLOCK_BYTES - 1) / BLOCK_BYTES);
-            for (uint32_t k = 0; k < nb; k++) {
-                uint32_t bl = (uint32_t)std::min<uint64_t>(BLOCK_BYTES, L - (uint64_t)k * BLOCK_BYTES);
-                (bl > 16 * 1024 ? ord_wide : ord_small).push_back((uint32_t)items.size());
-                items.push_back(EncItem{(uint32_t)i, k, nb, k == 0 ? ITEM_FIRST : 0u, r->prov_bytes});
-                plen.push_back(0);
-                r->prov_bytes += enc_slot_bytes(bl);
-            }
-        }
-    }
-    if (items.size() >= 0xFFFFFFF0ull) { znippy_rounds_destroy(r); return ZNIPPY_E_INVAL; }
-    r->n_items = (uint32_t)items.size();
-    r->n_small = (uint32_t)ord_small.size();
-    r->n_wide = (uint32_t)ord_wide.size();
-    if ((rc = dev_upload(ctx, &r->order_small, ord_small.data(), ord_small.size())) ||
-        (rc = dev_upload(ctx, &r->order_wide, ord_wide.data(), ord_wide.size()))) {
-        znippy_rounds_destroy(r);
-        return rc;
-    }
-    if (tmalloc(ctx, &r->retry_list, std::max<size_t>(4 * (size_t)r->n_small, 16)) != hipSuccess || tmalloc(ctx, &r->retry_count, 64) != hipSuccess) {
-        znippy_rounds_destroy(r);
-        return ZNIPPY_E_NOMEM;
-    }
+    td.mark("hash_plan");
+    // encoder plan: one item per output piece, in round order — counted, scanned and filled on the device
     const size_t ni = std::max<size_t>(r->n_items, 1), nsb = (ni + 255) / 256;
-    if ((rc = dev_upload(ctx, &r->first_item, first_item.data(), first_item.size())) ||
+    uint32_t *small_at = nullptr, *wide_at = nullptr;
+    uint64_t *prov_at = nullptr;
+    if (tmalloc(ctx, &r->first_item, std::max<size_t>(4 * (size_t)n, 16)) != hipSuccess || tmalloc(ctx, &small_at, std::max<size_t>(4 * (size_t)n, 16)) != hipSuccess ||
+        tmalloc(ctx, &wide_at, std::max<size_t>(4 * (size_t)n, 16)) != hipSuccess || tmalloc(ctx, &prov_at, std::max<size_t>(8 * (size_t)n, 16)) != hipSuccess ||
+        tmalloc(ctx, &r->order_small, std::max<size_t>(4 * (size_t)r->n_small, 16)) != hipSuccess ||
+        tmalloc(ctx, &r->order_wide, std::max<size_t>(4 * (size_t)r->n_wide, 16)) != hipSuccess ||
+        tmalloc(ctx, &r->retry_list, std::max<size_t>(4 * (size_t)r->n_small, 16)) != hipSuccess || tmalloc(ctx, &r->retry_count, 64) != hipSuccess ||
         tmalloc(ctx, &r->stored, std::max<size_t>(n, 16)) != hipSuccess ||
-        !(r->h_stored = (uint8_t *)pinned_take(ctx, std::max<size_t>(n, 16), &r->h_stored_cap))) {
-        znippy_rounds_destroy(r);
-        return rc ? rc : ZNIPPY_E_NOMEM;
-    }
-    if ((rc = dev_upload(ctx, &r->items, items.data(), items.size())) ||
-        (rc = dev_upload(ctx, &r->piece_len_init, plen.data(), plen.size()))) {
-        znippy_rounds_destroy(r);
-        return rc;
-    }
-    if (tmalloc(ctx, &r->piece_len, 4 * ni) != hipSuccess || tmalloc(ctx, &r->piece_start, 8 * ni) != hipSuccess ||
-        tmalloc(ctx, &r->local_excl, 8 * ni) != hipSuccess || tmalloc(ctx, &r->block_tot, 8 * nsb) != hipSuccess ||
-        false) {
+        !(r->h_stored = (uint8_t *)pinned_take(ctx, std::max<size_t>(n, 16), &r->h_stored_cap)) ||
+        tmalloc(ctx, &r->items, sizeof(EncItem) * ni) != hipSuccess || tmalloc(ctx, &r->piece_len_init, 4 * ni) != hipSuccess ||
+        tmalloc(ctx, &r->piece_len, 4 * ni) != hipSuccess || tmalloc(ctx, &r->piece_start, 8 * ni) != hipSuccess ||
+        tmalloc(ctx, &r->local_excl, 8 * ni) != hipSuccess || tmalloc(ctx, &r->block_tot, 8 * nsb) != hipSuccess) {
+        tfree(ctx, small_at); tfree(ctx, wide_at); tfree(ctx, prov_at);
         znippy_rounds_destroy(r);
         return ZNIPPY_E_NOMEM;
     }
+    if (n) {
+        hipLaunchKernelGGL(k_rounds_scan, dim3(1), dim3(1024), 0, ctx->stream, r->len, skip ? r->skip : (const uint8_t *)nullptr, (uint32_t)n, r->first_item,
+                           small_at, wide_at, prov_at);
+        hipLaunchKernelGGL(k_rounds_fill, dim3(((uint32_t)n + 255) / 256), dim3(256), 0, ctx->stream, r->len, skip ? r->skip : (const uint8_t *)nullptr, (uint32_t)n,
+                           r->first_item, small_at, wide_at, prov_at, r->items, r->piece_len_init, r->order_small, r->order_wide);
+    }
+    // (scratch of the two kernels: back to the pool; the pool hands memory to this context only, and every later use of it
+    // is a stream operation of this context or an upload into a table created after this one's kernels were queued —
+    // uploads are synchronous host copies, so the scratch is parked until the stream has passed the kernels)
+    r->plan_scratch[0] = small_at; r->plan_scratch[1] = wide_at; r->plan_scratch[2] = prov_at;
+    td.mark("encoder_plan");
     // store-path pieces keep their fixed lengths for the table's lifetime; encoded pieces are rewritten by
     // the encoder on every run, so one copy at creation is enough
-    if (r->n_items) HIPCHK(ctx, hipMemcpy(r->piece_len, r->piece_len_init, 4 * (size_t)r->n_items, hipMemcpyDeviceToDevice));
+    if (r->n_items) HIPCHK(ctx, hipMemcpyAsync(r->piece_len, r->piece_len_init, 4 * (size_t)r->n_items, hipMemcpyDeviceToDevice, ctx->stream));
+    td.mark("rest");
     *out = r;
     return ZNIPPY_OK;
 }
@@ -1777,7 +1913,7 @@ extern "C" int znippy_rounds_results(znippy_ctx *ctx, znippy_rounds *r, uint64_t
     if (checksum) memcpy(checksum, r->h_res + 16 + 16 * n, 32 * n);
     if (compressed)
         for (uint32_t i = 0; i < r->n; i++)
-            compressed[i] = (r->h_skip[i] || (r->store_incompressible && r->h_stored[i])) ? 0 : 1;
+            compressed[i] = ((!r->h_skip.empty() && r->h_skip[i]) || (r->store_incompressible && r->h_stored[i])) ? 0 : 1;
     if (blob_bytes) *blob_bytes = total;
     return ZNIPPY_OK;
 }

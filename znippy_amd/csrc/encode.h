@@ -36,7 +36,7 @@ struct EncItem {
 
 // provisional slot of one block: literals + sequences section, plus room behind the raw literals where the wide
 // variant stages its Huffman streams before moving them in front (any block can end up in the wide variant)
-inline uint64_t enc_slot_bytes(uint32_t n) { return ((HDR_ROOM + 16 + 2ull * n + (n >> 2) + 64) + 15) & ~15ull; }
+__host__ __device__ inline uint64_t enc_slot_bytes(uint32_t n) { return ((HDR_ROOM + 16 + 2ull * n + (n >> 2) + 64) + 15) & ~15ull; }
 
 struct EncodeArgs {
     const EncItem *items;
