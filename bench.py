@@ -420,6 +420,9 @@ def main():
                 passes = (blocks + (leaves - my_rows)) / 64.0                # + one per parent node; every lane busy
                 floor_ms = passes / 1024.0 * ns_pass * 1e-6
                 roofline["limiter"] = "valu"
+                # what the 0.40 target is to be read against: the fraction of the HBM roofline the step would reach if the
+                # dominant kernel ran AT the integer-VALU floor of its BLAKE3 passes (nothing but the hash, every lane busy)
+                roofline["ceiling_frac"] = round(alg[dom] / (floor_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
                 roofline["valu"] = dict(floor_ms=round(floor_ms, 4), frac_of_floor=round(floor_ms / k_read[dom], 4),
                                         ns_per_pass_per_simd=round(ns_pass, 1), passes_per_step=round(passes, 0),
                                         note="BLAKE3 compress passes (64 lanes) per step / 1024 SIMDs x measured ns per pass")

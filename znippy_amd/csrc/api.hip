@@ -1348,15 +1348,22 @@ int znippy_decode_verify_rows_async(znippy_ctx *ctx, znippy_rows *r, const void 
             x.pool_used = reinterpret_cast<unsigned long long *>(r->ctl + 256);
             x.pending2 = r->pending2; x.pending2_count = r->pending_count + 1;
             x.big_seq = ctx->sw.bx_big;
+            x.small_frames = r->n_compressed && r->bx_bytes / r->n_compressed <= 65536;
             if (ctx->sw.ddbg) {  // diagnostic: where the previous run's table kernel spent its waves' time
                 static unsigned long long *dbg = nullptr;
-                if (!dbg) { (void)hipMalloc(&dbg, 512); (void)hipMemset(dbg, 0, 512); }
-                unsigned long long h[64];
+                if (!dbg) { (void)hipMalloc(&dbg, 1024); (void)hipMemset(dbg, 0, 1024); }
+                unsigned long long h[128];
                 (void)hipStreamSynchronize(s);
-                (void)hipMemcpy(h, dbg, 512, hipMemcpyDeviceToHost);
+                (void)hipMemcpy(h, dbg, 1024, hipMemcpyDeviceToHost);
+                if (h[64]) {
+                    const unsigned long long *e = h + 64;
+                    fprintf(stderr, "[znippy ddbg] batch execute: frames=%llu groups=%llu seqs=%llu big=%llu rounds=%llu flushes=%llu histreads=%llu | kcycles/frame: total=%.1f records=%.1f rep+scan=%.1f big=%.1f flush=%.1f histread=%.1f lits=%.1f matches=%.1f tail=%.1f\n",
+                            e[0], e[1], e[2], e[3], e[4], e[5], e[6], e[8] / 1e3 / e[0], e[9] / 1e3 / e[0], e[10] / 1e3 / e[0], e[11] / 1e3 / e[0], e[12] / 1e3 / e[0], e[13] / 1e3 / e[0],
+                            e[14] / 1e3 / e[0], e[15] / 1e3 / e[0], e[16] / 1e3 / e[0]);
+                }
                 if (h[32]) fprintf(stderr, "[znippy ddbg] batch tables: wave passes=%llu  kcycles per pass: literals header + weights=%.1f sequences header=%.1f huffman table=%.1f sequence tables=%.1f\n", h[32],
                                    h[33] / 1e3 / h[32], h[34] / 1e3 / h[32], h[35] / 1e3 / h[32], h[36] / 1e3 / h[32]);
-                (void)hipMemset(dbg, 0, 512);
+                (void)hipMemset(dbg, 0, 1024);
                 x.dbg = dbg;
             }
             static const char *const bx_names[7] = {"zstd_batch_scan", "zstd_batch_tables", "zstd_batch_huffman", "zstd_batch_sequences", "zstd_batch_execute", "zstd_batch_finish",

@@ -245,6 +245,7 @@ struct BxArgs {
     unsigned long long *pool_used;  // [0] literal bytes [1] records [2] frames decoded [3] blocks given up [4..7] why [8] FSE cells [9] Huffman cells (zeroed per run)
     uint32_t *pending2, *pending2_count;  // what is left for the serial decoder
     unsigned long long *dbg;
+    int small_frames;  // the table's frames average <= 64 KiB: the execute stage runs its small-window variant (more frames per CU)
     uint32_t big_seq;  // blocks of this many sequences get a wave of their own (BX_BIG_SEQ; ZNIPPY_BX_BIG for A/B runs)
 };
 void launch_bx_stage(const BxArgs &a, int cus, int stage, hipStream_t s);  // 0 scan, 1 prep, 2 huf, 3 fse (lane = block), 4 exec, 5 finish, 6 fse (wave = block)

@@ -537,7 +537,9 @@ __global__ __launch_bounds__(128, 4) void k_fz_entropy(FzArgs a, const uint32_t 
 }
 
 // One frame, executed by one wave: the blocks' records and literals come from the pools, W is the wave's LDS window.
-template <bool PROF>
+constexpr uint32_t BX_SMALL_HIST = 2048, BX_SMALL_CAP = 4096;  // the small window (k_bx_exec)
+constexpr int BX_SMALL_WAVES = 5;                                // ... and the waves per SIMD its kernel is compiled for
+template <bool PROF, uint32_t WH = WIN_HIST, uint32_t WC = WIN_CAP, uint32_t WSM = WIN_SEQ_MAX>
 __device__ __forceinline__ bool fz_exec_frame(const FzArgs &a, const uint32_t c, uint8_t *const W, const uint32_t lane) {  // true: the frame is decoded
     const uint32_t nb = a.cand_nb[c];
     if (!nb) return false;
@@ -579,11 +581,13 @@ __device__ __forceinline__ bool fz_exec_frame(const FzArgs &a, const uint32_t c,
         const uint8_t *const lit_ptr = kind == 0 ? src + lit_off : a.lit_pool + lit_off;
         const unsigned long long *const recs = a.seq_pool + uni64(it.seq_off);
         uint32_t lpos = 0;
+        unsigned long long rec_next = lane < nseq ? recs[lane] : 0ull;  // the records of a group are fetched one group ahead
         for (uint32_t g0 = 0; g0 < nseq && !err; g0 += 64) {
             const uint32_t cnt = nseq - g0 < 64 ? nseq - g0 : 64;
             const bool on = lane < cnt;
             FZ_T0();
-            const unsigned long long rec = on ? recs[g0 + lane] : 0ull;
+            const unsigned long long rec = on ? rec_next : 0ull;
+            rec_next = g0 + 64 + lane < nseq ? recs[g0 + 64 + lane] : 0ull;
             FZ_T1(c_rec);
             if (PROF) { p_groups++; p_seqs += cnt; }
             const uint32_t ll0 = (uint32_t)rec & 0x1FFFFu, ml0 = (uint32_t)(rec >> 17) & 0x3FFFFu;
@@ -611,7 +615,7 @@ linc = wave_incl_scan(linc); pinc = wave_incl_scan(pinc);
                 uint32_t ll = __shfl(ll0, idx & 63), ml = __shfl(ml0, idx & 63), off = __shfl(offset, idx & 63);
                 if (!v) { ll = 0; ml = 0; off = 1; }
                 const uint32_t tot = ll + ml;
-                const uint64_t bigm = __ballot(v && tot > WIN_SEQ_MAX);
+                const uint64_t bigm = __ballot(v && tot > WSM);
                 const uint32_t nv = cnt - si;
                 const uint32_t ncand = bigm ? (uint32_t)__ffsll((long long)bigm) - 1 : nv;
                 if (ncand == 0) {
@@ -619,7 +623,7 @@ linc = wave_incl_scan(linc); pinc = wave_incl_scan(pinc);
                     if (PROF) p_big++;
                     // one long sequence, straight to HBM (the window is emptied first)
                     if (win_n) {
-                        (void)win_flush(W, out, opos, win_n, hist_n, lane, false);
+                        (void)win_flush<WH>(W, out, opos, win_n, hist_n, lane, false);
                         opos += win_n;
                         win_n = 0;
                     }
@@ -640,27 +644,27 @@ linc = wave_incl_scan(linc); pinc = wave_incl_scan(pinc);
                 }
                 uint32_t end = lane < ncand ? tot : 0, lend = lane < ncand ? ll : 0;
                 end = wave_incl_scan(end); lend = wave_incl_scan(lend);
-                uint32_t fit = (uint32_t)__popcll(__ballot(lane < ncand && end <= WIN_CAP - win_n));
+                uint32_t fit = (uint32_t)__popcll(__ballot(lane < ncand && end <= WC - win_n));
                 if (fit == 0) {  // chunk full: stream it out, keep the newest bytes as history
                     FZ_T0();
                     if (PROF) p_flush++;
-                    (void)win_flush(W, out, opos, win_n, hist_n, lane, true);
-                    hist_n = hist_n + win_n < WIN_HIST ? hist_n + win_n : WIN_HIST;
+                    (void)win_flush<WH>(W, out, opos, win_n, hist_n, lane, true);
+                    hist_n = hist_n + win_n < WH ? hist_n + win_n : WH;
                     opos += win_n;
                     win_n = 0;
-                    fit = (uint32_t)__popcll(__ballot(lane < ncand && end <= WIN_CAP));
+                    fit = (uint32_t)__popcll(__ballot(lane < ncand && end <= WC));
                     FZ_T1(c_flush);
                 }
                 if (dirty) { wave_mem_sync(); dirty = false; }
-                const uint32_t want_h = opos < WIN_HIST ? (uint32_t)opos : WIN_HIST;
+                const uint32_t want_h = opos < WH ? (uint32_t)opos : WH;
                 if (win_n == 0 && hist_n < want_h) {  // history lost to a direct copy: read the newest output back
                     FZ_T0();
                     if (PROF) p_hist++;
-                    coop_copy(W + WIN_HIST - want_h, out + opos - want_h, want_h, lane, 64);
+                    coop_copy(W + WH - want_h, out + opos - want_h, want_h, lane, 64);
                     hist_n = want_h;
                     FZ_T1(c_hist);
                 }
-                win_exec_group(W, out, opos, hist_n, lane, lane < fit, WIN_HIST + win_n + (end - tot), ll, ml, off,
+                win_exec_group<WH>(W, out, opos, hist_n, lane, lane < fit, WH + win_n + (end - tot), ll, ml, off,
                                lit_ptr + lpos + (lend - ll), rle_lits, rle_byte, PROF ? &prof : nullptr);
                 win_n += rdlane_u(end, fit - 1);
                 lpos += rdlane_u(lend, fit - 1);
@@ -685,14 +689,14 @@ linc = wave_incl_scan(linc); pinc = wave_incl_scan(pinc);
         FZ_T0();
         const uint32_t rest = lit_len - lpos;
         if (opos + win_n + rest > fcs) { err = E_CORRUPT; break; }
-        const bool in_win = rest <= WIN_CAP - win_n;
+        const bool in_win = rest <= WC - win_n;
         if (in_win && rest) {
-            uint8_t *d = W + WIN_HIST + win_n;
+            uint8_t *d = W + WH + win_n;
             if (rle_lits) for (uint32_t i = lane; i < rest; i += 64) d[i] = rle_byte;
             else coop_copy(d, lit_ptr + lpos, rest, lane, 64);
         }
         if (dirty) { wave_mem_sync(); dirty = false; }
-        uint32_t h = win_flush(W, out, opos, in_win ? win_n + rest : win_n, hist_n, lane, in_win);
+        uint32_t h = win_flush<WH>(W, out, opos, in_win ? win_n + rest : win_n, hist_n, lane, in_win);
         if (!in_win) {
             if (rle_lits) coop_fill(out + opos + win_n, rle_byte, rest, lane, 64);
             else coop_copy(out + opos + win_n, lit_ptr + lpos, rest, lane, 64);
@@ -1674,11 +1678,16 @@ __device__ __forceinline__ FzArgs bx_as_fz(const BxArgs &a) {
 }
 
 // wave = frame, frames dealt out by an atomic cursor (the slots are an upper bound, most runs use few of them)
-__global__ __launch_bounds__(64) void k_bx_exec(BxArgs a) {
-    __shared__ __attribute__((aligned(16))) uint8_t W[WIN_HIST + WIN_CAP + 64];
+// WH / WC: history and chunk bytes of the wave's LDS output window.  Tables of small frames run the small window: the
+// executor is a lone wave's instruction stream per frame (~250 cycles per sequence, most of them waiting), so frames
+// resident per CU are its throughput, and the window is what bounds them.
+template <bool PROF, uint32_t WH, uint32_t WC, int WAVES>
+__global__ __launch_bounds__(64, WAVES) void k_bx_exec(BxArgs a) {
+    __shared__ __attribute__((aligned(16))) uint8_t W[WH + WC + 64];
     const uint32_t lane = threadIdx.x;
     const uint32_t n_slots = a.ctr[0];
-    const FzArgs z = bx_as_fz(a);
+    FzArgs z = bx_as_fz(a);
+    z.dbg = PROF ? a.dbg + 64 : nullptr;  // diagnostic (ZNIPPY_DDBG): the execute stage's counters sit behind the table stage's
     uint32_t n_done = 0;
     const uint32_t chunk = n_slots >= 32768 ? 4u : 1u;  // big tables: four slots per atomic (one cursor word takes ~88 additions per microsecond)
     for (;;) {
@@ -1687,7 +1696,7 @@ __global__ __launch_bounds__(64) void k_bx_exec(BxArgs a) {
         c0 = rdlane_u(c0, 0);
         if (c0 >= n_slots) break;
         for (uint32_t c = c0; c < c0 + chunk && c < n_slots; c++) {
-            if (fz_exec_frame<false>(z, c, W, lane)) n_done++;
+            if (fz_exec_frame<PROF, WH, WC, (WC / 4 < WIN_SEQ_MAX ? WC / 4 : WIN_SEQ_MAX)>(z, c, W, lane)) n_done++;
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_wave_barrier();
         }
@@ -1731,7 +1740,11 @@ void launch_bx_stage(const BxArgs &a, int cus, int stage, hipStream_t s) {
         hipLaunchKernelGGL(k_bx_fse, cap((a.item_cap + 15) / 16, 3), dim3(64), 0, s, a, a.seq_list + 2 * (size_t)a.item_cap, a.ctr + 6, 16u);
         break;
     case 6: hipLaunchKernelGGL(k_bx_fse_wave, cap(a.item_cap, 12), dim3(64), 0, s, a, a.seq_list + 3 * (size_t)a.item_cap, a.ctr + 7); break;
-    case 4: hipLaunchKernelGGL(k_bx_exec, cap(slots, 12), dim3(64), 0, s, a); break;
+    case 4:
+        if (a.dbg) hipLaunchKernelGGL((k_bx_exec<true, WIN_HIST, WIN_CAP, 1>), cap(slots, 12), dim3(64), 0, s, a);
+        else if (a.small_frames) hipLaunchKernelGGL((k_bx_exec<false, BX_SMALL_HIST, BX_SMALL_CAP, BX_SMALL_WAVES>), cap(slots, 4 * BX_SMALL_WAVES), dim3(64), 0, s, a);
+        else hipLaunchKernelGGL((k_bx_exec<false, WIN_HIST, WIN_CAP, 1>), cap(slots, 12), dim3(64), 0, s, a);
+        break;
     default: hipLaunchKernelGGL(k_bx_finish, dim3(lane_grid), dim3(64), 0, s, a); break;
     }
 }

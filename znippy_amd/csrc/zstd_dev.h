@@ -346,6 +346,9 @@ __device__ __forceinline__ void coop_match(uint8_t *dst, uint32_t off, uint64_t 
 typedef __attribute__((address_space(3))) uint8_t lds8;
 #define LDS_CP(dst, src, n) __builtin_memcpy((__attribute__((address_space(3))) void *)(dst), (src), (n))
 #define LDS_LD(dst, src, n) __builtin_memcpy((dst), (const __attribute__((address_space(3))) void *)(src), (n))
+// (the same as functions: inside a template the builtin with an address-space pointer resolves to the host's memcpy)
+__device__ __forceinline__ uint4 lds_ld16(const lds8 *s) { uint4 v; LDS_LD(&v, s, 16); return v; }
+__device__ __forceinline__ void lds_st16(lds8 *d, const uint4 v) { LDS_CP(d, &v, 16); }
 
 __device__ __forceinline__ void lane_tail_copy(lds8 *d, const uint8_t *g, uint32_t n) {  // n < 16, pieces in ascending order
     uint64_t a = 0; uint32_t b = 0; uint16_t c = 0; uint8_t e = 0;
@@ -451,6 +454,7 @@ __device__ __forceinline__ void lane_copy_period(lds8 *d, const lds8 *s, uint32_
 // match still pending (the high-water mark); the first pending match is always ready (its own overlap is
 // a forward copy).  Text needs 1-3 rounds per 64 sequences.
 struct ExecProf { unsigned long long t_lits = 0, t_match = 0, rounds = 0; };
+template <uint32_t WH = WIN_HIST>
 __device__ __forceinline__ void win_exec_group(uint8_t *Wg, const uint8_t *out, uint64_t chunk_abs, uint32_t hist_n, uint32_t lane,
                                                bool on, uint32_t dpos, uint32_t ll, uint32_t ml, uint32_t off, const uint8_t *lit,
                                                bool rle, uint8_t rle_byte, ExecProf *prof = nullptr) {
@@ -479,7 +483,7 @@ __device__ __forceinline__ void win_exec_group(uint8_t *Wg, const uint8_t *out, 
     }
     const uint32_t mdst = dpos + ll;
     const int32_t msrc = (int32_t)mdst - (int32_t)off;  // window coordinate of the match source (may lie before the history)
-    const int32_t lds_lo = (int32_t)WIN_HIST - (int32_t)hist_n;
+    const int32_t lds_lo = (int32_t)WH - (int32_t)hist_n;
     bool pend = on && ml != 0;
     if (prof) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); const unsigned long long t1 = __builtin_amdgcn_s_memtime(); prof->t_lits += t1 - t0; t0 = t1; }
     for (;;) {
@@ -495,9 +499,8 @@ __device__ __forceinline__ void win_exec_group(uint8_t *Wg, const uint8_t *out, 
         // its instruction latency behind, so a round costs what its instruction COUNT costs.
         if (__ballot(ready && !(ml <= 16 && msrc >= lds_lo && off >= ml)) == 0ull) {
             if (ready) {
-                uint4 v;
-                LDS_LD(&v, W + msrc, 16);
-                if (ml == 16) LDS_CP(W + mdst, &v, 16);
+                const uint4 v = lds_ld16(W + msrc);
+                if (ml == 16) lds_st16(W + mdst, v);
                 else store_prefix16(W + mdst, v, ml);
                 pend = false;
             }
@@ -507,7 +510,7 @@ __device__ __forceinline__ void win_exec_group(uint8_t *Wg, const uint8_t *out, 
             uint32_t k = 0;
             if (msrc < lds_lo) {  // (part of) the source was flushed long ago: read it back from HBM
                 const uint32_t nf = (uint32_t)(lds_lo - msrc) < ml ? (uint32_t)(lds_lo - msrc) : ml;
-                const uint8_t *g = out + (chunk_abs - WIN_HIST) + (int64_t)msrc;
+                const uint8_t *g = out + (chunk_abs - WH) + (int64_t)msrc;
                 lane_copy_g2l(W + mdst, g, nf);
                 k = nf;
             }
@@ -528,7 +531,7 @@ __device__ __forceinline__ void win_exec_group(uint8_t *Wg, const uint8_t *out, 
             uint32_t k = 0;
             if (sj < lds_lo) {
                 const uint32_t nf = (uint32_t)(lds_lo - sj) < nj ? (uint32_t)(lds_lo - sj) : nj;
-                coop_copy(Wg + dj, out + (chunk_abs - WIN_HIST) + (int64_t)sj, nf, lane, 64);
+                coop_copy(Wg + dj, out + (chunk_abs - WH) + (int64_t)sj, nf, lane, 64);
                 k = nf;
                 asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // FLAT stores into the window, see above
             }
@@ -541,9 +544,8 @@ __device__ __forceinline__ void win_exec_group(uint8_t *Wg, const uint8_t *out, 
                 const uint32_t step = nj - k < lim ? nj - k : lim;
                 const uint32_t i = lane * 16;
                 if (i < step) {
-                    uint4 v;
-                    LDS_LD(&v, W + (sj + (int32_t)(k + i)), 16);
-                    if (step - i >= 16) LDS_CP(W + dj + k + i, &v, 16);
+                    const uint4 v = lds_ld16(W + (sj + (int32_t)(k + i)));
+                    if (step - i >= 16) lds_st16(W + dj + k + i, v);
                     else store_prefix16(W + dj + k + i, v, step - i);
                 }
                 k += step;
@@ -556,14 +558,15 @@ __device__ __forceinline__ void win_exec_group(uint8_t *Wg, const uint8_t *out, 
 }
 
 // chunk -> HBM, then keep the newest bytes as history.  Returns the new history length.
+template <uint32_t WH = WIN_HIST>
 __device__ __forceinline__ uint32_t win_flush(uint8_t *W, uint8_t *out, uint64_t chunk_abs, uint32_t win_n, uint32_t hist_n, uint32_t lane,
                                              bool keep_history) {
-    if (win_n) coop_copy(out + chunk_abs, W + WIN_HIST, win_n, lane, 64);
+    if (win_n) coop_copy(out + chunk_abs, W + WH, win_n, lane, 64);
     uint32_t h = 0;
     if (keep_history) {
-        h = hist_n + win_n < WIN_HIST ? hist_n + win_n : WIN_HIST;
-        const uint8_t *sp = W + WIN_HIST + win_n - h;
-        uint8_t *dp = W + WIN_HIST - h;
+        h = hist_n + win_n < WH ? hist_n + win_n : WH;
+        const uint8_t *sp = W + WH + win_n - h;
+        uint8_t *dp = W + WH - h;
         if (win_n)
             for (uint32_t base = 0; base < h; base += 1024) {  // moves down by win_n: ascending 1 KiB steps, read then write
                 const uint32_t i = base + lane * 16;
