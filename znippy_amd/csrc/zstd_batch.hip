@@ -664,7 +664,7 @@ linc = wave_incl_scan(linc); pinc = wave_incl_scan(pinc);
                     hist_n = want_h;
                     FZ_T1(c_hist);
                 }
-                win_exec_group<WH>(W, out, opos, hist_n, lane, lane < fit, WH + win_n + (end - tot), ll, ml, off,
+                win_exec_group<WH, WC>(W, out, opos, hist_n, lane, lane < fit, WH + win_n + (end - tot), ll, ml, off,
                                lit_ptr + lpos + (lend - ll), rle_lits, rle_byte, PROF ? &prof : nullptr);
                 win_n += rdlane_u(end, fit - 1);
                 lpos += rdlane_u(lend, fit - 1);
@@ -722,7 +722,7 @@ linc = wave_incl_scan(linc); pinc = wave_incl_scan(pinc);
 
 template <bool PROF>
 __global__ __launch_bounds__(64) void k_fz_exec(FzArgs a) {
-    __shared__ __attribute__((aligned(16))) uint8_t W[WIN_HIST + WIN_CAP + 64];
+    __shared__ __attribute__((aligned(16))) uint8_t W[WIN_HIST + WIN_CAP + 64 + WIN_SCRATCH];
     if (blockIdx.x < a.n_cand && fz_exec_frame<PROF>(a, blockIdx.x, W, threadIdx.x) && threadIdx.x == 0)
         atomicAdd(&a.pool_used[2], 1ull);  // statistics: frames decoded by this path
 }
@@ -1683,7 +1683,7 @@ __device__ __forceinline__ FzArgs bx_as_fz(const BxArgs &a) {
 // resident per CU are its throughput, and the window is what bounds them.
 template <bool PROF, uint32_t WH, uint32_t WC, int WAVES>
 __global__ __launch_bounds__(64, WAVES) void k_bx_exec(BxArgs a) {
-    __shared__ __attribute__((aligned(16))) uint8_t W[WH + WC + 64];
+    __shared__ __attribute__((aligned(16))) uint8_t W[WH + WC + 64 + WIN_SCRATCH];
     const uint32_t lane = threadIdx.x;
     const uint32_t n_slots = a.ctr[0];
     FzArgs z = bx_as_fz(a);
