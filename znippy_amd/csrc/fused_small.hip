@@ -682,6 +682,31 @@ __device__ __forceinline__ FastRow parse_fast_block(const uint8_t *w, uint32_t p
     return r;
 }
 
+// Lane-parallel: is this staged frame certainly NOT one of the simple shapes?  A well-formed frame header whose first block
+// is a compressed block with Huffman-coded literals (type 2 or 3): the scalar parser would say F_NOT_SIMPLE after reading the
+// same bytes, one row after the other.  (A table of real text is all such rows: they go to the batch path at once.)
+__device__ __forceinline__ bool not_simple_fast(const uint8_t *w, uint32_t n, uint64_t usize, bool want) {
+    bool ok = want && n >= 12 && usize <= 0xFFFFFFull;
+    const uint64_t h0 = lds8(w);
+    ok &= (uint32_t)h0 == 0xFD2FB528u;
+    const uint32_t fhd = (uint32_t)(h0 >> 32) & 0xFF;
+    ok &= (fhd & 0x0F) == 0;  // no reserved bit, no content checksum, no dictionary id
+    const uint32_t single = (fhd >> 5) & 1, fcs_flag = fhd >> 6;
+    const uint32_t fcs_bytes = fcs_flag == 0 ? single : (1u << fcs_flag);
+    ok &= fcs_bytes != 0;
+    uint32_t pos = 6 - single;
+    uint64_t f = lds8(w + pos);
+    if (fcs_bytes < 8) f &= (1ull << (8 * fcs_bytes)) - 1;
+    if (fcs_bytes == 2) f += 256;
+    ok &= f == usize;
+    pos += fcs_bytes;  // <= 14
+    const uint64_t b = lds8(w + pos);  // block header (3 bytes) + the literals header's first byte
+    const uint32_t bh = (uint32_t)b & 0xFFFFFF;
+    ok &= ((bh >> 1) & 3) == 2 && (bh >> 3) >= 2 && pos + 3 + (bh >> 3) <= n && (bh >> 3) <= 128 * 1024;
+    ok &= (((uint32_t)(b >> 24)) & 3) >= 2;
+    return ok;
+}
+
 __device__ __forceinline__ FastRow parse_fast(const uint8_t *w, uint32_t n, uint64_t usize, bool want, const FastTabs &T) {
     bool ok = want && n >= 12 && n <= WIN && usize >= 65 && usize <= 0xFFFFFFull;
     const uint64_t h0 = lds8(w);
@@ -936,6 +961,21 @@ __device__ __forceinline__ void fused_tile(const FusedArgs &a, const uint32_t wa
         }
         const bool want = lane < t.n_units && lane < WROWS && c_sel && c_oo + c_len <= a.out_cap && c_st == 0;
         fr = parse_fast(WL + (lane < WROWS ? lane : 0) * WSTRIDE, c_bs, c_len, want, T);
+        // rows that are certainly for the general decoders: handed over by their own lanes, one atomic per wave
+        const bool ho = !fr.ok && not_simple_fast(WL + (lane < WROWS ? lane : 0) * WSTRIDE, c_bs, c_len, want);
+        const uint64_t hom = __ballot(ho);
+        if (hom) {
+            uint32_t at = 0;
+            if (lane == 0) at = atomicAdd(a.pending_count, (uint32_t)__popcll(hom));
+            at = (uint32_t)__builtin_amdgcn_readlane((int)at, 0);
+            if (ho) {
+                const uint32_t row = t.first_unit + lane;
+                a.status[row] = F_NOT_SIMPLE;
+                l_st[lane] = F_NOT_SIMPLE;
+                a.pending[at + (uint32_t)__popcll(hom & ((1ull << lane) - 1ull))] = row;
+            }
+            done64 |= hom;  // the row loop below skips them
+        }
     }
     const uint32_t fmask = (uint32_t)__ballot(fr.ok != 0);
     Emitter em;
