@@ -393,7 +393,7 @@ struct znippy_rows {
     // batch path (k_bx_*): candidate slots (one per compressed row at most), item slots, the two entropy work lists
     uint32_t bx_slots = 0, bx_item_cap = 0;
     uint64_t bx_bytes = 0;  // content bytes of all compressed rows
-    uint32_t *bx_cand_row = nullptr, *bx_cand_base = nullptr, *bx_cand_nb = nullptr, *bx_huf_list = nullptr, *bx_seq_list = nullptr;
+    uint32_t *bx_cand_row = nullptr, *bx_cand_base = nullptr, *bx_cand_nb = nullptr, *bx_huf_list = nullptr, *bx_seq_list = nullptr, *bx_sort_tmp = nullptr;
     zn::FzItem *bx_items = nullptr;
     zn::BxPrep *bx_prep = nullptr;
     uint32_t *item_row = nullptr, *item_k = nullptr, *item_src = nullptr, *row_flag = nullptr;
@@ -823,7 +823,7 @@ void znippy_rows_destroy(znippy_rows *r) {
                     r->ctl, r->digests, r->corrupt, r->list_a, r->pending,
                     r->cand_row, r->cand_base, r->cand_nblocks, r->fz_base, r->fz_cap, r->fz_it_cand, r->fz_nb, r->fz_work, r->fz_items, r->item_row, r->item_k, r->item_src, r->row_flag, r->pending2,
                     r->bt_tile, r->bt_item, r->tile_done, r->item_done, r->todo, r->status_init, r->slow_list,
-                    r->bx_cand_row, r->bx_cand_base, r->bx_cand_nb, r->bx_huf_list, r->bx_seq_list, r->bx_items, r->bx_prep, r->d_bitmap};
+                    r->bx_cand_row, r->bx_cand_base, r->bx_cand_nb, r->bx_huf_list, r->bx_seq_list, r->bx_items, r->bx_prep, r->d_bitmap, r->bx_sort_tmp};
     for (void *p : ptrs)
         tfree(r->ctx, p);
     if (r->h_counters) {
@@ -981,7 +981,7 @@ int znippy_rows_create(znippy_ctx *ctx, const uint64_t *blob_offset, const uint6
                 r->bx_item_cap = (uint32_t)cap;
                 if (tmalloc(ctx, &r->bx_cand_row, 4 * (size_t)r->bx_slots) != hipSuccess || tmalloc(ctx, &r->bx_cand_base, 4 * (size_t)r->bx_slots) != hipSuccess ||
                     tmalloc(ctx, &r->bx_cand_nb, 4 * (size_t)r->bx_slots) != hipSuccess || tmalloc(ctx, &r->bx_huf_list, 4 * (size_t)cap) != hipSuccess ||
-                    tmalloc(ctx, &r->bx_seq_list, 4 * 4 * (size_t)cap) != hipSuccess || tmalloc(ctx, &r->bx_items, sizeof(zn::FzItem) * (size_t)cap) != hipSuccess ||
+                    tmalloc(ctx, &r->bx_seq_list, 4 * 4 * (size_t)cap) != hipSuccess || tmalloc(ctx, &r->bx_sort_tmp, 5 * 4 * (size_t)cap) != hipSuccess || tmalloc(ctx, &r->bx_items, sizeof(zn::FzItem) * (size_t)cap) != hipSuccess ||
                     tmalloc(ctx, &r->bx_prep, sizeof(zn::BxPrep) * (size_t)cap) != hipSuccess) {
                     znippy_rows_destroy(r);
                     return ZNIPPY_E_NOMEM;
@@ -1342,7 +1342,7 @@ int znippy_decode_verify_rows_async(znippy_ctx *ctx, znippy_rows *r, const void 
             x.cand_row = r->bx_cand_row; x.cand_base = r->bx_cand_base; x.cand_nb = r->bx_cand_nb; x.slot_cap = r->bx_slots;
             x.items = r->bx_items; x.prep = r->bx_prep; x.item_cap = r->bx_item_cap;
             x.ctr = reinterpret_cast<uint32_t *>(r->ctl + 384);
-            x.huf_list = r->bx_huf_list; x.seq_list = r->bx_seq_list;
+            x.huf_list = r->bx_huf_list; x.seq_list = r->bx_seq_list; x.sort_tmp = r->bx_sort_tmp;
             x.lit_pool = ctx->fz_lit_pool; x.lit_cap = ctx->fz_lit_cap; x.seq_pool = ctx->fz_seq_pool; x.seq_cap = ctx->fz_seq_cap;
             x.fse_pool = ctx->bx_fse_pool; x.fse_cap = ctx->bx_fse_cap; x.huf_pool = ctx->bx_huf_pool; x.huf_cap = ctx->bx_huf_cap;
             x.pool_used = reinterpret_cast<unsigned long long *>(r->ctl + 256);
@@ -1366,8 +1366,8 @@ int znippy_decode_verify_rows_async(znippy_ctx *ctx, znippy_rows *r, const void 
                 (void)hipMemset(dbg, 0, 1024);
                 x.dbg = dbg;
             }
-            static const char *const bx_names[7] = {"zstd_batch_scan", "zstd_batch_tables", "zstd_batch_huffman", "zstd_batch_sequences", "zstd_batch_execute", "zstd_batch_finish",
-                                                    "zstd_batch_sequences_long"};
+            static const char *const bx_names[8] = {"zstd_batch_scan", "zstd_batch_tables", "zstd_batch_huffman", "zstd_batch_sequences", "zstd_batch_execute", "zstd_batch_finish",
+                                                    "zstd_batch_sequences_long", "zstd_batch_sort"};
             auto stage = [&](int st, hipStream_t on) {
                 ktime_begin(ctx, bx_names[st], on);
                 launch_bx_stage(x, ctx->cus, st, on);
@@ -1375,6 +1375,7 @@ int znippy_decode_verify_rows_async(znippy_ctx *ctx, znippy_rows *r, const void 
             };
             stage(0, s);
             stage(1, s);
+            stage(7, s);
             // the long chains (blocks of >= BX_BIG_SEQ sequences, a wave each) run on the auxiliary stream beside the Huffman
             // streams and the lane-per-block sequence kernel: each is a few hundred long-lived waves at most
             HIPCHK(ctx, hipEventRecord(ctx->ev_fork, s));

@@ -237,6 +237,7 @@ struct BxArgs {
     uint32_t slot_cap;
     FzItem *items; BxPrep *prep; uint32_t item_cap;
     uint32_t *ctr;  // [0] slots, [1] items, [2] Huffman list, [3] [5] [6] [7] sequence lists (64 / 32 / 16 / 1 blocks per wave), [4] execute cursor, [8] cursor of the wave-per-block list (zeroed per run)
+    uint32_t *sort_tmp;  // 5 x item_cap entries: scratch of k_bx_sort
     uint32_t *huf_list, *seq_list;  // seq_list: four lists of item_cap entries (64 / 32 / 16 blocks per wave, wave per block)
     uint8_t *lit_pool; uint64_t lit_cap;
     unsigned long long *seq_pool; uint64_t seq_cap;
@@ -248,7 +249,7 @@ struct BxArgs {
     int small_frames;  // the table's frames average <= 64 KiB: the execute stage runs its small-window variant (more frames per CU)
     uint32_t big_seq;  // blocks of this many sequences get a wave of their own (BX_BIG_SEQ; ZNIPPY_BX_BIG for A/B runs)
 };
-void launch_bx_stage(const BxArgs &a, int cus, int stage, hipStream_t s);  // 0 scan, 1 prep, 2 huf, 3 fse (lane = block), 4 exec, 5 finish, 6 fse (wave = block)
+void launch_bx_stage(const BxArgs &a, int cus, int stage, hipStream_t s);  // 0 scan, 1 prep, 7 sort the work lists, 2 huf, 3 fse (lane = block), 4 exec, 5 finish, 6 fse (wave = block)
 void bx_predefined_tables(uint16_t cells[160]);  // host: the three predefined tables as pool cells
 
 }  // namespace zn

@@ -1338,6 +1338,42 @@ __global__ __launch_bounds__(64) void k_bx_prep(BxArgs a) {
     }
 }
 
+// The entropy kernels run a wave for as long as its longest lane: the work lists are ordered by size (descending: the long
+// ones start first), 8 size classes per octave.  One workgroup per list: histogram, scan, scatter through `tmp`, copy back.
+__global__ __launch_bounds__(1024) void k_bx_sort(BxArgs a, uint32_t *tmp) {
+    __shared__ uint32_t hist[256], base[256];
+    const uint32_t which = blockIdx.x, t = threadIdx.x;  // 0 Huffman list, 1..4 sequence lists
+    uint32_t *const list = which == 0 ? a.huf_list : a.seq_list + (size_t)(which - 1) * a.item_cap;
+    uint32_t *const out = tmp + (size_t)which * a.item_cap;
+    const uint32_t n = which == 0 ? a.ctr[2] : a.ctr[which == 1 ? 3 : 3 + which];  // ctr[2], [3], [5], [6], [7]
+    if (n < 128) return;  // (nothing to balance)
+    auto key_of = [&](uint32_t slot) -> uint32_t {
+        const uint32_t v = which == 0 ? a.items[slot].lit_len : a.items[slot].nseq;
+        const uint32_t hb = v ? 31u - (uint32_t)__clz(v) : 0u;
+        const uint32_t k = v < 16 ? v : 8 * hb + ((v >> (hb - 3)) & 7u) - 16 + 16;  // 16.. : (octave, top three bits below the leading one)
+        return 255u - (k > 255u ? 255u : k);  // descending
+    };
+    if (t < 256) hist[t] = 0;
+    __syncthreads();
+    for (uint32_t i = t; i < n; i += 1024) atomicAdd(&hist[key_of(list[i])], 1u);
+    __syncthreads();
+    if (t < 64) {  // exclusive scan of the 256 counters: four per lane
+        uint32_t c[4], sum = 0;
+        for (int q = 0; q < 4; q++) { c[q] = hist[4 * t + q]; sum += c[q]; }
+        uint32_t incl = sum;
+        for (int d = 1; d < 64; d <<= 1) { const uint32_t y = __shfl_up(incl, d); if (t >= (uint32_t)d) incl += y; }
+        uint32_t at = incl - sum;
+        for (int q = 0; q < 4; q++) { base[4 * t + q] = at; at += c[q]; }
+    }
+    __syncthreads();
+    for (uint32_t i = t; i < n; i += 1024) {
+        const uint32_t slot = list[i];
+        out[atomicAdd(&base[key_of(slot)], 1u)] = slot;
+    }
+    __syncthreads();
+    for (uint32_t i = t; i < n; i += 1024) list[i] = out[i];
+}
+
 // lane = Huffman stream; a wave takes 16 blocks of the list and keeps their decoding tables in LDS
 constexpr uint32_t BX_HUF_BLOCKS = 16, BX_HUF_LDS = BX_HUF_BLOCKS * 2048;  // u16 cells
 __global__ __launch_bounds__(64) void k_bx_huf(BxArgs a) {
@@ -1733,6 +1769,7 @@ void launch_bx_stage(const BxArgs &a, int cus, int stage, hipStream_t s) {
     switch (stage) {
     case 0: hipLaunchKernelGGL(k_bx_scan, dim3(lane_grid), dim3(64), 0, s, a); break;
     case 1: hipLaunchKernelGGL(k_bx_prep, cap((a.item_cap + 63) / 64, 3), dim3(64), 0, s, a); break;
+    case 7: hipLaunchKernelGGL(k_bx_sort, dim3(5), dim3(1024), 0, s, a, a.sort_tmp); break;
     case 2: hipLaunchKernelGGL(k_bx_huf, cap((a.item_cap + BX_HUF_BLOCKS - 1) / BX_HUF_BLOCKS, 2), dim3(64), 0, s, a); break;
     case 3:
         hipLaunchKernelGGL(k_bx_fse, cap((a.item_cap + 63) / 64, 3), dim3(64), 0, s, a, a.seq_list, a.ctr + 3, 64u);
