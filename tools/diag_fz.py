@@ -45,4 +45,4 @@ for rep in range(4):
     c, corrupt, st = rt.decode_verify(d_blobs, d_out)
     dt = time.perf_counter() - t0
     kt = dict(ctx.kernel_times())
-    print(f"rep {rep}: {dt * 1e3:.2f} ms ({nfr * sz / 2**20 / dt:.0f} MB/s) corrupt={c['corrupt_rows']} errs={c['decode_errors']} entropy={kt.get('zstd_foreign_entropy', 0):.2f} execute={kt.get('zstd_foreign_execute', 0):.2f} fallback={kt.get('zstd_decode_fallback', 0):.2f}", rt.foreign_stats() if rep == 0 else "")
+    print(f"rep {rep}: {dt * 1e3:.2f} ms ({nfr * sz / 2**20 / dt:.0f} MB/s) corrupt={c['corrupt_rows']} errs={c['decode_errors']} tables={kt.get('zstd_batch_tables', 0):.2f} huffman={kt.get('zstd_batch_huffman', 0):.2f} sequences={kt.get('zstd_batch_sequences', 0):.2f}+{kt.get('zstd_batch_sequences_long', 0):.2f} execute={kt.get('zstd_batch_execute', 0):.2f} fallback={kt.get('zstd_decode_fallback', 0):.2f}", rt.foreign_stats() if rep == 0 else "")
