@@ -110,7 +110,7 @@ struct znippy_ctx {
         int dbg = 0;             // ZNIPPY_DBG bit set (FusedArgs::dbg)
         unsigned lds_pad = 0;    // ZNIPPY_LDS_PAD
         bool no_block_items = false, no_fused_blocks = false, ddbg = false, edbg = false, no_fused_store = false,
-             nohash = false, no_roles = false, no_fz = false, fz_only = false, no_bx = false, tdbg = false;
+             nohash = false, no_roles = false, no_fz = false, fz_only = false, no_bx = false, tdbg = false, no_fuse_hash = false;
         // ZNIPPY_ROLES_MIN: small tiles from which the role-split persistent kernel takes the table (0 = never; below
         // a few CU-fillings a persistent grid only adds start-up latency)
         unsigned roles_min = 2048;
@@ -139,6 +139,7 @@ static void read_switches(znippy_ctx *ctx) {
     ctx->sw.no_roles = on("ZNIPPY_NO_ROLES");
     ctx->sw.no_fz = on("ZNIPPY_NO_FZ");
     ctx->sw.tdbg = on("ZNIPPY_TDBG");
+    ctx->sw.no_fuse_hash = on("ZNIPPY_NO_FUSE_HASH");  // A/B: the write side's hash as a kernel of its own beside the encoder (round 2)
     ctx->sw.no_bx = on("ZNIPPY_NO_BX");
     if (const char *e = getenv("ZNIPPY_BX_BIG")) ctx->sw.bx_big = (unsigned)atoi(e);  // A/B: foreign frames through the round-2 paths (serial decoder + wave-per-block two-phase path)
     if (const char *lv = getenv("ZNIPPY_LEVEL")) { const int v = atoi(lv); if (v >= 1 && v <= 22) ctx->level = v; }  // initial level of every context (tests, A/B runs)
@@ -441,6 +442,7 @@ struct znippy_rounds {
     uint64_t run_seq = 0;
     size_t res_bytes = 0;
     bool store_incompressible = false;  // opt-in (znippy_rounds_set_store_incompressible)
+    int fuse_tiles = 0;  // > 0: every round is a small encoded round (one block, no store path): the encoder hashes its tiles itself, this many per dequeue
     uint32_t *first_item = nullptr;     // first piece of every round
     uint8_t *stored = nullptr, *h_stored = nullptr;  // per round: turned into a raw payload by the opt-in pass
     uint64_t *blob_offset = nullptr, *blob_size = nullptr, *total = nullptr;
@@ -1636,6 +1638,12 @@ int znippy_rounds_create(znippy_ctx *ctx, const uint64_t *src_offset, const uint
         znippy_rounds_destroy(r);
         return rc;
     }
+    if (r->n_items == n && r->n_wide == 0 && r->enc_bytes == r->in_bytes && n) {
+        uint32_t max_units = 0;
+        for (const Tile &t : p.tiles) max_units = std::max(max_units, t.n_units);
+        r->fuse_tiles = 1;  // one tile per dequeue (C2: 6 rounds): 0.77 ms against 0.86 for two and 1.12 for ten on one box — with ~4 tiles per wave the finest grain balances best
+        if (const char *e = getenv("ZNIPPY_FUSE_TILES")) { const int v = atoi(e); if (v >= 1 && v * (int)max_units <= 64) r->fuse_tiles = v; }  // A/B
+    }
     td.mark("hash_plan");
     // encoder plan: one item per output piece, in round order — counted, scanned and filled on the device
     const size_t ni = std::max<size_t>(r->n_items, 1), nsb = (ni + 255) / 256;
@@ -1835,7 +1843,9 @@ extern "C" int znippy_encode_hash_rounds_async(znippy_ctx *ctx, znippy_rounds *r
         (void)hipMemset(dbg, 0, 64);
         a.dbg = dbg;
     }
-    ktime_begin(ctx, "zstd_encode");
+    // Tables of small encoded rounds only: the encoder's waves hash the rounds they are about to encode (EncodeArgs::fuse_tiles)
+    const bool fuse_hash = r->fuse_tiles && !r->store_incompressible && !ctx->sw.nohash && !ctx->sw.no_fuse_hash;
+    ktime_begin(ctx, fuse_hash ? "zstd_encode_hash" : "zstd_encode");
     for (int wide = 1; wide >= 0; wide--) {  // the wide share first: its blocks are the long ones
         a.n_items = wide ? r->n_wide : r->n_small;
         if (!a.n_items) continue;
@@ -1844,7 +1854,18 @@ extern "C" int znippy_encode_hash_rounds_async(znippy_ctx *ctx, znippy_rounds *r
         const int g = wide ? ctx->encode_grid : ctx->encode_grid_small;
         a.batch = std::max<uint32_t>(1, std::min<uint32_t>(16, a.n_items / (uint32_t)(g * 2)));
         if (!wide) { a.retry_list = r->retry_list; a.retry_count = ctx->cursor + 15; }
-        launch_encode(a, std::min<int>(g, (int)a.n_items), !wide, ctx->level >= HIGH_TIER_LEVEL, s);
+        int grid = std::min<int>(g, (int)a.n_items);
+        if (!wide && fuse_hash) {
+            a.fuse_tiles = r->fuse_tiles;
+            a.h = HashArgs{};
+            a.h.tiles = r->plan.tiles; a.h.n_tiles = r->plan.n_tiles;
+            a.h.len = r->len;
+            a.h.srcA = (const uint8_t *)d_src; a.h.offA = r->src_off; a.h.baseA = 0;
+            a.h.digests = r->digests; a.h.tile_cv = r->plan.tile_cv;
+            grid = std::min<int>(g, (int)((r->plan.n_tiles + r->fuse_tiles - 1) / r->fuse_tiles));
+        }
+        launch_encode(a, grid, !wide, ctx->level >= HIGH_TIER_LEVEL, s);
+        a.fuse_tiles = 0;
     }
     if (r->n_small) {  // second wide launch: whatever the small variant handed over (count on the device)
         a.order = r->retry_list; a.n_items = r->n_small; a.n_items_dev = ctx->cursor + 15;
@@ -1866,7 +1887,7 @@ extern "C" int znippy_encode_hash_rounds_async(znippy_ctx *ctx, znippy_rounds *r
     const bool fuse_store = heavy && !r->store_incompressible &&
                             !ctx->sw.no_fused_store && !ctx->sw.nohash;
     int rc = ZNIPPY_OK;
-    if (!fuse_store) {
+    if (!fuse_store && !fuse_hash) {
         HIPCHK(ctx, hipStreamWaitEvent(ctx->aux, ctx->ev_fork, 0));
         rc = ctx->sw.nohash ? ZNIPPY_OK : hash_rounds_async(ctx, r, d_src, ctx->aux);  // diagnostic switch
         if (rc) return rc;
@@ -1894,7 +1915,7 @@ extern "C" int znippy_encode_hash_rounds_async(znippy_ctx *ctx, znippy_rounds *r
     if (fuse_store) {
         rc = hash_rounds_async(ctx, r, d_src, nullptr, d_blob_out, blob_cap);
         if (rc) return rc;
-    } else {
+    } else if (!fuse_hash) {
         HIPCHK(ctx, hipStreamWaitEvent(s, ctx->ev_join, 0));  // digests are complete once the main stream drains
     }
     // the results leave on the copy stream (one DMA into the slot's pinned mirror) while the main stream is free for

@@ -56,6 +56,11 @@ struct EncodeArgs {
     const EncTables *tabs;
     int tail_mark;  // higher effort tier: frames of several blocks end with an empty raw block (zstd_encode.hip)
     int high;       // higher effort tier: the small variant keeps only blocks of the periodic shape
+    // Hash tiles inside the encoder (small variant, tables of small encoded rounds only: one item per round, item index =
+    // round index): the work unit is a hash TILE — the wave hashes the tile's rounds (blake3::hash(src), stream_packer.rs:L219),
+    // then encodes them; the cursor counts tiles.  fuse_tiles == 0: items as usual, the hash is a kernel of its own.
+    int fuse_tiles;
+    HashArgs h;
 };
 
 struct GatherArgs {

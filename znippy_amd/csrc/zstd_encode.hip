@@ -13,6 +13,7 @@
 // stream_packer.rs:L258, made deterministic).
 #include "common.h"
 #include "encode.h"
+#include "hash_dev.h"
 
 namespace zn {
 
@@ -1027,13 +1028,35 @@ __global__ __launch_bounds__(64) void k_zstd_encode(EncodeArgs a) {
     for (;;) {
         if (next == lim) {
             __syncthreads();
-            if (lane == 0) s_item = atomicAdd(a.cursor, a.batch);
-            __syncthreads();
-            next = first = s_item;
-            lim = next + a.batch;
+            uint32_t batch = a.batch;
+            if (HASH_LOG == 11 && !HIGH && a.fuse_tiles) {
+                // Fused mode: the unit of work is a hash tile.  The wave hashes the tiles' rounds first — VALU work that
+                // overlaps, on the SIMD, with the memory waits of the waves that are encoding — and then encodes the same
+                // rounds, whose bytes are now in L2: the input is fetched from HBM once.
+                const uint32_t FUSE_TILES = (uint32_t)a.fuse_tiles;  // tiles per dequeue (1; more only through ZNIPPY_FUSE_TILES, and never more than 64 rounds)
+                if (lane == 0) s_item = atomicAdd(a.cursor, FUSE_TILES);
+                __syncthreads();
+                const uint32_t t0 = s_item;
+                if (t0 >= a.h.n_tiles) break;
+                uint32_t r_first = 0, r_end = 0;
+                for (uint32_t k = 0; k < FUSE_TILES && t0 + k < a.h.n_tiles; k++) {
+                    const Tile t = a.h.tiles[t0 + k];
+                    hash_tile<false>(a.h, t);
+                    if (k == 0) r_first = t.first_unit;
+                    r_end = t.first_unit + t.n_units;
+                }
+                next = first = r_first;
+                batch = r_end - r_first;  // <= 64 rounds per tile
+                lim = r_end;
+            } else {
+                if (lane == 0) s_item = atomicAdd(a.cursor, a.batch);
+                __syncthreads();
+                next = first = s_item;
+                lim = next + a.batch;
+            }
             const uint32_t mine = first + lane;
             d_flags = ITEM_SKIP;
-            if (lane < a.batch && mine < n_items) {
+            if (lane < batch && mine < n_items) {
                 d_id = a.order ? a.order[mine] : mine;  // this variant's share of the plan (or all of it)
                 const EncItem e = a.items[d_id];
                 d_round = e.round; d_block = e.block; d_nblocks = e.n_blocks; d_flags = e.flags; d_prov = e.prov;
