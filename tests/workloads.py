@@ -43,8 +43,8 @@ def layout(name):
             lens = np.array([SLOT] * (size // SLOT) + ([size % SLOT] if size % SLOT else []), dtype=np.uint64)
             label = "single 2 GiB text file, 11 slices of <= 200 MiB (BASELINE configs[2] as worded there)"
         return dict(lens=lens, skip=None, name=label, gen=lambda torch, b0, b1: gen_gpu.text(b1 - b0, start=b0))
-    if name in ("c5", "c5small"):
-        xml, jars = c5_layout(1 if name == "c5" else 16)
+    if name in ("c5", "c5small", "c5text"):
+        xml, jars = c5_layout(16 if name == "c5small" else 1)
         lens, skip = list(xml), [0] * len(xml)
         for j in jars:
             for o in range(0, j, SLICE):
@@ -52,9 +52,18 @@ def layout(name):
                 skip.append(1)
         nx, nj = sum(xml), sum(jars)
 
+        real = None
+        if name == "c5text":  # the xml files hold REAL text (sources found in the image; word soup where it has none): nothing periodic
+            raw = b"".join(image_corpus("text", nx + (1 << 20), whole_files=False))
+            if len(raw) < nx:
+                raw += gen.pseudo_text(nx - len(raw), seed=13)
+            real = np.frombuffer(raw[:nx], dtype=np.uint8)
+
         def g(torch, b0, b1):  # [text of all xml files | ONE LCG stream cut into the jars]
             parts = []
-            if b0 < nx:
+            if b0 < nx and real is not None:
+                parts.append(torch.from_numpy(real[b0:min(b1, nx)].copy()).cuda())
+            elif b0 < nx:
                 parts.append(gen_gpu.text(min(b1, nx) - b0, start=b0))
             if b1 > nx:
                 j0 = max(b0, nx) - nx
@@ -62,7 +71,7 @@ def layout(name):
             return torch.cat(parts) if len(parts) > 1 else parts[0]
         return dict(lens=np.array(lens, np.uint64), skip=np.array(skip, np.uint8), gen=g,
                     name=("mixed artifact repo stand-in: %d xml (1-8 KiB) + %d jars (100 KiB-%.1f MiB, store path), %.2f GB"
-                          % (len(xml), len(jars), max(jars) / 2**20, (nx + nj) / 1e9)) + ("" if name == "c5" else " (reduced; NOT BASELINE's size)"))
+                          % (len(xml), len(jars), max(jars) / 2**20, (nx + nj) / 1e9)) + ({"c5": "", "c5text": "; the xml files hold real (non-periodic) text"}.get(name, " (reduced; NOT BASELINE's size)")))
     if name in ("c4store", "c4codec"):
         size = 500 << 20
         lens = np.array([SLICE] * (size // SLICE) + ([size % SLICE] if size % SLICE else []), dtype=np.uint64)
