@@ -10,6 +10,10 @@ cd /tmp && export TMPDIR=/tmp
 set -e
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_${TAG} -- python3 $R/bench.py --steps 20 --warmup 3 > $O/prof_${TAG}_bench.log 2>&1
 grep "^{\"metric\"" $O/prof_${TAG}_bench.log | head -1 > $O/${TAG}_bench_c2.json
+# the same command with the headline leg alone: the other read legs launch the same kernels, so only here does the
+# stats file's per-kernel average describe the leg `roofline` is quoted on
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_${TAG}_headline -- python3 $R/bench.py --steps 20 --warmup 3 --headline-only --no-cpu-baseline > $O/prof_${TAG}_headline.log 2>&1
+grep "^{\"metric\"" $O/prof_${TAG}_headline.log | head -1 > $O/${TAG}_bench_c2_headline.json
 for wl in c2 c4store; do
   for c in FETCH_SIZE WRITE_SIZE; do
     timeout -k 10 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/pmc_${TAG}_${wl}_$c -- python3 $R/bench.py --workload $wl --steps 6 --warmup 2 --no-cpu-baseline > $O/pmc_${TAG}_${wl}_$c.log 2>&1
