@@ -124,3 +124,33 @@ def test_damaged_small_frames_agree_with_oracle(gpu_ctx, oracle):
     data = _py_corpus(1 << 20)
     bases = [(data[i * 9000:i * 9000 + 10240], (19, 3, 1)[i % 3]) for i in range(12)]
     fuzz_run(gpu_ctx, oracle, bases, 40, 2024, 10, 100)
+
+
+def test_more_blocks_than_item_slots(gpu_ctx, oracle):
+    """A writer may cut its frames into far more blocks than ceil(size / 128 KiB) — libzstd with a 1 KiB window emits
+    1 KiB blocks — and the batch path's item slots (sized from the index columns) then run out: the frames that no longer
+    fit stay with the serial decoder, and the table kernel must not touch the slots the scan left unfilled.  A first
+    table on the same context leaves stale items in the memory the second one's arrays are carved from (found by
+    tools/soak_foreign.py: a memory access fault on the third table of a process)."""
+    data = _py_corpus(8 << 20)
+    first = [data[i * 2000:i * 2000 + 1500 + (i % 5) * 300] for i in range(3000)]
+    A0 = _table(oracle, first, [workloads.libzstd_compress(e, 3) for e in first])
+    c, status, out, st, kt = _decode(gpu_ctx, A0, reps=1)
+    assert c["corrupt_rows"] == 0 and out.tobytes() == b"".join(first)
+    entries = [data[i * 200_000:i * 200_000 + 262_144] for i in range(30)] + [data[i * 3000:i * 3000 + 2500] for i in range(200)]
+    frames = [workloads.libzstd_compress_adv(e, level=(3, 19)[i % 2], window_log=10) for i, e in enumerate(entries[:30])]
+    frames += [workloads.libzstd_compress(e, 3) for e in entries[30:]]
+    nblk = 0
+    for f in frames[:30]:   # count the blocks of the big frames: 256 of 1 KiB each
+        assert not (f[4] >> 5) & 1   # a window descriptor, not a single segment
+        pos, k = 6 + (1, 2, 4, 8)[f[4] >> 6], 0
+        while True:
+            bh = f[pos] | f[pos + 1] << 8 | f[pos + 2] << 16
+            pos += 3 + (1 if (bh >> 1) & 3 == 1 else bh >> 3); k += 1
+            if bh & 1: break
+        nblk += k
+    assert nblk > 30 * 200   # ~7,700 blocks against ~1,900 item slots
+    A = _table(oracle, entries, frames)
+    c, status, out, st, kt = _decode(gpu_ctx, A)
+    assert c["corrupt_rows"] == 0 and c["decode_errors"] == 0, (c, np.nonzero(status)[0][:10])
+    assert out.tobytes() == b"".join(entries)

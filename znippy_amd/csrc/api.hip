@@ -110,7 +110,7 @@ struct znippy_ctx {
         int dbg = 0;             // ZNIPPY_DBG bit set (FusedArgs::dbg)
         unsigned lds_pad = 0;    // ZNIPPY_LDS_PAD
         bool no_block_items = false, no_fused_blocks = false, ddbg = false, edbg = false, no_fused_store = false,
-             nohash = false, no_roles = false, no_fz = false, fz_only = false, no_bx = false, tdbg = false, no_fuse_hash = false;
+             nohash = false, no_roles = false, no_fz = false, fz_only = false, no_bx = false, tdbg = false, no_fuse_hash = false, trace = false;
         // ZNIPPY_ROLES_MIN: small tiles from which the role-split persistent kernel takes the table (0 = never; below
         // a few CU-fillings a persistent grid only adds start-up latency)
         unsigned roles_min = 2048;
@@ -139,6 +139,7 @@ static void read_switches(znippy_ctx *ctx) {
     ctx->sw.no_roles = on("ZNIPPY_NO_ROLES");
     ctx->sw.no_fz = on("ZNIPPY_NO_FZ");
     ctx->sw.tdbg = on("ZNIPPY_TDBG");
+    ctx->sw.trace = on("ZNIPPY_TRACE");
     ctx->sw.no_fuse_hash = on("ZNIPPY_NO_FUSE_HASH");  // A/B: the write side's hash as a kernel of its own beside the encoder (round 2)
     ctx->sw.no_bx = on("ZNIPPY_NO_BX");
     if (const char *e = getenv("ZNIPPY_BX_BIG")) ctx->sw.bx_big = (unsigned)atoi(e);  // A/B: foreign frames through the round-2 paths (serial decoder + wave-per-block two-phase path)
@@ -454,6 +455,7 @@ static bool ktime_on(const znippy_ctx *ctx, const char *name) {
     return ctx->sw.ktime >= 2 || (ctx->sw.ktime == 1 && !strncmp(name, "decode_verify_", 14));
 }
 static void ktime_begin(znippy_ctx *ctx, const char *name, hipStream_t on = nullptr) {
+    if (ctx->sw.trace) { fprintf(stderr, "[znippy trace] %s ...", name); fflush(stderr); }
     ctx->ktime_open = ktime_on(ctx, name);
     if (!ctx->ktime_open) return;
     if ((int)ctx->ktimes.size() <= ctx->n_ktimes) {
@@ -466,6 +468,11 @@ static void ktime_begin(znippy_ctx *ctx, const char *name, hipStream_t on = null
     (void)hipEventRecord(ctx->ktimes[ctx->n_ktimes].t0, on ? on : ctx->stream);
 }
 static void ktime_end(znippy_ctx *ctx, hipStream_t on = nullptr) {
+    if (ctx->sw.trace) {  // diagnosis of a faulting launch: every bracketed launch runs to its end before the next starts
+        const hipError_t e = hipStreamSynchronize(on ? on : ctx->stream);
+        fprintf(stderr, " %s\n", e == hipSuccess ? "done" : hipGetErrorString(e));
+        fflush(stderr);
+    }
     if (!ctx->ktime_open) return;
     (void)hipEventRecord(ctx->ktimes[ctx->n_ktimes].t1, on ? on : ctx->stream);
     ctx->n_ktimes++;
@@ -1020,7 +1027,10 @@ int znippy_rows_create(znippy_ctx *ctx, const uint64_t *blob_offset, const uint6
             return ZNIPPY_E_NOMEM;
         }
         if (!ctx->sw.no_bx) {
-            const uint64_t cap = nblk + nblk / 2 + 1024;  // a writer may split blocks: half as many again, shared by all frames
+            // a writer may split blocks (libzstd's high levels cut a 128 KiB block into 2-5; runs of equal bytes come as
+            // strings of small RLE blocks): half as many again + up to 64k more, shared by all frames.  Frames that find no
+            // slot stay with the serial decoder.
+            const uint64_t cap = nblk + nblk / 2 + std::min<uint64_t>(3 * nblk, 65536) + 1024;
             if (cap < 0x7FFFFFFFull) {
                 r->bx_slots = r->n_compressed;
                 r->bx_item_cap = (uint32_t)cap;

@@ -1139,7 +1139,15 @@ __global__ __launch_bounds__(64) void k_bx_prep(BxArgs a) {
     const uint32_t n_items = a.ctr[1] < a.item_cap ? a.ctr[1] : a.item_cap;
     for (uint32_t i0 = blockIdx.x * 64; i0 < n_items; i0 += gridDim.x * 64) {
         const uint32_t slot = i0 + lane;
-        const bool on = slot < n_items;
+        bool on = slot < n_items;
+        if (on) {
+            // A slot is a block only if the scan filled it.  When the item slots run out, the frames that no longer fit keep
+            // nb = 0, but the counter has moved past them: the slots between the last frame that fitted and the capacity hold
+            // whatever the memory held before (found by tools/soak_foreign.py: a stale frame index -> a read far outside the
+            // table's columns).
+            const uint32_t c = a.prep[slot].frame, k = a.prep[slot].k;
+            on = c < a.ctr[0] && k < a.cand_nb[c] && a.cand_base[c] + k == slot;
+        }
         unsigned long long t_p = a.dbg ? __builtin_amdgcn_s_memtime() : 0;  // diagnostic (ZNIPPY_DDBG): where the wave's time goes
 #define PSTAMP(i) do { if (a.dbg) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); if (lane == 0) atomicAdd(&a.dbg[i], now_ - t_p); t_p = now_; } } while (0)
         if (a.dbg && lane == 0) atomicAdd(&a.dbg[32], 1ull);
