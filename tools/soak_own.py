@@ -8,7 +8,7 @@
             swaps, block-header bytes — thousands of rows per table: the run must end, rows whose bytes are reported
             verified must equal the source, and intact control rows must stay untouched.
 
-    python tools/soak_own.py write|mutants [tables] [entries per table] [first seed]
+    python tools/soak_own.py write|mutants|tables [tables] [entries per table] [first seed]
 """
 import ctypes as C
 import os
@@ -149,6 +149,85 @@ def run_write(pool, tables, per, seed0):
     return bad
 
 
+def run_tables(pool, tables, per, seed0):
+    """Mixed tables: every row is this encoder's frame, a libzstd frame or a stored row, at random; blobs and outputs
+    laid out in shuffled order with random gaps (odd addresses), the read path must return every row's bytes."""
+    import torch
+    from znippy_amd import hip
+    from oracle import oracle as O
+    O.build()
+    jobs = [pool.map_async(SF.make, range(seed0 + t * per, seed0 + (t + 1) * per), chunksize=16) for t in range(tables)]
+    bad = 0
+    for t, job in enumerate(jobs):
+        t0 = time.time()
+        items = [m for m in job.get() if m[2] is not None and (200, 0) not in m[4]]
+        rng = np.random.default_rng(seed0 + 17 * t)
+        n = len(items)
+        entries = [m[1] for m in items]
+        kind = rng.integers(0, 3, size=n)          # 0 own frame, 1 libzstd frame, 2 stored
+        ctx = hip.Context(0)
+        ctx.set_level(int(rng.choice([1, 3, 9, 19])))
+        own = np.nonzero(kind == 0)[0]
+        frames = [None] * n
+        if len(own):
+            lens = np.array([len(entries[i]) for i in own], np.uint64)
+            offs = np.concatenate([[0], np.cumsum(lens)[:-1]]).astype(np.uint64)
+            d_src = torch.from_numpy(np.frombuffer(b"".join(entries[i] for i in own) + bytes(64), dtype=np.uint8).copy()).cuda()
+            rd = hip.RoundTable(ctx, offs, lens, None)
+            d_blob = torch.zeros(rd.blob_bound() + 64, dtype=torch.uint8, device="cuda")
+            e = rd.encode_hash(d_src, d_blob)
+            blob = d_blob.cpu().numpy()
+            for j, i in enumerate(own):
+                frames[i] = blob[int(e["blob_offset"][j]):int(e["blob_offset"][j] + e["blob_size"][j])].tobytes()
+            rd.close()
+        for i in range(n):
+            if kind[i] == 1: frames[i] = items[i][2]
+            elif kind[i] == 2: frames[i] = entries[i]
+        comp = (kind != 2).astype(np.uint8)
+        # layouts: shuffled, with gaps
+        bo = np.zeros(n, np.uint64); oo = np.zeros(n, np.uint64)
+        pos = int(rng.integers(0, 100))
+        for i in rng.permutation(n):
+            bo[i] = pos; pos += len(frames[i]) + int(rng.integers(0, 70))
+        blob_total = pos + 64
+        pos = int(rng.integers(0, 100))
+        for i in rng.permutation(n):
+            oo[i] = pos; pos += len(entries[i]) + int(rng.integers(0, 40))
+        out_total = pos + 64
+        hb = np.zeros(blob_total, np.uint8)
+        for i in range(n):
+            hb[int(bo[i]):int(bo[i]) + len(frames[i])] = np.frombuffer(frames[i], dtype=np.uint8)
+        bs = np.array([len(f) for f in frames], np.uint64)
+        us = np.array([len(x) for x in entries], np.uint64)
+        ck = np.stack([np.frombuffer(O.blake3(x), dtype=np.uint8) for x in entries])
+        bm = np.packbits(comp.astype(bool), bitorder="little")
+        d_blobs = torch.from_numpy(hb).cuda()
+        d_out = torch.full((out_total,), 0xEE, dtype=torch.uint8, device="cuda")
+        rt = hip.RowTable(ctx, bo, bs, us, oo, bm, ck)
+        nb = 0
+        for rep in range(2):
+            d_out.fill_(0xEE); torch.cuda.synchronize()
+            c, corrupt, status = rt.decode_verify(d_blobs, d_out)
+            out = d_out.cpu().numpy()
+            for i in range(n):
+                if status[i] != 0 or out[int(oo[i]):int(oo[i] + us[i])].tobytes() != entries[i]:
+                    nb += 1
+                    if nb < 10: print("FAIL table %d rep %d row %d kind %d seed %d status %d size %d" % (t, rep, i, int(kind[i]), items[i][0], int(status[i]), len(entries[i])))
+            if int(c["corrupt_rows"]) or int(c["decode_errors"]):
+                nb += 1; print("FAIL table %d counters %s" % (t, dict(c)))
+            # the gaps between rows must be untouched
+            mask = np.ones(out_total, bool)
+            for i in range(n): mask[int(oo[i]):int(oo[i] + us[i])] = False
+            mask[out_total - 64:] = False
+            if not (out[mask] == 0xEE).all():
+                nb += 1; print("FAIL table %d rep %d: bytes between the rows were written (%d)" % (t, rep, int((out[mask] != 0xEE).sum())))
+        bad += nb
+        print("tables %d: %d rows (own %d, libzstd %d, stored %d), %.1f s, bad so far %d"
+              % (t, n, int((kind == 0).sum()), int((kind == 1).sum()), int((kind == 2).sum()), time.time() - t0, bad), flush=True)
+        rt.close(); ctx.close()
+    return bad
+
+
 def run_mutants(pool, tables, per, seed0):
     import torch
     from znippy_amd import hip
@@ -233,7 +312,7 @@ def main():
     seed0 = int(sys.argv[4]) if len(sys.argv) > 4 else 0
     pool = Pool(int(os.environ.get("SOAK_WORKERS", "12")))
     pool.map(entry_only, range(4))   # the workers exist before the GPU is touched
-    bad = run_write(pool, tables, per, seed0) if mode == "write" else run_mutants(pool, tables, per, seed0)
+    bad = {"write": run_write, "mutants": run_mutants, "tables": run_tables}[mode](pool, tables, per, seed0)
     pool.close()
     print("SOAK %s DONE bad = %d" % (mode, bad))
     return 1 if bad else 0
