@@ -1,6 +1,7 @@
 // C ABI of libznippy_hip.so (include/znippy_hip.h).  Host-side plumbing only: uploads of the
 // index columns / Round tables, the tile plan that drives the kernels' work cursor, kernel
 // launches on the context's HIP stream, and result read-back.
+#include <unistd.h>
 #include "common.h"
 #include "encode.h"
 #include "../../include/znippy_hip.h"
@@ -91,6 +92,9 @@ struct znippy_ctx {
     uint16_t *bx_fse_pool = nullptr;
     uint16_t *bx_huf_pool = nullptr;
     uint64_t bx_fse_cap = 0, bx_huf_cap = 0;
+    // the resolve path's word pool (k_rx_*: one 32-bit word per output byte of the big frames) and its chunk -> frame table
+    uint32_t *rx_pool = nullptr, *rx_chunk = nullptr;
+    uint64_t rx_cap = 0;  // words
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     // kernel timing
     std::vector<KTime> ktimes;
@@ -110,7 +114,7 @@ struct znippy_ctx {
         int dbg = 0;             // ZNIPPY_DBG bit set (FusedArgs::dbg)
         unsigned lds_pad = 0;    // ZNIPPY_LDS_PAD
         bool no_block_items = false, no_fused_blocks = false, ddbg = false, edbg = false, no_fused_store = false,
-             nohash = false, no_roles = false, no_fz = false, fz_only = false, no_bx = false, tdbg = false, no_fuse_hash = false, trace = false;
+             nohash = false, no_roles = false, no_fz = false, fz_only = false, no_bx = false, tdbg = false, no_fuse_hash = false, trace = false, no_rx = false;
         // ZNIPPY_ROLES_MIN: small tiles from which the role-split persistent kernel takes the table (0 = never; below
         // a few CU-fillings a persistent grid only adds start-up latency)
         unsigned roles_min = 2048;
@@ -140,6 +144,7 @@ static void read_switches(znippy_ctx *ctx) {
     ctx->sw.no_fz = on("ZNIPPY_NO_FZ");
     ctx->sw.tdbg = on("ZNIPPY_TDBG");
     ctx->sw.trace = on("ZNIPPY_TRACE");
+    ctx->sw.no_rx = on("ZNIPPY_NO_RX");  // A/B: big foreign frames executed by a wave each (round 3's first form)
     ctx->sw.no_fuse_hash = on("ZNIPPY_NO_FUSE_HASH");  // A/B: the write side's hash as a kernel of its own beside the encoder (round 2)
     ctx->sw.no_bx = on("ZNIPPY_NO_BX");
     if (const char *e = getenv("ZNIPPY_BX_BIG")) ctx->sw.bx_big = (unsigned)atoi(e);  // A/B: foreign frames through the round-2 paths (serial decoder + wave-per-block two-phase path)
@@ -398,6 +403,8 @@ struct znippy_rows {
     uint32_t *bx_cand_row = nullptr, *bx_cand_base = nullptr, *bx_cand_nb = nullptr, *bx_huf_list = nullptr, *bx_seq_list = nullptr, *bx_sort_tmp = nullptr;
     zn::FzItem *bx_items = nullptr;
     zn::BxPrep *bx_prep = nullptr;
+    uint64_t rx_words = 0;  // resolve path: words its frames (compressed rows of >= RX_MIN bytes) can ask for
+    uint32_t *rx_base = nullptr, *rx_fail = nullptr, *rx_blk = nullptr, *rx_list = nullptr;
     uint32_t *item_row = nullptr, *item_k = nullptr, *item_src = nullptr, *row_flag = nullptr;
     // fused block kernel: big-slice tiles of the candidate rows, the item each belongs to, and what it got done
     uint32_t n_bt = 0;
@@ -541,6 +548,25 @@ static int ensure_bx_pools(znippy_ctx *ctx, uint64_t content_bytes, uint32_t ite
         if (hipMalloc(&ctx->bx_huf_pool, huf * 2) != hipSuccess) { (void)hipGetLastError(); ctx->bx_huf_pool = nullptr; return ZNIPPY_OK; }
         ctx->bx_huf_cap = huf;
     }
+    return ZNIPPY_OK;
+}
+// Word pool of the resolve path: 4 bytes per output byte of the frames it takes, at most 2^31 - 2^20 words (a word with bit 31
+// clear is an index).  hipMalloc of 8 GiB takes 0.3 ms on this system; frames that find no room are executed by a wave each.
+static int ensure_rx_pool(znippy_ctx *ctx, uint64_t words) {
+    constexpr uint64_t CAP = (1ull << 31) - (1ull << 20);
+    words = std::min<uint64_t>((words + 1023) & ~1023ull, CAP);
+    if (words <= ctx->rx_cap) return ZNIPPY_OK;
+    (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->rx_pool) (void)hipFree(ctx->rx_pool);
+    if (ctx->rx_chunk) (void)hipFree(ctx->rx_chunk);
+    ctx->rx_pool = nullptr; ctx->rx_chunk = nullptr; ctx->rx_cap = 0;
+    if (hipMalloc(&ctx->rx_pool, words * 4) != hipSuccess || hipMalloc(&ctx->rx_chunk, words / 1024 * 4) != hipSuccess) {
+        (void)hipGetLastError();
+        if (ctx->rx_pool) (void)hipFree(ctx->rx_pool);
+        ctx->rx_pool = nullptr; ctx->rx_chunk = nullptr;
+        return ZNIPPY_OK;  // no pool: the frames are executed by a wave each
+    }
+    ctx->rx_cap = words;
     return ZNIPPY_OK;
 }
 static int ensure_encoder(znippy_ctx *ctx) {
@@ -736,6 +762,8 @@ static void ctx_teardown(znippy_ctx *ctx) {
     if (ctx->fz_seq_pool) (void)hipFree(ctx->fz_seq_pool);
     if (ctx->bx_fse_pool) (void)hipFree(ctx->bx_fse_pool);
     if (ctx->bx_huf_pool) (void)hipFree(ctx->bx_huf_pool);
+    if (ctx->rx_pool) (void)hipFree(ctx->rx_pool);
+    if (ctx->rx_chunk) (void)hipFree(ctx->rx_chunk);
     if (ctx->cursor) (void)hipFree(ctx->cursor);
     if (ctx->shim_in) (void)hipFree(ctx->shim_in);
     if (ctx->shim_out) (void)hipFree(ctx->shim_out);
@@ -875,7 +903,8 @@ void znippy_rows_destroy(znippy_rows *r) {
                     r->ctl, r->digests, r->corrupt, r->list_a, r->pending,
                     r->cand_row, r->cand_base, r->cand_nblocks, r->fz_base, r->fz_cap, r->fz_it_cand, r->fz_nb, r->fz_work, r->fz_items, r->item_row, r->item_k, r->item_src, r->row_flag, r->pending2,
                     r->bt_tile, r->bt_item, r->tile_done, r->item_done, r->todo, r->status_init, r->slow_list,
-                    r->bx_cand_row, r->bx_cand_base, r->bx_cand_nb, r->bx_huf_list, r->bx_seq_list, r->bx_items, r->bx_prep, r->d_bitmap, r->bx_sort_tmp};
+                    r->bx_cand_row, r->bx_cand_base, r->bx_cand_nb, r->bx_huf_list, r->bx_seq_list, r->bx_items, r->bx_prep, r->d_bitmap, r->bx_sort_tmp,
+                    r->rx_base, r->rx_fail, r->rx_blk, r->rx_list};
     for (void *p : ptrs)
         tfree(r->ctx, p);
     if (r->h_counters) {
@@ -995,6 +1024,7 @@ int znippy_rows_create(znippy_ctx *ctx, const uint64_t *blob_offset, const uint6
             if (!c) continue;
             nblk += us ? (us + BLK - 1) / BLK : 1;
             r->bx_bytes += us;
+            if (us >= zn::RX_MIN && us < (1ull << 30)) r->rx_words += (us + 1023) & ~1023ull;
             if (us <= 64 * 1024) continue;
             big_bytes += us;
             big_blob += bs;
@@ -1037,7 +1067,10 @@ int znippy_rows_create(znippy_ctx *ctx, const uint64_t *blob_offset, const uint6
                 if (tmalloc(ctx, &r->bx_cand_row, 4 * (size_t)r->bx_slots) != hipSuccess || tmalloc(ctx, &r->bx_cand_base, 4 * (size_t)r->bx_slots) != hipSuccess ||
                     tmalloc(ctx, &r->bx_cand_nb, 4 * (size_t)r->bx_slots) != hipSuccess || tmalloc(ctx, &r->bx_huf_list, 4 * (size_t)cap) != hipSuccess ||
                     tmalloc(ctx, &r->bx_seq_list, 4 * 4 * (size_t)cap) != hipSuccess || tmalloc(ctx, &r->bx_sort_tmp, 5 * 4 * (size_t)cap) != hipSuccess || tmalloc(ctx, &r->bx_items, sizeof(zn::FzItem) * (size_t)cap) != hipSuccess ||
-                    tmalloc(ctx, &r->bx_prep, sizeof(zn::BxPrep) * (size_t)cap) != hipSuccess) {
+                    tmalloc(ctx, &r->bx_prep, sizeof(zn::BxPrep) * (size_t)cap) != hipSuccess ||
+                    (r->rx_words && !ctx->sw.no_rx &&
+                     (tmalloc(ctx, &r->rx_base, 4 * (size_t)r->bx_slots) != hipSuccess || tmalloc(ctx, &r->rx_fail, 4 * (size_t)r->bx_slots) != hipSuccess ||
+                      tmalloc(ctx, &r->rx_blk, 16 * (size_t)cap) != hipSuccess || tmalloc(ctx, &r->rx_list, 4 * (size_t)cap) != hipSuccess))) {
                     znippy_rows_destroy(r);
                     return ZNIPPY_E_NOMEM;
                 }
@@ -1184,6 +1217,7 @@ int znippy_decode_verify_rows_async(znippy_ctx *ctx, znippy_rows *r, const void 
     if (r->bx_slots) {
         int rc0 = ensure_fz_pools(ctx, r->bx_bytes, r->bx_item_cap);
         if (!rc0) rc0 = ensure_bx_pools(ctx, r->bx_bytes, r->bx_item_cap);
+        if (!rc0 && r->rx_base && r->bx_hint != 0) rc0 = ensure_rx_pool(ctx, r->rx_words);
         if (rc0) return rc0;
     }
     if (r->run_seq && r->bx_hint < 0 && r->n) {  // a run of this table has finished meanwhile?
@@ -1403,6 +1437,13 @@ int znippy_decode_verify_rows_async(znippy_ctx *ctx, znippy_rows *r, const void 
             x.pool_used = reinterpret_cast<unsigned long long *>(r->ctl + 256);
             x.pending2 = r->pending2; x.pending2_count = r->pending_count + 1;
             x.big_seq = ctx->sw.bx_big;
+            const bool rx = r->rx_base && ctx->rx_pool;
+            if (rx) {
+                x.rx_ptr = ctx->rx_pool; x.rx_cap = ctx->rx_cap; x.rx_chunk = ctx->rx_chunk;
+                x.rx_base = r->rx_base; x.rx_fail = r->rx_fail; x.rx_blk = r->rx_blk; x.rx_list = r->rx_list;
+                x.rx_pending = reinterpret_cast<uint32_t *>(r->ctl + 448);
+                x.rx_bound = std::min<uint64_t>(r->rx_words, ctx->rx_cap);
+            }
             x.small_frames = r->n_compressed && r->bx_bytes / r->n_compressed <= 65536;
             if (ctx->sw.ddbg) {  // diagnostic: where the previous run's table kernel spent its waves' time
                 static unsigned long long *dbg = nullptr;
@@ -1421,8 +1462,8 @@ int znippy_decode_verify_rows_async(znippy_ctx *ctx, znippy_rows *r, const void 
                 (void)hipMemset(dbg, 0, 1024);
                 x.dbg = dbg;
             }
-            static const char *const bx_names[8] = {"zstd_batch_scan", "zstd_batch_tables", "zstd_batch_huffman", "zstd_batch_sequences", "zstd_batch_execute", "zstd_batch_finish",
-                                                    "zstd_batch_sequences_long", "zstd_batch_sort"};
+            static const char *const bx_names[10] = {"zstd_batch_scan", "zstd_batch_tables", "zstd_batch_huffman", "zstd_batch_sequences", "zstd_batch_execute", "zstd_batch_finish",
+                                                     "zstd_batch_sequences_long", "zstd_batch_sort", "zstd_resolve_plan", "zstd_resolve_expand"};
             auto stage = [&](int st, hipStream_t on) {
                 ktime_begin(ctx, bx_names[st], on);
                 launch_bx_stage(x, ctx->cus, st, on);
@@ -1440,6 +1481,24 @@ int znippy_decode_verify_rows_async(znippy_ctx *ctx, znippy_rows *r, const void 
             stage(2, s);
             stage(3, s);
             HIPCHK(ctx, hipStreamWaitEvent(s, ctx->ev_join, 0));
+            if (rx) {  // big frames: resolved in parallel (every byte a word, pointer jumping) instead of executed by a wave each
+                stage(8, s);
+                if (ctx->sw.trace) {
+                    uint32_t g[16];
+                    unsigned long long pu[16];
+                    (void)hipMemcpy(g, r->ctl + 384, 64, hipMemcpyDeviceToHost);
+                    (void)hipMemcpy(pu, r->ctl + 256, 128, hipMemcpyDeviceToHost);
+                    fprintf(stderr, "[znippy trace] resolve plan: slots %u items %u list %u frames %u words %llu extent %llu cap %llu item_cap %u\n", g[0], g[1], g[9], g[11], pu[10], pu[11],
+                            (unsigned long long)ctx->rx_cap, r->bx_item_cap);
+                }
+                stage(9, s);
+                ktime_begin(ctx, "zstd_resolve_jump", s);
+                for (int rd = 0; rd < (int)zn::RX_ROUNDS; rd++) launch_bx_stage(x, ctx->cus, 10 + rd, s);
+                ktime_end(ctx, s);
+                ktime_begin(ctx, "zstd_resolve_store", s);
+                launch_bx_stage(x, ctx->cus, 30, s);
+                ktime_end(ctx, s);
+            }
             stage(4, s);
             stage(5, s);
             a.list_a = nullptr; a.n_list_a = 0;

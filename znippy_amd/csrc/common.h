@@ -248,8 +248,20 @@ struct BxArgs {
     unsigned long long *dbg;
     int small_frames;  // the table's frames average <= 64 KiB: the execute stage runs its small-window variant (more frames per CU)
     uint32_t big_seq;  // blocks of this many sequences get a wave of their own (BX_BIG_SEQ; ZNIPPY_BX_BIG for A/B runs)
+    // The resolve path (k_rx_*): frames of >= RX_MIN bytes are not executed by one wave each but resolved in parallel — every
+    // output byte gets a 32-bit word, RX_DONE | value for a literal byte, the word index it copies from for a match byte;
+    // rounds of pointer jumping turn every word into a value; a last pass stores the bytes.  ctr[9] list length, [10] expand
+    // cursor, [11] frames taken; pool_used[10] words handed out, [11] words in use (the extent the rounds run over).
+    uint32_t *rx_ptr; uint64_t rx_cap;  // the word pool (rx_cap < 2^31 words: a word with bit 31 clear is an index)
+    uint32_t *rx_chunk;                 // 1,024-word chunk of the pool -> candidate slot
+    uint32_t *rx_base, *rx_fail;        // per candidate slot: first word (RX_NONE: not taken), a block did not check out
+    uint32_t *rx_blk;                   // per block item: first output byte inside the frame, incoming repeat offsets [3]
+    uint32_t *rx_list;                  // block items to expand
+    uint32_t *rx_pending;               // [round]: words still unresolved after that round (zeroed per run)
+    uint64_t rx_bound;                  // host's bound on the words a run can use (grid sizing)
 };
-void launch_bx_stage(const BxArgs &a, int cus, int stage, hipStream_t s);  // 0 scan, 1 prep, 7 sort the work lists, 2 huf, 3 fse (lane = block), 4 exec, 5 finish, 6 fse (wave = block)
+constexpr uint32_t RX_NONE = 0xFFFFFFFFu, RX_DONE = 0x80000000u, RX_MIN = 256u << 10, RX_ROUNDS = 12, RX_JUMPS = 6;
+void launch_bx_stage(const BxArgs &a, int cus, int stage, hipStream_t s);  // 0 scan, 1 prep, 7 sort the work lists, 2 huf, 3 fse (lane = block), 4 exec, 5 finish, 6 fse (wave = block), 8 resolve: plan, 9 expand, 10 + r jump round r, 30 store
 void bx_predefined_tables(uint16_t cells[160]);  // host: the three predefined tables as pool cells
 
 }  // namespace zn

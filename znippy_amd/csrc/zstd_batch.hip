@@ -1740,12 +1740,225 @@ __global__ __launch_bounds__(64, WAVES) void k_bx_exec(BxArgs a) {
         c0 = rdlane_u(c0, 0);
         if (c0 >= n_slots) break;
         for (uint32_t c = c0; c < c0 + chunk && c < n_slots; c++) {
+            if (a.rx_base && a.rx_base[c] != RX_NONE) continue;  // the resolve path's frame
             if (fz_exec_frame<PROF, WH, WC, (WC / 4 < WIN_SEQ_MAX ? WC / 4 : WIN_SEQ_MAX)>(z, c, W, lane)) n_done++;
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_wave_barrier();
         }
     }
     if (lane == 0 && n_done) atomicAdd(&a.pool_used[2], (unsigned long long)n_done);  // statistics: frames decoded by this path
+}
+
+
+// =============================================================================================
+// The resolve path: big frames without a serial executor.
+//
+// One frame is one LZ77 dependency chain for a wave that executes its sequences in order (fz_exec_frame: ~3 ns per byte,
+// 20 ms for 8 MiB whatever else the chip does).  Seen per BYTE the dependencies are shallow: a byte is a literal, or a
+// copy of an earlier byte — which is a literal or a copy ...  So: every output byte gets a 32-bit word, RX_DONE | value
+// for a literal, the index of the word it copies from for a match byte (k_rx_expand: wave = block, positions by prefix
+// sums, 64 bytes per step); then rounds of pointer jumping over all words at once (k_rx_jump: word = *word, until the
+// word is a value; RX_JUMPS hops per launch, so RX_ROUNDS launches cover any chain a 2 GiB frame can hold — a launch
+// returns at once when the round before it left nothing); then the values are stored as the rows' bytes (k_rx_store).
+// Updates are in place and unordered: whatever a thread reads through a word is a position further up the same chain
+// or the final value, and 32-bit stores are whole.  Malformed input (mutants) only ever produces words that point
+// backwards inside their own frame: offsets are checked against the position when the words are written.
+// =============================================================================================
+__global__ __launch_bounds__(64) void k_rx_plan(BxArgs a) {
+    const uint32_t lane = threadIdx.x;
+    const uint32_t n_slots = a.ctr[0];
+    for (uint32_t c = blockIdx.x; c < n_slots; c += gridDim.x) {
+        if (lane == 0) { a.rx_base[c] = RX_NONE; a.rx_fail[c] = 0; }
+        const uint32_t nb = a.cand_nb[c], row = a.cand_row[c];
+        if (!nb || row == 0xFFFFFFFFu) continue;
+        const uint64_t fcs = a.usize[row];
+        if (fcs < RX_MIN || fcs >= (1ull << 30)) continue;
+        const uint32_t base = a.cand_base[c];
+        {   // every block came through the entropy stages and the sizes add up (as fz_exec_frame checks)
+            unsigned long long tot = 0, seqs = 0;
+            uint32_t bad = 0;
+            for (uint32_t i = lane; i < nb; i += 64) {
+                bad |= a.items[base + i].err != 0;
+                tot += a.items[base + i].out;
+                seqs += a.items[base + i].nseq;
+            }
+            for (int d = 32; d >= 1; d >>= 1) { tot += __shfl_xor(tot, d); seqs += __shfl_xor(seqs, d); bad |= __shfl_xor(bad, d); }
+            if (bad || tot != fcs) continue;
+            if (fcs >= (1u << 20) && seqs * 2048 < fcs) continue;  // a few very long copies: the serial decoder's wide variant (fz_exec_frame)
+        }
+        const uint32_t need = ((uint32_t)fcs + 1023u) & ~1023u;
+        unsigned long long at = 0;
+        if (lane == 0) at = atomicAdd(&a.pool_used[10], (unsigned long long)need);
+        at = rdlane64_u(at, 0);
+        if (at + need > a.rx_cap) continue;  // pool full (every later request fails too: the words in use stay one prefix)
+        if (lane == 0) atomicMax(&a.pool_used[11], at + need);
+        for (uint32_t i = lane; i < need / 1024; i += 64) a.rx_chunk[at / 1024 + i] = c;
+        for (uint32_t i = (uint32_t)fcs + lane; i < need; i += 64) a.rx_ptr[at + i] = RX_DONE;  // padding behind the frame
+        // per block: where its output starts, and the repeat offsets it starts with (the blocks' own records were decoded
+        // against a symbolic history; composed here block by block, as the serial executor does between blocks)
+        uint32_t r0 = 1, r1 = 4, r2 = 8, ob = 0;
+        for (uint32_t g = 0; g < nb; g += 64) {
+            const uint32_t i = g + lane;
+            const bool on = i < nb;
+            uint32_t o = 0, x0 = FZ_SYM, x1 = FZ_SYM | (1u << 26), x2 = FZ_SYM | (2u << 26);
+            if (on) { const FzItem it = a.items[base + i]; o = it.out; x0 = it.rep[0]; x1 = it.rep[1]; x2 = it.rep[2]; }
+            const uint32_t inc = wave_incl_scan(o);
+            uint32_t h0 = 0, h1 = 0, h2 = 0;
+            const uint32_t cnt = nb - g < 64 ? nb - g : 64;
+            for (uint32_t j = 0; j < cnt; j++) {
+                if (lane == j) { h0 = r0; h1 = r1; h2 = r2; }
+                const uint32_t y[3] = {rdlane_u(x0, j), rdlane_u(x1, j), rdlane_u(x2, j)};
+                uint32_t nr[3];
+#pragma unroll
+                for (int q = 0; q < 3; q++) {
+                    const uint32_t x = y[q];
+                    if (x & FZ_SYM) {
+                        const uint32_t kk = (x >> 26) & 3, dd = x & 0x3FFFFFFu;
+                        const uint32_t in = kk == 0 ? r0 : (kk == 1 ? r1 : r2);
+                        nr[q] = in > dd ? in - dd : 0u;
+                    } else nr[q] = x;
+                }
+                r0 = nr[0]; r1 = nr[1]; r2 = nr[2];
+            }
+            if (on) {
+                uint32_t *const bk = a.rx_blk + 4 * (size_t)(base + i);
+                bk[0] = ob + inc - o; bk[1] = h0; bk[2] = h1; bk[3] = h2;
+            }
+            ob += rdlane_u(inc, 63);
+        }
+        uint32_t lp = 0;
+        if (lane == 0) lp = atomicAdd(&a.ctr[9], nb);
+        lp = rdlane_u(lp, 0);
+        for (uint32_t i = lane; i < nb; i += 64) a.rx_list[lp + i] = base + i;
+        if (lane == 0) { a.rx_base[c] = (uint32_t)at; atomicAdd(&a.ctr[11], 1u); }
+    }
+}
+
+// (Control flow kept visibly uniform for the compiler — work items by a static stride, every wave-uniform value through
+// readfirstlane, no break out of the group loop.  The first form of this kernel took its items from an atomic cursor and
+// left the group loop by `break`; the structurizer turned that into exec-masked loops whose exit mask on the failure path
+// was the `lane == 0` mask of the statement behind it, and a wave that hit a damaged block went round the same block for
+// ever: tests/test_gpu_fuzz.py::test_every_bit_of_block_heads_in_big_frames hung, any added store made it pass.)
+__global__ __launch_bounds__(64) void k_rx_expand(BxArgs a) {
+    const uint32_t lane = threadIdx.x;
+    const uint32_t n = uni(a.ctr[9] < a.item_cap ? a.ctr[9] : a.item_cap);
+    for (uint32_t wi = blockIdx.x; wi < n; wi += gridDim.x) {
+        const uint32_t slot = uni(a.rx_list[wi]);
+        const FzItem it = a.items[slot];
+        const uint32_t c = uni(a.prep[slot].frame), row = uni(a.cand_row[c]);
+        const uint32_t fb = uni(a.rx_base[c]);
+        const uint32_t *const bk = a.rx_blk + 4 * (size_t)slot;
+        const uint32_t h0 = uni(bk[1]), h1 = uni(bk[2]), h2 = uni(bk[3]);
+        const uint8_t *const src = a.blobs + (uni64(a.blob_off[row]) - a.blob_base);
+        uint32_t *const P = a.rx_ptr + fb;  // P[position inside the frame]
+        const uint32_t nseq = uni(it.nseq), lit_len = uni(it.lit_len), kind = uni(it.lit_kind);
+        const uint64_t lit_off = uni64(it.lit_off);
+        const bool rle = kind == 1;
+        const uint32_t rle_word = RX_DONE | (uint32_t)(uint8_t)lit_off;
+        const uint8_t *const lit_ptr = kind == 0 ? src + lit_off : a.lit_pool + lit_off;
+        const unsigned long long *const recs = a.seq_pool + uni64(it.seq_off);
+        uint32_t pos = uni(bk[0]), lpos = 0;
+        const uint32_t end = pos + uni(it.out);
+        uint32_t fail = 0;  // wave-uniform
+        unsigned long long rec_next = lane < nseq ? recs[lane] : 0ull;
+        for (uint32_t g0 = 0; g0 < nseq && !fail; g0 += 64) {
+            const uint32_t cnt = nseq - g0 < 64 ? nseq - g0 : 64;
+            const bool on = lane < cnt;
+            const unsigned long long rec = on ? rec_next : 0ull;
+            rec_next = g0 + 64 + lane < nseq ? recs[g0 + 64 + lane] : 0ull;
+            const uint32_t ll0 = (uint32_t)rec & 0x1FFFFu, ml0 = (uint32_t)(rec >> 17) & 0x3FFFFu;
+            const uint32_t ov = on ? (uint32_t)(rec >> 35) : 4u;
+            uint32_t offset = ov;
+            if (ov & FZ_SYM) {
+                const uint32_t kk = (ov >> 26) & 3, dd = ov & 0x3FFFFFFu;
+                const uint32_t in = kk == 0 ? h0 : (kk == 1 ? h1 : h2);
+                offset = in > dd ? in - dd : 0u;
+            }
+            const uint32_t linc = wave_incl_scan(ll0), pinc = wave_incl_scan(ll0 + ml0);
+            const uint32_t total = rdlane_u(pinc, 63), lits = rdlane_u(linc, 63);
+            // a match starts at pos + pinc - ml0 and may reach back to the frame's first byte, no further; literals and
+            // output stay inside what the block declared
+            const bool bad = on && (offset == 0 || offset > pos + pinc - ml0);
+            fail = uni((__ballot(bad) != 0ull || lpos + lits > lit_len || total > end - pos) ? 1u : 0u);
+            const uint32_t todo = fail ? 0u : total;
+            for (uint32_t b0 = 0; b0 < todo; b0 += 64) {
+                const uint32_t b = b0 + lane;
+                const bool v = b < total;
+                const uint32_t bb = v ? b : total - 1;
+                uint32_t lo = 0, hi = cnt - 1;  // the sequence that holds byte bb: smallest i with pinc[i] > bb
+#pragma unroll
+                for (int s_ = 0; s_ < 6; s_++) {
+                    const uint32_t mid = (lo + hi) >> 1;
+                    const uint32_t pm = __shfl(pinc, mid);
+                    if (lo < hi) { if (pm > bb) hi = mid; else lo = mid + 1; }
+                }
+                const uint32_t pe = __shfl(pinc, lo), le = __shfl(linc, lo), li = __shfl(ll0, lo), mi = __shfl(ml0, lo), of = __shfl(offset, lo);
+                const uint32_t w = bb - (pe - li - mi);  // position inside the sequence: literals first
+                if (v) {
+                    uint32_t word;
+                    if (w < li) word = rle ? rle_word : (RX_DONE | lit_ptr[lpos + (le - li) + w]);
+                    else word = fb + pos + b - of;
+                    P[pos + b] = word;
+                }
+            }
+            pos += todo; lpos += fail ? 0u : lits;
+        }
+        const uint32_t rest = lit_len - lpos;
+        if (!fail && rest != end - pos) fail = 1;
+        // literals behind the last sequence — or, when the block did not check out, values for every word it has not
+        // written (the frame goes to the serial decoder; no word may stay stale)
+        const uint32_t fill_n = end - pos;
+        for (uint32_t t = lane; t < fill_n; t += 64) P[pos + t] = fail ? RX_DONE : (rle ? rle_word : (RX_DONE | lit_ptr[lpos + t]));
+        if (fail && lane == 0) a.rx_fail[c] = 1;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_rx_jump(BxArgs a, uint32_t round) {
+    if (round && a.rx_pending[round - 1] == 0) return;
+    const unsigned long long used = a.pool_used[11];
+    uint32_t *const P = a.rx_ptr;
+    uint32_t pend = 0;
+    for (unsigned long long e0 = ((unsigned long long)blockIdx.x * 256 + threadIdx.x) * 4; e0 < used; e0 += (unsigned long long)gridDim.x * 1024) {
+        uint4 w = *reinterpret_cast<const uint4 *>(P + e0);
+        uint32_t v[4] = {w.x, w.y, w.z, w.w};
+        bool changed = false;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            if (v[i] & RX_DONE) continue;
+            uint32_t x = v[i];
+            for (uint32_t j = 0; j < RX_JUMPS; j++) {
+                if (x >= used) { x = RX_DONE; break; }  // (cannot happen for words this run wrote: kept as the bound of the read)
+                x = P[x];
+                if (x & RX_DONE) break;
+            }
+            v[i] = x; changed = true;
+            pend |= !(x & RX_DONE);
+        }
+        if (changed) *reinterpret_cast<uint4 *>(P + e0) = make_uint4(v[0], v[1], v[2], v[3]);
+    }
+    if (__ballot(pend != 0) != 0ull && (threadIdx.x & 63) == 0) atomicAdd(&a.rx_pending[round], 1u);
+}
+
+__global__ __launch_bounds__(256) void k_rx_store(BxArgs a) {
+    const unsigned long long used = a.pool_used[11];
+    for (unsigned long long ch = blockIdx.x; ch * 1024 < used; ch += gridDim.x) {
+        const uint32_t c = a.rx_chunk[ch];
+        const uint32_t fb = a.rx_base[c];
+        if (fb == RX_NONE || a.rx_fail[c]) continue;
+        const uint32_t row = a.cand_row[c];
+        const uint32_t fcs = (uint32_t)a.usize[row];
+        const uint32_t rel = (uint32_t)(ch * 1024 - fb) + threadIdx.x * 4;
+        if (rel >= fcs) continue;
+        const uint4 w = *reinterpret_cast<const uint4 *>(a.rx_ptr + ch * 1024 + threadIdx.x * 4);
+        const uint32_t n = fcs - rel < 4 ? fcs - rel : 4;
+        const uint32_t v[4] = {w.x, w.y, w.z, w.w};
+        bool ok = true;
+        for (uint32_t i = 0; i < n; i++) ok = ok && (v[i] & RX_DONE);
+        if (!ok) { a.rx_fail[c] = 1; continue; }  // a chain longer than the rounds cover: cannot happen below 2^31 bytes
+        uint8_t *const d = a.out + a.out_off[row] + rel;
+        if (n == 4 && ((uintptr_t)d & 3) == 0) *reinterpret_cast<uint32_t *>(d) = (v[0] & 255) | (v[1] & 255) << 8 | (v[2] & 255) << 16 | (v[3] & 255) << 24;
+        else for (uint32_t i = 0; i < n; i++) d[i] = (uint8_t)v[i];
+    }
 }
 
 __global__ __launch_bounds__(64) void k_bx_finish(BxArgs a) {
@@ -1756,6 +1969,10 @@ __global__ __launch_bounds__(64) void k_bx_finish(BxArgs a) {
         const uint32_t row = t < n_slots ? a.cand_row[t] : 0xFFFFFFFFu;
         bool left = false;
         if (row != 0xFFFFFFFFu) {
+            if (a.rx_base && a.rx_base[t] != RX_NONE && !a.rx_fail[t]) {  // resolved and stored (k_rx_store found every word a value)
+                a.row_flag[row] = 0;
+                atomicAdd(&a.pool_used[2], 1ull);
+            }
             if (a.row_flag[row]) { a.status[row] = 1; left = true; }
             else a.status[row] = 2;  // decoded: the second hash pass takes it
         }
@@ -1790,7 +2007,14 @@ void launch_bx_stage(const BxArgs &a, int cus, int stage, hipStream_t s) {
         else if (a.small_frames) hipLaunchKernelGGL((k_bx_exec<false, BX_SMALL_HIST, BX_SMALL_CAP, BX_SMALL_WAVES>), cap(slots, 4 * BX_SMALL_WAVES), dim3(64), 0, s, a);
         else hipLaunchKernelGGL((k_bx_exec<false, WIN_HIST, WIN_CAP, 1>), cap(slots, 12), dim3(64), 0, s, a);
         break;
-    default: hipLaunchKernelGGL(k_bx_finish, dim3(lane_grid), dim3(64), 0, s, a); break;
+    case 8: hipLaunchKernelGGL(k_rx_plan, cap(slots, 8), dim3(64), 0, s, a); break;
+    case 9: hipLaunchKernelGGL(k_rx_expand, cap(a.item_cap, 16), dim3(64), 0, s, a); break;  // (static stride over the list)
+    case 30: hipLaunchKernelGGL(k_rx_store, cap((uint32_t)std::min<uint64_t>((a.rx_bound + 1023) / 1024, 1u << 30), 64), dim3(256), 0, s, a); break;
+    case 5: hipLaunchKernelGGL(k_bx_finish, dim3(lane_grid), dim3(64), 0, s, a); break;
+    default:
+        if (stage >= 10 && stage < 10 + (int)RX_ROUNDS)
+            hipLaunchKernelGGL(k_rx_jump, cap((uint32_t)std::min<uint64_t>((a.rx_bound + 1023) / 1024, 1u << 30), 32), dim3(256), 0, s, a, (uint32_t)(stage - 10));
+        break;
     }
 }
 
