@@ -94,6 +94,7 @@ struct znippy_ctx {
     uint64_t bx_fse_cap = 0, bx_huf_cap = 0;
     // the resolve path's word pool (k_rx_*: one 32-bit word per output byte of the big frames) and its chunk -> frame table
     uint32_t *rx_pool = nullptr, *rx_chunk = nullptr;
+    uint8_t *rx_cdone = nullptr;
     uint64_t rx_cap = 0;  // words
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     // kernel timing
@@ -119,6 +120,7 @@ struct znippy_ctx {
         // a few CU-fillings a persistent grid only adds start-up latency)
         unsigned roles_min = 2048;
         unsigned bx_big = BX_BIG_SEQ;  // ZNIPPY_BX_BIG
+        bool bx_big_set = false;
         int ktime = 2;  // per-kernel HIP events: 2 = every kernel, 1 = the dominant read kernels only, 0 = none
     } sw;
     int cus = 256;
@@ -147,7 +149,7 @@ static void read_switches(znippy_ctx *ctx) {
     ctx->sw.no_rx = on("ZNIPPY_NO_RX");  // A/B: big foreign frames executed by a wave each (round 3's first form)
     ctx->sw.no_fuse_hash = on("ZNIPPY_NO_FUSE_HASH");  // A/B: the write side's hash as a kernel of its own beside the encoder (round 2)
     ctx->sw.no_bx = on("ZNIPPY_NO_BX");
-    if (const char *e = getenv("ZNIPPY_BX_BIG")) ctx->sw.bx_big = (unsigned)atoi(e);  // A/B: foreign frames through the round-2 paths (serial decoder + wave-per-block two-phase path)
+    if (const char *e = getenv("ZNIPPY_BX_BIG")) { ctx->sw.bx_big = (unsigned)atoi(e); ctx->sw.bx_big_set = true; }  // A/B: foreign frames through the round-2 paths (serial decoder + wave-per-block two-phase path)
     if (const char *lv = getenv("ZNIPPY_LEVEL")) { const int v = atoi(lv); if (v >= 1 && v <= 22) ctx->level = v; }  // initial level of every context (tests, A/B runs)
     if (const char *gs = getenv("ZNIPPY_GEN_SHARE")) { const int v = atoi(gs); if (v >= 1 && v <= 4) ctx->gen_share = v; }  // A/B
     ctx->sw.fz_only = on("ZNIPPY_FZ_ONLY");  // test hook: no serial fallback behind the two-phase path (what it leaves shows up as corrupt rows)
@@ -400,6 +402,7 @@ struct znippy_rows {
     // batch path (k_bx_*): candidate slots (one per compressed row at most), item slots, the two entropy work lists
     uint32_t bx_slots = 0, bx_item_cap = 0;
     uint64_t bx_bytes = 0;  // content bytes of all compressed rows
+    uint64_t bx_nblk = 0;   // their 128 KiB blocks, as the index columns have them
     uint32_t *bx_cand_row = nullptr, *bx_cand_base = nullptr, *bx_cand_nb = nullptr, *bx_huf_list = nullptr, *bx_seq_list = nullptr, *bx_sort_tmp = nullptr;
     zn::FzItem *bx_items = nullptr;
     zn::BxPrep *bx_prep = nullptr;
@@ -559,11 +562,13 @@ static int ensure_rx_pool(znippy_ctx *ctx, uint64_t words) {
     (void)hipStreamSynchronize(ctx->stream);
     if (ctx->rx_pool) (void)hipFree(ctx->rx_pool);
     if (ctx->rx_chunk) (void)hipFree(ctx->rx_chunk);
-    ctx->rx_pool = nullptr; ctx->rx_chunk = nullptr; ctx->rx_cap = 0;
-    if (hipMalloc(&ctx->rx_pool, words * 4) != hipSuccess || hipMalloc(&ctx->rx_chunk, words / 1024 * 4) != hipSuccess) {
+    if (ctx->rx_cdone) (void)hipFree(ctx->rx_cdone);
+    ctx->rx_pool = nullptr; ctx->rx_chunk = nullptr; ctx->rx_cdone = nullptr; ctx->rx_cap = 0;
+    if (hipMalloc(&ctx->rx_pool, words * 4) != hipSuccess || hipMalloc(&ctx->rx_chunk, words / 1024 * 4) != hipSuccess || hipMalloc(&ctx->rx_cdone, words / 1024) != hipSuccess) {
         (void)hipGetLastError();
         if (ctx->rx_pool) (void)hipFree(ctx->rx_pool);
-        ctx->rx_pool = nullptr; ctx->rx_chunk = nullptr;
+        if (ctx->rx_chunk) (void)hipFree(ctx->rx_chunk);
+        ctx->rx_pool = nullptr; ctx->rx_chunk = nullptr; ctx->rx_cdone = nullptr;
         return ZNIPPY_OK;  // no pool: the frames are executed by a wave each
     }
     ctx->rx_cap = words;
@@ -764,6 +769,7 @@ static void ctx_teardown(znippy_ctx *ctx) {
     if (ctx->bx_huf_pool) (void)hipFree(ctx->bx_huf_pool);
     if (ctx->rx_pool) (void)hipFree(ctx->rx_pool);
     if (ctx->rx_chunk) (void)hipFree(ctx->rx_chunk);
+    if (ctx->rx_cdone) (void)hipFree(ctx->rx_cdone);
     if (ctx->cursor) (void)hipFree(ctx->cursor);
     if (ctx->shim_in) (void)hipFree(ctx->shim_in);
     if (ctx->shim_out) (void)hipFree(ctx->shim_out);
@@ -1060,6 +1066,7 @@ int znippy_rows_create(znippy_ctx *ctx, const uint64_t *blob_offset, const uint6
             // a writer may split blocks (libzstd's high levels cut a 128 KiB block into 2-5; runs of equal bytes come as
             // strings of small RLE blocks): half as many again + up to 64k more, shared by all frames.  Frames that find no
             // slot stay with the serial decoder.
+            r->bx_nblk = nblk;
             const uint64_t cap = nblk + nblk / 2 + std::min<uint64_t>(3 * nblk, 65536) + 1024;
             if (cap < 0x7FFFFFFFull) {
                 r->bx_slots = r->n_compressed;
@@ -1436,10 +1443,12 @@ int znippy_decode_verify_rows_async(znippy_ctx *ctx, znippy_rows *r, const void 
             x.fse_pool = ctx->bx_fse_pool; x.fse_cap = ctx->bx_fse_cap; x.huf_pool = ctx->bx_huf_pool; x.huf_cap = ctx->bx_huf_cap;
             x.pool_used = reinterpret_cast<unsigned long long *>(r->ctl + 256);
             x.pending2 = r->pending2; x.pending2_count = r->pending_count + 1;
-            x.big_seq = ctx->sw.bx_big;
+            // 0: the blocks that get a wave of their own are picked from the table's histogram (k_bx_split: one workgroup per
+            // list, worth its ~0.1-0.4 ms where the chip is not full of blocks anyway); big tables keep the fixed threshold
+            x.big_seq = ctx->sw.bx_big_set || r->bx_nblk > 32768 ? ctx->sw.bx_big : 0u;
             const bool rx = r->rx_base && ctx->rx_pool;
             if (rx) {
-                x.rx_ptr = ctx->rx_pool; x.rx_cap = ctx->rx_cap; x.rx_chunk = ctx->rx_chunk;
+                x.rx_ptr = ctx->rx_pool; x.rx_cap = ctx->rx_cap; x.rx_chunk = ctx->rx_chunk; x.rx_cdone = ctx->rx_cdone;
                 x.rx_base = r->rx_base; x.rx_fail = r->rx_fail; x.rx_blk = r->rx_blk; x.rx_list = r->rx_list;
                 x.rx_pending = reinterpret_cast<uint32_t *>(r->ctl + 448);
                 x.rx_bound = std::min<uint64_t>(r->rx_words, ctx->rx_cap);
@@ -1492,9 +1501,16 @@ int znippy_decode_verify_rows_async(znippy_ctx *ctx, znippy_rows *r, const void 
                             (unsigned long long)ctx->rx_cap, r->bx_item_cap);
                 }
                 stage(9, s);
-                ktime_begin(ctx, "zstd_resolve_jump", s);
-                for (int rd = 0; rd < (int)zn::RX_ROUNDS; rd++) launch_bx_stage(x, ctx->cus, 10 + rd, s);
-                ktime_end(ctx, s);
+                static const char *const jump_names[12] = {"zstd_resolve_jump_0", "zstd_resolve_jump_1", "zstd_resolve_jump_2", "zstd_resolve_jump_3", "zstd_resolve_jump_4", "zstd_resolve_jump_5",
+                                                           "zstd_resolve_jump_6", "zstd_resolve_jump_7", "zstd_resolve_jump_8", "zstd_resolve_jump_9", "zstd_resolve_jump_10", "zstd_resolve_jump_11"};
+                static_assert(zn::RX_ROUNDS <= 12, "names");
+                if (!ctx->sw.ddbg) ktime_begin(ctx, "zstd_resolve_jump", s);
+                for (int rd = 0; rd < (int)zn::RX_ROUNDS; rd++) {
+                    if (ctx->sw.ddbg) ktime_begin(ctx, jump_names[rd], s);  // diagnostic: every round by itself
+                    launch_bx_stage(x, ctx->cus, 10 + rd, s);
+                    if (ctx->sw.ddbg) ktime_end(ctx, s);
+                }
+                if (!ctx->sw.ddbg) ktime_end(ctx, s);
                 ktime_begin(ctx, "zstd_resolve_store", s);
                 launch_bx_stage(x, ctx->cus, 30, s);
                 ktime_end(ctx, s);

@@ -254,6 +254,7 @@ struct BxArgs {
     // cursor, [11] frames taken; pool_used[10] words handed out, [11] words in use (the extent the rounds run over).
     uint32_t *rx_ptr; uint64_t rx_cap;  // the word pool (rx_cap < 2^31 words: a word with bit 31 clear is an index)
     uint32_t *rx_chunk;                 // 1,024-word chunk of the pool -> candidate slot
+    uint8_t *rx_cdone;                  // ... -> every word of the chunk is a value (set by a jump round, cleared by the plan)
     uint32_t *rx_base, *rx_fail;        // per candidate slot: first word (RX_NONE: not taken), a block did not check out
     uint32_t *rx_blk;                   // per block item: first output byte inside the frame, incoming repeat offsets [3]
     uint32_t *rx_list;                  // block items to expand

@@ -1324,7 +1324,8 @@ __global__ __launch_bounds__(64) void k_bx_prep(BxArgs a) {
                 cls = cells <= 384 ? 0u : (cells <= 768 ? 1u : 2u);
                 // a long chain gets a wave of its own (k_bx_fse_wave); so does a stream that starts within 64 bytes of the blob
                 // region's first byte (the lane kernel's buffer loads reach 64 bytes in front of the stream, the wave decoder's do not)
-                if (it.nseq >= a.big_seq || (a.blob_off[a.cand_row[pr.frame]] - a.blob_base) + pr.bs_off < 64) cls = 3;
+                // (a.big_seq == 0: the long chains are picked from the table's histogram afterwards, k_bx_split)
+                if ((a.big_seq && it.nseq >= a.big_seq) || (a.blob_off[a.cand_row[pr.frame]] - a.blob_base) + pr.bs_off < 64) cls = 3;
             }
         }
         {   // the block joins the lists of the two entropy kernels
@@ -1344,6 +1345,86 @@ __global__ __launch_bounds__(64) void k_bx_prep(BxArgs a) {
             }
         }
     }
+}
+
+// Which blocks get a wave of their own in the sequence stage?  A chain runs ~4x faster there (0.23 against ~1.1 us per
+// sequence when the wave is alone on its SIMD) but costs the chip ~1,100 SIMD cycles per sequence (measured: 19.9 M sequences
+// of 8,192 blocks, 16 waves per CU: 10.6 ms = 0.55 us per sequence per SIMD), where the lane kernel does 64 sequences in
+// ~2,000.  So: the longest blocks, as many as keep the wave kernel's work below the lane kernel's pole —
+// sum(nseq >= T) * 0.55 us / 1,024 SIMDs <= T * 1.1 us, i.e. sum <= 2,048 T — with T taken from a histogram of the table's
+// blocks (8 classes per octave).  A table of 8,192 blocks of ~2,400 sequences: T ~ 3,000 (10.6 -> ~3.5 ms); the image's
+// source text (5,500 blocks, a few of 15,000 sequences): T ~ 1,000.  One workgroup per lane list: the histogram over all
+// three, then its own list compacted in place, the long ones appended to the wave list.
+__global__ __launch_bounds__(1024) void k_bx_split(BxArgs a) {
+    __shared__ uint32_t hist[256], wcnt[16], sT, skept;
+    const uint32_t which = blockIdx.x, t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const uint32_t cidx[3] = {3, 5, 6};
+    if (t < 256) hist[t] = 0;
+    __syncthreads();
+    for (uint32_t l = 0; l < 3; l++) {
+        const uint32_t n = a.ctr[cidx[l]] < a.item_cap ? a.ctr[cidx[l]] : a.item_cap;
+        const uint32_t *const list = a.seq_list + (size_t)l * a.item_cap;
+        for (uint32_t i0 = 0; i0 < n; i0 += 1024) {  // (whole waves: the classes of a wave's 64 blocks are counted together —
+            const uint32_t i = i0 + t;                 //  a table of like blocks is 100,000 additions to one LDS word otherwise)
+            uint32_t k = 0xFFFFFFFFu;
+            if (i < n) {
+                const uint32_t v = a.items[list[i]].nseq;
+                const uint32_t hb = v ? 31u - (uint32_t)__clz(v) : 0u;
+                k = v < 16 ? v : 8 * hb + ((v >> (hb - 3)) & 7u);
+                k = k > 255u ? 255u : k;
+            }
+            uint64_t left = __ballot(k != 0xFFFFFFFFu);
+            while (left) {
+                const uint32_t k0 = (uint32_t)__builtin_amdgcn_readlane((int)k, (int)((uint32_t)__ffsll((long long)left) - 1));
+                const uint64_t same = __ballot(k == k0);
+                if (lane == (uint32_t)__ffsll((long long)left) - 1) atomicAdd(&hist[k0], (uint32_t)__popcll(same));
+                left &= ~same;
+            }
+        }
+    }
+    __syncthreads();
+    if (t == 0) {
+        unsigned long long S = 0;
+        uint32_t T = 0xFFFFFFFFu;
+        for (int k = 255; k >= 16; k--) {
+            const uint32_t cn = hist[k];
+            if (!cn) continue;
+            const uint32_t hb = (uint32_t)k >> 3, lb = (8u + ((uint32_t)k & 7u)) << (hb - 3);  // smallest nseq of the class
+            if (lb < 256) break;
+            S += (unsigned long long)cn * (lb + (lb >> 4));
+            if (S > 2048ull * lb) break;
+            T = lb;
+        }
+        sT = T; skept = 0;
+    }
+    __syncthreads();
+    const uint32_t T = sT;
+    uint32_t *const list = a.seq_list + (size_t)which * a.item_cap;
+    uint32_t *const wave_list = a.seq_list + 3 * (size_t)a.item_cap;
+    const uint32_t n = a.ctr[cidx[which]] < a.item_cap ? a.ctr[cidx[which]] : a.item_cap;
+    if (T == 0xFFFFFFFFu) return;  // (uniform) nothing is long enough
+    for (uint32_t base = 0; base < n; base += 1024) {
+        const uint32_t i = base + t;
+        const uint32_t slot = i < n ? list[i] : 0;
+        const bool mv = i < n && a.items[slot].nseq >= T, keep = i < n && !mv;
+        const uint64_t km = __ballot(keep), mm = __ballot(mv);
+        const uint64_t below = lane ? (~0ull >> (64 - lane)) : 0ull;
+        if (lane == 0) wcnt[wv] = (uint32_t)__popcll(km);
+        uint32_t mb = 0;
+        if (lane == 0 && mm) mb = atomicAdd(&a.ctr[7], (uint32_t)__popcll(mm));
+        mb = (uint32_t)__builtin_amdgcn_readfirstlane((int)mb);
+        __syncthreads();  // every thread has read its entry; the waves' counts are in place
+        uint32_t before = skept;
+        for (uint32_t w = 0; w < wv; w++) before += wcnt[w];
+        uint32_t tile = 0;
+        for (uint32_t w = 0; w < 16; w++) tile += wcnt[w];
+        if (keep) list[before + (uint32_t)__popcll(km & below)] = slot;
+        if (mv) { const uint32_t at = mb + (uint32_t)__popcll(mm & below); if (at < a.item_cap) wave_list[at] = slot; }
+        __syncthreads();
+        if (t == 0) skept += tile;
+        __syncthreads();
+    }
+    if (t == 0) a.ctr[cidx[which]] = skept;
 }
 
 // The entropy kernels run a wave for as long as its longest lane: the work lists are ordered by size (descending: the long
@@ -1764,6 +1845,18 @@ __global__ __launch_bounds__(64, WAVES) void k_bx_exec(BxArgs a) {
 // or the final value, and 32-bit stores are whole.  Malformed input (mutants) only ever produces words that point
 // backwards inside their own frame: offsets are checked against the position when the words are written.
 // =============================================================================================
+// OR of a 64-bit value over the wave's 64 lanes (wave-uniform result), on the DPP path like wave_incl_scan
+__device__ __forceinline__ uint32_t wave_or32(uint32_t v) {
+    v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true);   // row_shr:1
+    v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true);   // row_shr:2
+    v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, true);   // row_shr:4
+    v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, true);   // row_shr:8
+    v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);  // row_bcast:15 -> rows 1, 3
+    v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);  // row_bcast:31 -> rows 2, 3
+    return rdlane_u(v, 63);
+}
+__device__ __forceinline__ uint64_t wave_or64(uint64_t v) { return ((uint64_t)wave_or32((uint32_t)(v >> 32)) << 32) | wave_or32((uint32_t)v); }
+
 __global__ __launch_bounds__(64) void k_rx_plan(BxArgs a) {
     const uint32_t lane = threadIdx.x;
     const uint32_t n_slots = a.ctr[0];
@@ -1792,7 +1885,7 @@ __global__ __launch_bounds__(64) void k_rx_plan(BxArgs a) {
         at = rdlane64_u(at, 0);
         if (at + need > a.rx_cap) continue;  // pool full (every later request fails too: the words in use stay one prefix)
         if (lane == 0) atomicMax(&a.pool_used[11], at + need);
-        for (uint32_t i = lane; i < need / 1024; i += 64) a.rx_chunk[at / 1024 + i] = c;
+        for (uint32_t i = lane; i < need / 1024; i += 64) { a.rx_chunk[at / 1024 + i] = c; a.rx_cdone[at / 1024 + i] = 0; }
         for (uint32_t i = (uint32_t)fcs + lane; i < need; i += 64) a.rx_ptr[at + i] = RX_DONE;  // padding behind the frame
         // per block: where its output starts, and the repeat offsets it starts with (the blocks' own records were decoded
         // against a symbolic history; composed here block by block, as the serial executor does between blocks)
@@ -1881,18 +1974,24 @@ __global__ __launch_bounds__(64) void k_rx_expand(BxArgs a) {
             const bool bad = on && (offset == 0 || offset > pos + pinc - ml0);
             fail = uni((__ballot(bad) != 0ull || lpos + lits > lit_len || total > end - pos) ? 1u : 0u);
             const uint32_t todo = fail ? 0u : total;
+            // Which sequence holds byte b?  Sequences are at least 3 bytes long and start in increasing order: every
+            // sequence lane whose first byte lies in the 64-byte window sets that byte's bit, the bits are OR-ed across
+            // the wave (DPP: no LDS round trip), and byte lane b counts the bits at or below its own — the number of
+            // sequences that have started — on top of those of the windows before.  (First form: a binary search over
+            // the inclusive sums through __shfl, six dependent LDS crossbar trips per 64 bytes: 3.5 ms per GB.)
+            const uint32_t start = pinc - (ll0 + ml0);
+            uint32_t started = 0;  // sequences whose first byte lies before the window (wave-uniform)
             for (uint32_t b0 = 0; b0 < todo; b0 += 64) {
                 const uint32_t b = b0 + lane;
                 const bool v = b < total;
-                const uint32_t bb = v ? b : total - 1;
-                uint32_t lo = 0, hi = cnt - 1;  // the sequence that holds byte bb: smallest i with pinc[i] > bb
-#pragma unroll
-                for (int s_ = 0; s_ < 6; s_++) {
-                    const uint32_t mid = (lo + hi) >> 1;
-                    const uint32_t pm = __shfl(pinc, mid);
-                    if (lo < hi) { if (pm > bb) hi = mid; else lo = mid + 1; }
-                }
+                const bool mine = on && (ll0 + ml0) != 0 && start >= b0 && start < b0 + 64;
+                const uint64_t M = wave_or64(mine ? 1ull << (start - b0) : 0ull);
+                const uint64_t le_mask = lane == 63 ? ~0ull : ((2ull << lane) - 1ull);
+                uint32_t lo = started + (uint32_t)__popcll(M & le_mask);
+                lo = lo ? lo - 1 : 0;  // (a group's first sequence starts at byte 0: lo >= 1 for every byte)
+                started += (uint32_t)__popcll(M);
                 const uint32_t pe = __shfl(pinc, lo), le = __shfl(linc, lo), li = __shfl(ll0, lo), mi = __shfl(ml0, lo), of = __shfl(offset, lo);
+                const uint32_t bb = v ? b : pe - 1;
                 const uint32_t w = bb - (pe - li - mi);  // position inside the sequence: literals first
                 if (v) {
                     uint32_t word;
@@ -1918,46 +2017,76 @@ __global__ __launch_bounds__(256) void k_rx_jump(BxArgs a, uint32_t round) {
     const unsigned long long used = a.pool_used[11];
     uint32_t *const P = a.rx_ptr;
     uint32_t pend = 0;
-    for (unsigned long long e0 = ((unsigned long long)blockIdx.x * 256 + threadIdx.x) * 4; e0 < used; e0 += (unsigned long long)gridDim.x * 1024) {
+    // workgroup = one chunk of 1,024 words per step; a chunk whose words are all values is marked and skipped from then on
+    // (after the first round most are: the later rounds then read a byte per chunk instead of 4 KiB)
+    for (unsigned long long ch = blockIdx.x; ch * 1024 < used; ch += gridDim.x) {
+        if (uni((uint32_t)a.rx_cdone[ch])) continue;  // (read by every thread, made visibly uniform: a barrier follows)
+        const unsigned long long e0 = ch * 1024 + threadIdx.x * 4;
         uint4 w = *reinterpret_cast<const uint4 *>(P + e0);
         uint32_t v[4] = {w.x, w.y, w.z, w.w};
         bool changed = false;
+        uint32_t mine = 0;
+        // the four bytes of a thread mostly belong to one match: their words point at four consecutive words, which are
+        // one 16-byte load (any 4-byte boundary) — and the words found there are often consecutive again
+        uint32_t hops = 0;
+        while (hops < RX_JUMPS && !((v[0] | v[1] | v[2] | v[3]) & RX_DONE) && v[1] == v[0] + 1 && v[2] == v[0] + 2 && v[3] == v[0] + 3 &&
+               (unsigned long long)v[0] + 4 <= used) {
+            const uint4 q = *reinterpret_cast<const uint4 *>(P + v[0]);
+            v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+            changed = true;
+            hops++;
+        }
 #pragma unroll
         for (int i = 0; i < 4; i++) {
             if (v[i] & RX_DONE) continue;
             uint32_t x = v[i];
-            for (uint32_t j = 0; j < RX_JUMPS; j++) {
+            for (uint32_t j = hops; j < RX_JUMPS; j++) {
                 if (x >= used) { x = RX_DONE; break; }  // (cannot happen for words this run wrote: kept as the bound of the read)
                 x = P[x];
                 if (x & RX_DONE) break;
             }
             v[i] = x; changed = true;
-            pend |= !(x & RX_DONE);
+            mine |= !(x & RX_DONE);
         }
         if (changed) *reinterpret_cast<uint4 *>(P + e0) = make_uint4(v[0], v[1], v[2], v[3]);
+        const int any = __syncthreads_or((int)mine);
+        if (!any && threadIdx.x == 0) a.rx_cdone[ch] = 1;
+        pend |= (uint32_t)any;
     }
-    if (__ballot(pend != 0) != 0ull && (threadIdx.x & 63) == 0) atomicAdd(&a.rx_pending[round], 1u);
+    if (pend && threadIdx.x == 0) atomicAdd(&a.rx_pending[round], 1u);
 }
 
+// The values leave as the rows' bytes.  A row starts at any address: thread t of a chunk writes the ALIGNED dword that holds
+// bytes [4t - m, 4t - m + 4) of the chunk (m = the row address's low two bits), from four consecutive words (a 16-byte
+// load on a 4-byte boundary); the bytes at a row's two ends that do not fill a dword are stored one by one.
 __global__ __launch_bounds__(256) void k_rx_store(BxArgs a) {
     const unsigned long long used = a.pool_used[11];
     for (unsigned long long ch = blockIdx.x; ch * 1024 < used; ch += gridDim.x) {
-        const uint32_t c = a.rx_chunk[ch];
-        const uint32_t fb = a.rx_base[c];
-        if (fb == RX_NONE || a.rx_fail[c]) continue;
-        const uint32_t row = a.cand_row[c];
-        const uint32_t fcs = (uint32_t)a.usize[row];
-        const uint32_t rel = (uint32_t)(ch * 1024 - fb) + threadIdx.x * 4;
-        if (rel >= fcs) continue;
-        const uint4 w = *reinterpret_cast<const uint4 *>(a.rx_ptr + ch * 1024 + threadIdx.x * 4);
-        const uint32_t n = fcs - rel < 4 ? fcs - rel : 4;
-        const uint32_t v[4] = {w.x, w.y, w.z, w.w};
+        const uint32_t c = uni(a.rx_chunk[ch]);
+        const uint32_t fb = uni(a.rx_base[c]);
+        if (fb == RX_NONE || uni(a.rx_fail[c])) continue;
+        const uint32_t row = uni(a.cand_row[c]);
+        const uint32_t fcs = uni((uint32_t)a.usize[row]);
+        uint8_t *const D = a.out + uni64(a.out_off[row]);
+        const uint32_t m = (uint32_t)((uintptr_t)D & 3);
+        const uint32_t r0 = (uint32_t)(ch * 1024 - fb);
+        const int64_t rel = (int64_t)r0 + 4 * (int64_t)threadIdx.x - m;  // first byte of this thread's dword, inside the row
+        const uint32_t *const W = a.rx_ptr + fb;
         bool ok = true;
-        for (uint32_t i = 0; i < n; i++) ok = ok && (v[i] & RX_DONE);
-        if (!ok) { a.rx_fail[c] = 1; continue; }  // a chain longer than the rounds cover: cannot happen below 2^31 bytes
-        uint8_t *const d = a.out + a.out_off[row] + rel;
-        if (n == 4 && ((uintptr_t)d & 3) == 0) *reinterpret_cast<uint32_t *>(d) = (v[0] & 255) | (v[1] & 255) << 8 | (v[2] & 255) << 16 | (v[3] & 255) << 24;
-        else for (uint32_t i = 0; i < n; i++) d[i] = (uint8_t)v[i];
+        if (rel >= 0 && rel + 4 <= (int64_t)fcs) {
+            const uint4 w = *reinterpret_cast<const uint4 *>(W + rel);
+            ok = ((w.x & w.y & w.z & w.w) & RX_DONE) != 0;
+            *reinterpret_cast<uint32_t *>(D + rel) = (w.x & 255) | (w.y & 255) << 8 | (w.z & 255) << 16 | (w.w & 255) << 24;
+        } else {
+            for (int i = 0; i < 4; i++) {
+                const int64_t p = rel + i;
+                if (p >= 0 && p < (int64_t)fcs) { const uint32_t x = W[p]; ok = ok && (x & RX_DONE); D[p] = (uint8_t)x; }
+            }
+        }
+        // the chunks cover [-m, need - m): a row that fills its last chunk to the end has m more bytes
+        if (threadIdx.x == 255 && r0 + 1024 >= fcs)
+            for (uint32_t p = r0 + 1024 - m; p < fcs; p++) { const uint32_t x = W[p]; ok = ok && (x & RX_DONE); D[p] = (uint8_t)x; }
+        if (!ok) a.rx_fail[c] = 1;  // a chain longer than the rounds cover: cannot happen below 2^31 bytes
     }
 }
 
@@ -1994,14 +2123,17 @@ void launch_bx_stage(const BxArgs &a, int cus, int stage, hipStream_t s) {
     switch (stage) {
     case 0: hipLaunchKernelGGL(k_bx_scan, dim3(lane_grid), dim3(64), 0, s, a); break;
     case 1: hipLaunchKernelGGL(k_bx_prep, cap((a.item_cap + 63) / 64, 3), dim3(64), 0, s, a); break;
-    case 7: hipLaunchKernelGGL(k_bx_sort, dim3(5), dim3(1024), 0, s, a, a.sort_tmp); break;
+    case 7:
+        if (!a.big_seq) hipLaunchKernelGGL(k_bx_split, dim3(3), dim3(1024), 0, s, a);
+        hipLaunchKernelGGL(k_bx_sort, dim3(5), dim3(1024), 0, s, a, a.sort_tmp);
+        break;
     case 2: hipLaunchKernelGGL(k_bx_huf, cap((a.item_cap + BX_HUF_BLOCKS - 1) / BX_HUF_BLOCKS, 2), dim3(64), 0, s, a); break;
     case 3:
         hipLaunchKernelGGL(k_bx_fse, cap((a.item_cap + 63) / 64, 3), dim3(64), 0, s, a, a.seq_list, a.ctr + 3, 64u);
         hipLaunchKernelGGL(k_bx_fse, cap((a.item_cap + 31) / 32, 3), dim3(64), 0, s, a, a.seq_list + a.item_cap, a.ctr + 5, 32u);
         hipLaunchKernelGGL(k_bx_fse, cap((a.item_cap + 15) / 16, 3), dim3(64), 0, s, a, a.seq_list + 2 * (size_t)a.item_cap, a.ctr + 6, 16u);
         break;
-    case 6: hipLaunchKernelGGL(k_bx_fse_wave, cap(a.item_cap, 12), dim3(64), 0, s, a, a.seq_list + 3 * (size_t)a.item_cap, a.ctr + 7); break;
+    case 6: hipLaunchKernelGGL(k_bx_fse_wave, cap(a.item_cap, 16), dim3(64), 0, s, a, a.seq_list + 3 * (size_t)a.item_cap, a.ctr + 7); break;  // 10 KB of LDS per wave: 16 per CU
     case 4:
         if (a.dbg) hipLaunchKernelGGL((k_bx_exec<true, WIN_HIST, WIN_CAP, 1>), cap(slots, 12), dim3(64), 0, s, a);
         else if (a.small_frames) hipLaunchKernelGGL((k_bx_exec<false, BX_SMALL_HIST, BX_SMALL_CAP, BX_SMALL_WAVES>), cap(slots, 4 * BX_SMALL_WAVES), dim3(64), 0, s, a);

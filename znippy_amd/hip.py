@@ -66,9 +66,9 @@ class Context:
         self._chk(self.L.znippy_ctx_sync(self.h), "znippy_ctx_sync")
 
     def kernel_times(self):
-        names = (C.c_char_p * 16)()
-        ms = (C.c_float * 16)()
-        n = self.L.znippy_last_kernel_times(self.h, names, ms, 16)
+        names = (C.c_char_p * 48)()
+        ms = (C.c_float * 48)()
+        n = self.L.znippy_last_kernel_times(self.h, names, ms, 48)
         return [(names[i].decode(), float(ms[i])) for i in range(n)]
 
     def set_level(self, level):
