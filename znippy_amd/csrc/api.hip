@@ -407,6 +407,9 @@ struct znippy_rows {
     zn::FzItem *bx_items = nullptr;
     zn::BxPrep *bx_prep = nullptr;
     uint64_t rx_words = 0;  // resolve path: words its frames (compressed rows of >= RX_MIN bytes) can ask for
+    uint64_t rx_words_small = 0;  // ... counting every row above 64 KiB
+    uint32_t rx_min = zn::RX_MIN;  // a table whose rows above 64 KiB are few (<= 256 M words) resolves all of them: one wave per frame is the slower way
+                                   // when the frames do not fill the chip (the image's source text: its 64-256 KiB frames were 1.6 ms of one-wave execution)
     uint32_t *rx_base = nullptr, *rx_fail = nullptr, *rx_blk = nullptr, *rx_list = nullptr;
     uint32_t *item_row = nullptr, *item_k = nullptr, *item_src = nullptr, *row_flag = nullptr;
     // fused block kernel: big-slice tiles of the candidate rows, the item each belongs to, and what it got done
@@ -1030,6 +1033,7 @@ int znippy_rows_create(znippy_ctx *ctx, const uint64_t *blob_offset, const uint6
             if (!c) continue;
             nblk += us ? (us + BLK - 1) / BLK : 1;
             r->bx_bytes += us;
+            if (us > 65536 && us < (1ull << 30)) r->rx_words_small += (us + 1023) & ~1023ull;
             if (us >= zn::RX_MIN && us < (1ull << 30)) r->rx_words += (us + 1023) & ~1023ull;
             if (us <= 64 * 1024) continue;
             big_bytes += us;
@@ -1067,6 +1071,7 @@ int znippy_rows_create(znippy_ctx *ctx, const uint64_t *blob_offset, const uint6
             // strings of small RLE blocks): half as many again + up to 64k more, shared by all frames.  Frames that find no
             // slot stay with the serial decoder.
             r->bx_nblk = nblk;
+            if (r->rx_words_small && r->rx_words_small <= (256ull << 20)) { r->rx_min = 65537; r->rx_words = r->rx_words_small; }
             const uint64_t cap = nblk + nblk / 2 + std::min<uint64_t>(3 * nblk, 65536) + 1024;
             if (cap < 0x7FFFFFFFull) {
                 r->bx_slots = r->n_compressed;
@@ -1075,7 +1080,7 @@ int znippy_rows_create(znippy_ctx *ctx, const uint64_t *blob_offset, const uint6
                     tmalloc(ctx, &r->bx_cand_nb, 4 * (size_t)r->bx_slots) != hipSuccess || tmalloc(ctx, &r->bx_huf_list, 4 * (size_t)cap) != hipSuccess ||
                     tmalloc(ctx, &r->bx_seq_list, 4 * 4 * (size_t)cap) != hipSuccess || tmalloc(ctx, &r->bx_sort_tmp, 5 * 4 * (size_t)cap) != hipSuccess || tmalloc(ctx, &r->bx_items, sizeof(zn::FzItem) * (size_t)cap) != hipSuccess ||
                     tmalloc(ctx, &r->bx_prep, sizeof(zn::BxPrep) * (size_t)cap) != hipSuccess ||
-                    (r->rx_words && !ctx->sw.no_rx &&
+                    ((r->rx_words || r->rx_words_small) && !ctx->sw.no_rx &&
                      (tmalloc(ctx, &r->rx_base, 4 * (size_t)r->bx_slots) != hipSuccess || tmalloc(ctx, &r->rx_fail, 4 * (size_t)r->bx_slots) != hipSuccess ||
                       tmalloc(ctx, &r->rx_blk, 16 * (size_t)cap) != hipSuccess || tmalloc(ctx, &r->rx_list, 4 * (size_t)cap) != hipSuccess))) {
                     znippy_rows_destroy(r);
@@ -1446,12 +1451,13 @@ int znippy_decode_verify_rows_async(znippy_ctx *ctx, znippy_rows *r, const void 
             // 0: the blocks that get a wave of their own are picked from the table's histogram (k_bx_split: one workgroup per
             // list, worth its ~0.1-0.4 ms where the chip is not full of blocks anyway); big tables keep the fixed threshold
             x.big_seq = ctx->sw.bx_big_set || r->bx_nblk > 32768 ? ctx->sw.bx_big : 0u;
-            const bool rx = r->rx_base && ctx->rx_pool;
+            const bool rx = r->rx_base && ctx->rx_pool && r->rx_words;
             if (rx) {
                 x.rx_ptr = ctx->rx_pool; x.rx_cap = ctx->rx_cap; x.rx_chunk = ctx->rx_chunk; x.rx_cdone = ctx->rx_cdone;
                 x.rx_base = r->rx_base; x.rx_fail = r->rx_fail; x.rx_blk = r->rx_blk; x.rx_list = r->rx_list;
                 x.rx_pending = reinterpret_cast<uint32_t *>(r->ctl + 448);
                 x.rx_bound = std::min<uint64_t>(r->rx_words, ctx->rx_cap);
+                x.rx_min = r->rx_min;
             }
             x.small_frames = r->n_compressed && r->bx_bytes / r->n_compressed <= 65536;
             if (ctx->sw.ddbg) {  // diagnostic: where the previous run's table kernel spent its waves' time

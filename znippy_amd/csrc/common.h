@@ -260,6 +260,7 @@ struct BxArgs {
     uint32_t *rx_list;                  // block items to expand
     uint32_t *rx_pending;               // [round]: words still unresolved after that round (zeroed per run)
     uint64_t rx_bound;                  // host's bound on the words a run can use (grid sizing)
+    uint32_t rx_min;                    // frames of at least this many bytes are resolved (RX_MIN; less for tables with few rows above 64 KiB)
 };
 constexpr uint32_t RX_NONE = 0xFFFFFFFFu, RX_DONE = 0x80000000u, RX_MIN = 256u << 10, RX_ROUNDS = 12, RX_JUMPS = 6;
 void launch_bx_stage(const BxArgs &a, int cus, int stage, hipStream_t s);  // 0 scan, 1 prep, 7 sort the work lists, 2 huf, 3 fse (lane = block), 4 exec, 5 finish, 6 fse (wave = block), 8 resolve: plan, 9 expand, 10 + r jump round r, 30 store

@@ -1865,7 +1865,7 @@ __global__ __launch_bounds__(64) void k_rx_plan(BxArgs a) {
         const uint32_t nb = a.cand_nb[c], row = a.cand_row[c];
         if (!nb || row == 0xFFFFFFFFu) continue;
         const uint64_t fcs = a.usize[row];
-        if (fcs < RX_MIN || fcs >= (1ull << 30)) continue;
+        if (fcs < a.rx_min || fcs >= (1ull << 30)) continue;
         const uint32_t base = a.cand_base[c];
         {   // every block came through the entropy stages and the sizes add up (as fz_exec_frame checks)
             unsigned long long tot = 0, seqs = 0;
