@@ -377,6 +377,7 @@ def main():
             assert int(e_["blob_size"].sum()) > 0
             best = dt_ if best is None else min(best, dt_)
         return best
+    ctx.set_kernel_timing(timed_level)  # as in the timed steps (the kernel-time collection above brackets every kernel)
     ss_read = None if args.headline_only else single_shot_read(archives[archive_kind])
     ss_write = single_shot_write()
     for k, leg in legs.items():  # every step of every read leg (warmup, timed, kernel-time collection) verified every byte
