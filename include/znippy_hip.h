@@ -120,7 +120,12 @@ int znippy_rows_set_blob_cap(znippy_rows *rows, uint64_t blob_cap);
  *               mismatched (ascending); may be NULL
  *   row_status: HOST, optional (NULL ok): one int32 per row of the table, 0 = decoded, <0 = ZNIPPY_E_*
  * Asynchronous variant: znippy_decode_verify_rows_async queues the work only; results are read
- * back with znippy_rows_results after znippy_ctx_sync. */
+ * back with znippy_rows_results after znippy_ctx_sync.
+ * Device memory a context takes for this call beyond the table's own columns (kept until the context goes): pools of the
+ * batch path sized from the table's content (literals 1 byte, sequence records 1.5, decoding tables 1 per content byte of
+ * its compressed rows, each capped at 16 GiB) and — only for tables with compressed rows above 64 KiB — 4 bytes per byte of
+ * those rows for the resolve path, capped at 8 GiB (ZNIPPY_NO_RX=1 in the environment of znippy_ctx_create: none, such
+ * frames are then executed by one wave each).  A pool that cannot be allocated is not an error: its path is not used. */
 int znippy_decode_verify_rows(znippy_ctx *ctx, znippy_rows *rows, const void *d_blobs,
                               uint64_t blob_base, void *d_out, uint64_t out_cap,
                               znippy_verify_counters *counters, uint64_t *corrupt_rows,
