@@ -780,12 +780,17 @@ void launch_fz_exec(const FzArgs &a, hipStream_t s) {
 struct BxScratch {  // per wave; [i * 64 + lane]: a lane's i-th entry (consecutive lanes, consecutive addresses)
     int16_t norm[64 * 64];
     uint16_t nxt[64 * 64];
+    // Two lives of one region: the Huffman side (phase 1 reads the weights, phase 2 fills the decoding table from them) is
+    // over for a lane before it builds its first sequence table — 48 KB per wave instead of 66: three waves per CU, not two
+    // (the kernel is lone waves waiting on their own chains: 100k blocks 1.58 -> 1.1 ms)
     union {
-        uint16_t wtab[64 * 64];  // FSE table of the Huffman weights: weight:4 | nbits:3 << 4 | next:6 << 7
-        uint8_t sym[512 * 64];   // a sequence table under construction: the symbol of every cell
+        struct {
+            uint16_t wtab[64 * 64];  // FSE table of the Huffman weights: weight:4 | nbits:3 << 4 | next:6 << 7
+            uint8_t weights[256 * 64];
+            uint16_t rank[16 * 64];
+        };
+        uint8_t sym[512 * 64];       // a sequence table under construction: the symbol of every cell
     };
-    uint8_t weights[256 * 64];
-    uint16_t rank[16 * 64];
 };
 
 // every lane asks for `mine` units: one atomic per wave (all 64 lanes call this, converged)
@@ -1479,8 +1484,11 @@ __global__ __launch_bounds__(1024) void k_bx_sort(BxArgs a, uint32_t *tmp) {
 }
 
 // lane = Huffman stream; a wave takes 16 blocks of the list and keeps their decoding tables in LDS
+// (Tried: a second form with 1,024- or 512-cell tables in 32 / 16 KB per wave for groups whose tables all fit, four / eight
+// waves per CU — slower on the text archive, 1.10 / 1.20 against 0.96 ms: its tables are mostly the full 2,048 cells.)
 constexpr uint32_t BX_HUF_BLOCKS = 16, BX_HUF_LDS = BX_HUF_BLOCKS * 2048;  // u16 cells
 __global__ __launch_bounds__(64) void k_bx_huf(BxArgs a) {
+    constexpr uint32_t STRIDE = 2048;
     __shared__ __attribute__((aligned(16))) uint16_t T[BX_HUF_LDS];
     typedef __attribute__((address_space(3))) uint16_t lds16;
     const uint32_t lane = threadIdx.x, j = lane >> 2, sidx = lane & 3;
@@ -1498,7 +1506,7 @@ __global__ __launch_bounds__(64) void k_bx_huf(BxArgs a) {
             const uint32_t cells = rdlane_u(on ? (1u << hlog) : 0u, 4 * b), off = rdlane_u(pr.huf_off, 4 * b);
             for (uint32_t i = lane * 8; i < cells; i += 512) {
                 const uint4 v = *reinterpret_cast<const uint4 *>(a.huf_pool + off + i);
-                *reinterpret_cast<uint4 *>(&T[b * 2048 + i]) = v;
+                *reinterpret_cast<uint4 *>(&T[b * STRIDE + i]) = v;
             }
         }
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -1513,7 +1521,7 @@ __global__ __launch_bounds__(64) void k_bx_huf(BxArgs a) {
             uint8_t *const dst = a.lit_pool + it.lit_off + (pr.n_streams == 1 ? 0 : sidx * seg);
             const uint8_t *const p = src + pr.st_off[sidx];
             const uint32_t n = pr.st_len[sidx];
-            const lds16 *const huf = (const lds16 *)&T[j * 2048];
+            const lds16 *const huf = (const lds16 *)&T[j * STRIDE];
             int rc = 0;
             BitR b;
             if (!b.init(p, n, blob_end)) rc = E_CORRUPT;
