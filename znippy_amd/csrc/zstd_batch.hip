@@ -1885,11 +1885,11 @@ __global__ __launch_bounds__(64) void k_rx_plan(BxArgs a) {
     const uint32_t n_slots = a.ctr[0];
     for (uint32_t c = blockIdx.x; c < n_slots; c += gridDim.x) {
         if (lane == 0) { a.rx_base[c] = RX_NONE; a.rx_fail[c] = 0; }
-        const uint32_t nb = a.cand_nb[c], row = a.cand_row[c];
+        const uint32_t nb = uni(a.cand_nb[c]), row = uni(a.cand_row[c]);  // (every wave-uniform value made visibly so: see k_rx_expand)
         if (!nb || row == 0xFFFFFFFFu) continue;
-        const uint64_t fcs = a.usize[row];
+        const uint64_t fcs = uni64(a.usize[row]);
         if (fcs < a.rx_min || fcs >= (1ull << 30)) continue;
-        const uint32_t base = a.cand_base[c];
+        const uint32_t base = uni(a.cand_base[c]);
         {   // every block came through the entropy stages and the sizes add up (as fz_exec_frame checks)
             unsigned long long tot = 0, seqs = 0;
             uint32_t bad = 0;
@@ -1899,6 +1899,7 @@ __global__ __launch_bounds__(64) void k_rx_plan(BxArgs a) {
                 seqs += a.items[base + i].nseq;
             }
             for (int d = 32; d >= 1; d >>= 1) { tot += __shfl_xor(tot, d); seqs += __shfl_xor(seqs, d); bad |= __shfl_xor(bad, d); }
+            tot = uni64(tot); seqs = uni64(seqs); bad = uni(bad);
             if (bad || tot != fcs) continue;
             if (fcs >= (1u << 20) && seqs * 2048 < fcs) continue;  // a few very long copies: the serial decoder's wide variant (fz_exec_frame)
         }
