@@ -285,3 +285,51 @@ def test_valid_rows_between_undecodable_ones_keep_their_digests(gpu_ctx, oracle,
     assert c["corrupt_rows"] == 0, [int(x) for x in corrupt]
     assert c["decode_errors"] == int((~valid).sum()) and c["verified_bytes"] == int(valid.sum()) * len(data)
     assert (rt.digests()[valid] == ck[valid]).all()
+
+
+def test_front_to_back_tables_are_built_from_their_size_columns(oracle):
+    """A table whose offsets are the running sums of its sizes goes to the device as two 32-bit columns and the 64-bit columns
+    are made there (k_rows_unpack_*); ZNIPPY_NO_PACK=1 sends the four columns as they are.  Same results either way — for a
+    front-to-back table, for one with a gap (sent as it is in both contexts), with stored rows, with a row_begin window."""
+    import os
+    import torch
+    import gen
+    from znippy_amd import hip
+    rng = np.random.default_rng(8)
+    n = 1500
+    entries = [gen.pseudo_text(int(rng.integers(0, 6000)), seed=i) if i % 3 else gen.text(int(rng.integers(1, 12000))) for i in range(n)]
+    ctx0 = hip.Context(0)
+    frames = [ctx0.compress(e) if i % 7 else e for i, e in enumerate(entries)]   # every 7th row stored
+    comp = np.array([1 if i % 7 else 0 for i in range(n)], np.uint8)
+    ctx0.close()
+    bs = np.array([len(f) for f in frames], np.uint64)
+    us = np.array([len(e) for e in entries], np.uint64)
+    ck = np.stack([np.frombuffer(oracle.blake3(e), dtype=np.uint8) for e in entries])
+    bm = np.packbits(comp.astype(bool), bitorder="little")
+    results = {}
+    for gap in (0, 3):
+        bo = (np.cumsum(bs) - bs).astype(np.uint64)
+        oo = (np.cumsum(us) - us).astype(np.uint64)
+        if gap:
+            bo[n // 2:] += np.uint64(gap); oo[n // 3:] += np.uint64(16)
+        blob = np.zeros(int(bo[-1] + bs[-1]) + 64, np.uint8)
+        for i, f in enumerate(frames):
+            blob[int(bo[i]):int(bo[i]) + len(f)] = np.frombuffer(f, np.uint8)
+        d_blobs = torch.from_numpy(blob).cuda()
+        for mode in ("pack", "nopack"):
+            if mode == "nopack": os.environ["ZNIPPY_NO_PACK"] = "1"
+            try:
+                ctx = hip.Context(0)
+            finally:
+                os.environ.pop("ZNIPPY_NO_PACK", None)
+            d_out = torch.zeros(int(oo[-1] + us[-1]) + 64, dtype=torch.uint8, device="cuda")
+            rt = hip.RowTable(ctx, bo, bs, us, oo, bm, ck)
+            c, corrupt, status = rt.decode_verify(d_blobs, d_out)
+            out = d_out.cpu().numpy()
+            assert c["corrupt_rows"] == 0 and c["decode_errors"] == 0 and (status == 0).all(), (gap, mode, c)
+            for i in (0, 1, n // 2 - 1, n // 2, n - 1):
+                assert out[int(oo[i]):int(oo[i] + us[i])].tobytes() == entries[i]
+            results[(gap, mode)] = (dict(c), out.copy())
+            rt.close(); ctx.close()
+        assert results[(gap, "pack")][0] == results[(gap, "nopack")][0]
+        assert (results[(gap, "pack")][1] == results[(gap, "nopack")][1]).all()

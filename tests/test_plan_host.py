@@ -64,3 +64,35 @@ def test_rows_extents_match_numpy():
     out = (C.c_uint64 * 8)()
     L.zn_rows_extents(*(a.ctypes.data_as(C.c_void_p) for a in (bo, bs, z, z)), 1, out)
     assert out[3] != 0
+
+
+def test_rows_pack32_recognises_front_to_back_tables():
+    """zn_rows_pack32 (csrc/host/extents.cc): a table whose blobs and rows follow one another (what the reference's writer lays
+    down: running blob offsets, index.rs / decompress.rs:L135-190 reads them back in order) is sent to the device as its two
+    size columns, 32 bits each; anything else — a gap, an overlap, a size of 4 GiB or more — is not."""
+    L = _lib.lib()
+    L.zn_rows_pack32.argtypes = [C.c_void_p] * 4 + [C.c_size_t, C.c_void_p]
+    L.zn_rows_pack32.restype = C.c_int
+    rng = np.random.default_rng(6)
+
+    def call(bo, bs, oo, us):
+        dst = np.zeros(2 * len(bo), np.uint32)
+        rc = L.zn_rows_pack32(*(a.ctypes.data_as(C.c_void_p) for a in (bo, bs, oo, us)), len(bo), dst.ctypes.data_as(C.c_void_p))
+        return rc, dst
+
+    for n in (1, 2, 63, 1000, 100_001):
+        bs = rng.integers(0, 5000, size=n).astype(np.uint64)
+        us = rng.integers(0, 300_000, size=n).astype(np.uint64)
+        bo = (np.cumsum(bs) - bs + 777).astype(np.uint64)
+        oo = (np.cumsum(us) - us + 5).astype(np.uint64)
+        rc, dst = call(bo, bs, oo, us)
+        assert rc == 1 and (dst[:n] == bs).all() and (dst[n:] == us).all()
+        if n >= 3:
+            for col, k in ((bo, n // 2), (oo, n - 1), (bo, 1)):
+                old = int(col[k]); col[k] = old + 1
+                assert call(bo, bs, oo, us)[0] == 0          # a gap (or an overlap) in either running sum
+                col[k] = old
+            big = bs.copy(); big[n // 3] = 1 << 32
+            bo2 = (np.cumsum(big) - big + 777).astype(np.uint64)
+            assert call(bo2, big, oo, us)[0] == 0            # a size that does not fit 32 bits
+            assert call(bo, bs, oo, us)[0] == 1

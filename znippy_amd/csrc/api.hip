@@ -25,6 +25,7 @@ void set_fused_abl(int v);
 using namespace zn;
 extern "C" void zn_rounds_totals(const uint64_t *len, const uint8_t *skip, size_t n, uint64_t out[8]);  // host/extents.cpp
 extern "C" void zn_rows_extents(const uint64_t *bo, const uint64_t *bs, const uint64_t *oo, const uint64_t *us, size_t n, uint64_t out[8]);  // host/extents.cpp
+extern "C" int zn_rows_pack32(const uint64_t *bo, const uint64_t *bs, const uint64_t *oo, const uint64_t *us, size_t n, uint32_t *dst);
 
 #define HIPCHK(ctx, call)                                                                         \
     do {                                                                                          \
@@ -115,7 +116,7 @@ struct znippy_ctx {
         int dbg = 0;             // ZNIPPY_DBG bit set (FusedArgs::dbg)
         unsigned lds_pad = 0;    // ZNIPPY_LDS_PAD
         bool no_block_items = false, no_fused_blocks = false, ddbg = false, edbg = false, no_fused_store = false,
-             nohash = false, no_roles = false, no_fz = false, fz_only = false, no_bx = false, tdbg = false, no_fuse_hash = false, trace = false, no_rx = false;
+             nohash = false, no_roles = false, no_fz = false, fz_only = false, no_bx = false, tdbg = false, no_fuse_hash = false, trace = false, no_rx = false, no_pack = false;
         // ZNIPPY_ROLES_MIN: small tiles from which the role-split persistent kernel takes the table (0 = never; below
         // a few CU-fillings a persistent grid only adds start-up latency)
         unsigned roles_min = 2048;
@@ -146,6 +147,7 @@ static void read_switches(znippy_ctx *ctx) {
     ctx->sw.no_fz = on("ZNIPPY_NO_FZ");
     ctx->sw.tdbg = on("ZNIPPY_TDBG");
     ctx->sw.trace = on("ZNIPPY_TRACE");
+    ctx->sw.no_pack = on("ZNIPPY_NO_PACK");  // A/B: the index columns always as four 64-bit copies
     ctx->sw.no_rx = on("ZNIPPY_NO_RX");  // A/B: big foreign frames executed by a wave each (round 3's first form)
     ctx->sw.no_fuse_hash = on("ZNIPPY_NO_FUSE_HASH");  // A/B: the write side's hash as a kernel of its own beside the encoder (round 2)
     ctx->sw.no_bx = on("ZNIPPY_NO_BX");
@@ -348,6 +350,9 @@ struct znippy_rows {
     uint32_t n_compressed = 0;
     uint64_t *blob_off = nullptr, *blob_size = nullptr, *usize = nullptr, *out_off = nullptr;
     uint8_t *compressed = nullptr, *checksum = nullptr, *d_bitmap = nullptr;
+    uint32_t *h_pack = nullptr, *d_pack = nullptr;  // front-to-back tables: the two size columns as 32-bit values (page-locked / device)
+    size_t h_pack_cap = 0;
+    unsigned long long *d_pack_sums = nullptr;
     // One allocation, cleared (or preset) by ONE stream operation per run: [counters 8 x u64][hand-over counts 16 x u32]
     // [work cursors 16 x u32][pad 64 B][status n x i32]
     uint8_t *ctl = nullptr;
@@ -588,6 +593,59 @@ static int ensure_encoder(znippy_ctx *ctx) {
         return ZNIPPY_E_NOMEM;
     }
     return ZNIPPY_OK;
+}
+
+// rows of a front-to-back table arrive as two 32-bit size columns (zn_rows_pack32): the four 64-bit columns the kernels read
+// are made here — sizes widened, offsets = first offset + running sum (per 1,024 rows: sums, their scan, fill)
+__device__ __forceinline__ void block_excl_scan2(unsigned long long &a, unsigned long long &b, unsigned long long *sa, unsigned long long *sb,
+                                                 unsigned long long *ta, unsigned long long *tb) {  // 256 threads: exclusive sums + totals
+    const uint32_t t = threadIdx.x;
+    const unsigned long long a0 = a, b0 = b;
+    sa[t] = a; sb[t] = b;
+    __syncthreads();
+    for (uint32_t d = 1; d < 256; d <<= 1) {
+        unsigned long long xa = 0, xb = 0;
+        if (t >= d) { xa = sa[t - d]; xb = sb[t - d]; }
+        __syncthreads();
+        sa[t] += xa; sb[t] += xb;
+        __syncthreads();
+    }
+    *ta = sa[255]; *tb = sb[255];
+    a = sa[t] - a0; b = sb[t] - b0;
+    __syncthreads();
+}
+__global__ __launch_bounds__(256) void k_rows_unpack_sums(const uint32_t *bs32, const uint32_t *us32, uint32_t n, unsigned long long *sums) {
+    __shared__ unsigned long long sa[256], sb[256];
+    const uint32_t lo = blockIdx.x * 1024 + threadIdx.x * 4;
+    unsigned long long a = 0, b = 0, ta, tb;
+    for (uint32_t k = 0; k < 4; k++) if (lo + k < n) { a += bs32[lo + k]; b += us32[lo + k]; }
+    block_excl_scan2(a, b, sa, sb, &ta, &tb);
+    if (threadIdx.x == 0) { sums[2 * blockIdx.x] = ta; sums[2 * blockIdx.x + 1] = tb; }
+}
+__global__ __launch_bounds__(256) void k_rows_unpack_scan(unsigned long long *sums, uint32_t nblk) {  // exclusive, in place, one workgroup
+    __shared__ unsigned long long sa[256], sb[256];
+    unsigned long long ca = 0, cb = 0;
+    for (uint32_t b0 = 0; b0 < nblk; b0 += 256) {
+        const uint32_t i = b0 + threadIdx.x;
+        unsigned long long a = i < nblk ? sums[2 * i] : 0, b = i < nblk ? sums[2 * i + 1] : 0, ta, tb;
+        block_excl_scan2(a, b, sa, sb, &ta, &tb);
+        if (i < nblk) { sums[2 * i] = ca + a; sums[2 * i + 1] = cb + b; }
+        ca += ta; cb += tb;
+    }
+}
+__global__ __launch_bounds__(256) void k_rows_unpack_fill(const uint32_t *bs32, const uint32_t *us32, uint32_t n, const unsigned long long *sums,
+                                                          uint64_t bo0, uint64_t oo0, uint64_t *bo, uint64_t *bs, uint64_t *oo, uint64_t *us) {
+    __shared__ unsigned long long sa[256], sb[256];
+    const uint32_t lo = blockIdx.x * 1024 + threadIdx.x * 4;
+    uint32_t vb[4] = {0, 0, 0, 0}, vu[4] = {0, 0, 0, 0};
+    unsigned long long a = 0, b = 0, ta, tb;
+    for (uint32_t k = 0; k < 4; k++) if (lo + k < n) { vb[k] = bs32[lo + k]; vu[k] = us32[lo + k]; a += vb[k]; b += vu[k]; }
+    block_excl_scan2(a, b, sa, sb, &ta, &tb);
+    unsigned long long pb = bo0 + sums[2 * blockIdx.x] + a, po = oo0 + sums[2 * blockIdx.x + 1] + b;
+    for (uint32_t k = 0; k < 4; k++) if (lo + k < n) {
+        bo[lo + k] = pb; bs[lo + k] = vb[k]; oo[lo + k] = po; us[lo + k] = vu[k];
+        pb += vb[k]; po += vu[k];
+    }
 }
 
 // rows: the bit column -> one byte per row, and a stored row's length = its blob (the reference hashes and writes the
@@ -913,12 +971,16 @@ void znippy_rows_destroy(znippy_rows *r) {
                     r->cand_row, r->cand_base, r->cand_nblocks, r->fz_base, r->fz_cap, r->fz_it_cand, r->fz_nb, r->fz_work, r->fz_items, r->item_row, r->item_k, r->item_src, r->row_flag, r->pending2,
                     r->bt_tile, r->bt_item, r->tile_done, r->item_done, r->todo, r->status_init, r->slow_list,
                     r->bx_cand_row, r->bx_cand_base, r->bx_cand_nb, r->bx_huf_list, r->bx_seq_list, r->bx_items, r->bx_prep, r->d_bitmap, r->bx_sort_tmp,
-                    r->rx_base, r->rx_fail, r->rx_blk, r->rx_list};
+                    r->rx_base, r->rx_fail, r->rx_blk, r->rx_list, r->d_pack, r->d_pack_sums};
     for (void *p : ptrs)
         tfree(r->ctx, p);
     if (r->h_counters) {
         (void)hipStreamSynchronize(r->ctx->stream);  // a queued run may still copy into the slot
         pinned_give(r->ctx, r->h_counters, r->h_counters_cap);
+    }
+    if (r->h_pack) {
+        (void)hipStreamSynchronize(r->ctx->stream);  // (the copy out of it is stream-ordered)
+        pinned_give(r->ctx, r->h_pack, r->h_pack_cap);
     }
     for (hipEvent_t e : r->ev_done) event_give(r->ctx, e);
     free_plan(r->ctx, r->plan);
@@ -959,8 +1021,31 @@ int znippy_rows_create(znippy_ctx *ctx, const uint64_t *blob_offset, const uint6
     // the columns as they are (the device derives the byte-per-row flags and the stored rows' lengths)
     uint8_t *&d_bitmap = r->d_bitmap;  // (kept until the table goes: k_rows_fixup reads it on the stream, uploads are not stream-ordered)
     const uint64_t bm0 = row_begin >> 3, bm1 = (row_end + 7) >> 3;
-    if ((rc = dev_upload(ctx, &r->blob_off, bo_in, n)) || (rc = dev_upload(ctx, &r->blob_size, bs_in, n)) ||
-        (rc = dev_upload(ctx, &r->usize, us_in, n)) || (rc = dev_upload(ctx, &r->out_off, oo_in, n)) ||
+    // A table written front to back is its two size columns (zn_rows_pack32): 8 bytes per row go to the device, from
+    // page-locked memory, and three small kernels make the four 64-bit columns there.  (The four pageable copies of 0.8 MB
+    // each were 0.18 of the 0.36 ms a table of 100k rows took to build.)
+    bool packed = false;
+    if (n >= 64 && !ctx->sw.no_pack) {
+        r->h_pack = (uint32_t *)pinned_take(ctx, 8 * (size_t)n, &r->h_pack_cap);
+        if (r->h_pack && zn_rows_pack32(bo_in, bs_in, oo_in, us_in, n, r->h_pack)) {
+            const uint32_t nblk = (n + 1023) / 1024;
+            if (tmalloc(ctx, &r->d_pack, 8 * (size_t)n) == hipSuccess && tmalloc(ctx, &r->d_pack_sums, 16 * (size_t)nblk) == hipSuccess &&
+                tmalloc(ctx, &r->blob_off, 8 * (size_t)n) == hipSuccess && tmalloc(ctx, &r->blob_size, 8 * (size_t)n) == hipSuccess &&
+                tmalloc(ctx, &r->usize, 8 * (size_t)n) == hipSuccess && tmalloc(ctx, &r->out_off, 8 * (size_t)n) == hipSuccess &&
+                hipMemcpyAsync(r->d_pack, r->h_pack, 8 * (size_t)n, hipMemcpyHostToDevice, ctx->stream) == hipSuccess) {
+                hipLaunchKernelGGL(k_rows_unpack_sums, dim3(nblk), dim3(256), 0, ctx->stream, r->d_pack, r->d_pack + n, n, r->d_pack_sums);
+                hipLaunchKernelGGL(k_rows_unpack_scan, dim3(1), dim3(256), 0, ctx->stream, r->d_pack_sums, nblk);
+                hipLaunchKernelGGL(k_rows_unpack_fill, dim3(nblk), dim3(256), 0, ctx->stream, r->d_pack, r->d_pack + n, n, r->d_pack_sums, bo_in[0], oo_in[0],
+                                   r->blob_off, r->blob_size, r->out_off, r->usize);
+                packed = true;
+            } else {
+                znippy_rows_destroy(r);
+                return ZNIPPY_E_NOMEM;
+            }
+        }
+    }
+    if ((!packed && ((rc = dev_upload(ctx, &r->blob_off, bo_in, n)) || (rc = dev_upload(ctx, &r->blob_size, bs_in, n)) ||
+                     (rc = dev_upload(ctx, &r->usize, us_in, n)) || (rc = dev_upload(ctx, &r->out_off, oo_in, n)))) ||
         (compressed_bitmap && (rc = dev_upload(ctx, &d_bitmap, compressed_bitmap + bm0, (size_t)(bm1 - bm0)))) ||
         tmalloc(ctx, &r->compressed, std::max<size_t>(n, 16)) != hipSuccess) {
         znippy_rows_destroy(r);

@@ -57,3 +57,25 @@ void zn_rounds_totals(const uint64_t *len, const uint8_t *skip, size_t n, uint64
     if (skip) rounds_totals_body<true>(len, skip, n, out);
     else rounds_totals_body<false>(len, skip, n, out);
 }
+
+// A table written front to back (every blob behind the one before it, every row's bytes behind the one before it: what the
+// reference's writer and reader produce) is its two size columns: the offset columns are their running sums.  One pass:
+// checks that, narrows the sizes to 32 bits into dst (bs32[n] then us32[n]); returns 1 when the table is of that kind and
+// every size fits 32 bits — the caller then sends 8 bytes per row to the device instead of 32.
+extern "C" __attribute__((target_clones("avx512f", "avx2", "default")))
+int zn_rows_pack32(const uint64_t *bo, const uint64_t *bs, const uint64_t *oo, const uint64_t *us, size_t n, uint32_t *dst) {
+    if (n == 0) return 0;
+    uint64_t bad = 0;
+    uint32_t *const d_bs = dst, *const d_us = dst + n;
+    for (size_t i = 0; i + 1 < n; i++) {
+        bad |= (bo[i] + bs[i]) ^ bo[i + 1];
+        bad |= (oo[i] + us[i]) ^ oo[i + 1];
+        bad |= (bs[i] | us[i]) >> 32;
+        d_bs[i] = (uint32_t)bs[i];
+        d_us[i] = (uint32_t)us[i];
+    }
+    bad |= (bs[n - 1] | us[n - 1]) >> 32;
+    d_bs[n - 1] = (uint32_t)bs[n - 1];
+    d_us[n - 1] = (uint32_t)us[n - 1];
+    return bad == 0;
+}
