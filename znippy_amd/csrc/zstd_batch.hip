@@ -2164,7 +2164,7 @@ void launch_bx_stage(const BxArgs &a, int cus, int stage, hipStream_t s) {
         else hipLaunchKernelGGL((k_bx_exec<false, WIN_HIST, WIN_CAP, 1>), cap(slots, 12), dim3(64), 0, s, a);
         break;
     case 8: hipLaunchKernelGGL(k_rx_plan, cap(slots, 8), dim3(64), 0, s, a); break;
-    case 9: hipLaunchKernelGGL(k_rx_expand, cap(a.item_cap, 16), dim3(64), 0, s, a); break;  // (static stride over the list)
+    case 9: hipLaunchKernelGGL(k_rx_expand, cap(a.item_cap, 32), dim3(64), 0, s, a); break;  // (static stride over the list; lone chains: the more the better, 54 VGPRs, no LDS)
     case 30: hipLaunchKernelGGL(k_rx_store, cap((uint32_t)std::min<uint64_t>((a.rx_bound + 1023) / 1024, 1u << 30), 64), dim3(256), 0, s, a); break;
     case 5: hipLaunchKernelGGL(k_bx_finish, dim3(lane_grid), dim3(64), 0, s, a); break;
     default:
