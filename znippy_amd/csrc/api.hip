@@ -97,7 +97,7 @@ struct znippy_ctx {
     uint32_t *rx_pool = nullptr, *rx_chunk = nullptr;
     uint8_t *rx_cdone = nullptr;
     uint64_t rx_cap = 0;  // words
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_join2 = nullptr;
     // kernel timing
     std::vector<KTime> ktimes;
     int n_ktimes = 0;
@@ -784,7 +784,8 @@ int znippy_ctx_create(int device, void *hip_stream, znippy_ctx **out) {
     if (hipStreamCreateWithFlags(&ctx->aux, hipStreamNonBlocking) != hipSuccess ||
         hipStreamCreateWithFlags(&ctx->copy, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming) != hipSuccess) {
+        hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ev_join2, hipEventDisableTiming) != hipSuccess) {
         znippy_ctx_destroy(ctx);
         return ZNIPPY_E_HIP;
     }
@@ -844,6 +845,7 @@ static void ctx_teardown(znippy_ctx *ctx) {
     for (hipEvent_t e : ctx->event_pool) (void)hipEventDestroy(e);
     if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
     if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
+    if (ctx->ev_join2) (void)hipEventDestroy(ctx->ev_join2);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -1578,9 +1580,21 @@ int znippy_decode_verify_rows_async(znippy_ctx *ctx, znippy_rows *r, const void 
             HIPCHK(ctx, hipStreamWaitEvent(ctx->aux, ctx->ev_fork, 0));
             stage(6, ctx->aux);
             HIPCHK(ctx, hipEventRecord(ctx->ev_join, ctx->aux));
+            // ... and the lane-per-block sequence kernel beside the Huffman streams on a third stream (the write side's copy
+            // stream, idle here): the two touch different pools and different fields of a block's record.  A small table is
+            // its longest chains: the image's source text had Huffman 2.5 + sequences 1.8 ms in a row beside 3.5 ms of long chains.
+            // (Only where the chip is not full of blocks anyway: 100k blocks, both kernels chip-wide: 2.98 ms together against
+            // 1.85 + 0.96 one after the other.)
+            const bool third = r->bx_nblk <= 32768;
+            if (third) {
+                HIPCHK(ctx, hipStreamWaitEvent(ctx->copy, ctx->ev_fork, 0));
+                stage(3, ctx->copy);
+                HIPCHK(ctx, hipEventRecord(ctx->ev_join2, ctx->copy));
+            }
             stage(2, s);
-            stage(3, s);
+            if (!third) stage(3, s);
             HIPCHK(ctx, hipStreamWaitEvent(s, ctx->ev_join, 0));
+            if (third) HIPCHK(ctx, hipStreamWaitEvent(s, ctx->ev_join2, 0));
             if (rx) {  // big frames: resolved in parallel (every byte a word, pointer jumping) instead of executed by a wave each
                 stage(8, s);
                 if (ctx->sw.trace) {
