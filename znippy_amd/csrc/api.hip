@@ -1605,6 +1605,11 @@ int znippy_decode_verify_rows_async(znippy_ctx *ctx, znippy_rows *r, const void 
                     fprintf(stderr, "[znippy trace] resolve plan: slots %u items %u list %u frames %u words %llu extent %llu cap %llu item_cap %u\n", g[0], g[1], g[9], g[11], pu[10], pu[11],
                             (unsigned long long)ctx->rx_cap, r->bx_item_cap);
                 }
+                // the frames the plan did not take are executed by a wave each, beside the resolve stages (they share nothing)
+                HIPCHK(ctx, hipEventRecord(ctx->ev_fork, s));
+                HIPCHK(ctx, hipStreamWaitEvent(ctx->aux, ctx->ev_fork, 0));
+                stage(4, ctx->aux);
+                HIPCHK(ctx, hipEventRecord(ctx->ev_join, ctx->aux));
                 stage(9, s);
                 static const char *const jump_names[12] = {"zstd_resolve_jump_0", "zstd_resolve_jump_1", "zstd_resolve_jump_2", "zstd_resolve_jump_3", "zstd_resolve_jump_4", "zstd_resolve_jump_5",
                                                            "zstd_resolve_jump_6", "zstd_resolve_jump_7", "zstd_resolve_jump_8", "zstd_resolve_jump_9", "zstd_resolve_jump_10", "zstd_resolve_jump_11"};
@@ -1619,8 +1624,8 @@ int znippy_decode_verify_rows_async(znippy_ctx *ctx, znippy_rows *r, const void 
                 ktime_begin(ctx, "zstd_resolve_store", s);
                 launch_bx_stage(x, ctx->cus, 30, s);
                 ktime_end(ctx, s);
-            }
-            stage(4, s);
+                HIPCHK(ctx, hipStreamWaitEvent(s, ctx->ev_join, 0));
+            } else stage(4, s);
             stage(5, s);
             a.list_a = nullptr; a.n_list_a = 0;
             a.pending = r->pending2; a.pending_count = r->pending_count + 1;
