@@ -169,3 +169,66 @@ def test_mixed_row_shapes_decode_the_same_every_time(gpu_ctx_roles, oracle):
         assert c["corrupt_rows"] == 0 and c["decode_errors"] == 0 and c["verified_bytes"] == int(us.sum()), (rep, c, corrupt[:8])
         assert (rt.digests() == ck).all(), rep
         assert torch.equal(d_out[:int(us.sum())], ref), rep
+
+
+def test_lean_runs_notice_changed_blobs(oracle):
+    """A table whose last run left nothing behind the role-split kernel is run lean (memset + that kernel + verify: the three
+    launches behind it would only look at empty lists).  If the blobs have changed since — a frame the kernel no longer
+    recognises, a damaged one — the verify kernel flags the run and whoever reads its results runs the table again in full:
+    the caller sees exactly what a context without lean runs (ZNIPPY_NO_LEAN=1) reports.  Reference: the read loop looks at
+    every row on every pass (decompress.rs:L135-190); nothing may depend on what an earlier pass over the table found."""
+    import os
+    import torch
+    import gen
+    from znippy_amd import hip
+    n = 6 * 700
+    data = gen.text(10240)
+    frame = oracle.libzstd_compress(data, 19)
+    other = gen.pseudo_text(10240, seed=5)                    # same size, another content: decodes, verify flags it
+    other_frame = oracle.libzstd_compress(other, 3)
+    assert len(other_frame) > len(frame)
+    slot = len(other_frame) + 7                               # every row's blob slot is big enough for either frame
+    bo = (np.arange(n, dtype=np.uint64) * np.uint64(slot))
+    bs = np.full(n, len(frame), np.uint64)
+    us = np.full(n, 10240, np.uint64)
+    oo = np.arange(n, dtype=np.uint64) * np.uint64(10240)
+    ck = np.tile(np.frombuffer(oracle.blake3(data), dtype=np.uint8), (n, 1))
+    blob = np.zeros(n * slot + 64, np.uint8)
+    for i in range(n):
+        blob[i * slot:i * slot + len(frame)] = np.frombuffer(frame, np.uint8)
+
+    def run(env):
+        old = {k: os.environ.get(k) for k in ("ZNIPPY_ROLES_MIN", "ZNIPPY_NO_LEAN")}
+        os.environ["ZNIPPY_ROLES_MIN"] = "1"
+        os.environ.update(env)
+        try:
+            ctx = hip.Context(0)
+        finally:
+            for k, v in old.items():
+                if v is None: os.environ.pop(k, None)
+                else: os.environ[k] = v
+        d_blobs = torch.from_numpy(blob.copy()).cuda()
+        d_out = torch.zeros(n * 10240 + 64, dtype=torch.uint8, device="cuda")
+        rt = hip.RowTable(ctx, bo, bs, us, oo, None, ck)
+        seen = []
+        for step in range(6):
+            if step == 3:     # row 1234 becomes a frame of other content (longer blob: the table says the old size -> truncated -> error),
+                d_blobs[1234 * slot:1234 * slot + len(other_frame)] = torch.from_numpy(np.frombuffer(other_frame, np.uint8).copy()).cuda()
+                d_blobs[77 * slot + 20] ^= 0x55   # ... row 77 is damaged in its sequence section
+            d_out.zero_()
+            torch.cuda.synchronize()
+            c, corrupt, status = rt.decode_verify(d_blobs, d_out)
+            kt = dict(ctx.kernel_times())
+            seen.append((dict(c), sorted(int(x) for x in corrupt), status.copy(), rt.digests().copy(), d_out[:n * 10240].cpu().numpy().copy(),
+                         "blake3_second_pass" in kt))
+        rt.close(); ctx.close()
+        return seen
+
+    lean, full = run({}), run({"ZNIPPY_NO_LEAN": "1"})
+    assert [s[5] for s in full] == [True] * 6
+    assert lean[0][5] and not lean[2][5]          # the first run is a full one, the third a lean one
+    for a, b in zip(lean, full):
+        assert a[0] == b[0] and a[1] == b[1] and (a[2] == b[2]).all() and (a[3] == b[3]).all() and (a[4] == b[4]).all()
+    assert lean[2][0]["corrupt_rows"] == 0 and lean[2][0]["decode_errors"] == 0
+    bad = lean[3][0]["corrupt_rows"] + lean[3][0]["decode_errors"]
+    assert bad == 2, lean[3][0]                   # both changed rows are reported by the run that met them

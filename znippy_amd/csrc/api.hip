@@ -116,7 +116,7 @@ struct znippy_ctx {
         int dbg = 0;             // ZNIPPY_DBG bit set (FusedArgs::dbg)
         unsigned lds_pad = 0;    // ZNIPPY_LDS_PAD
         bool no_block_items = false, no_fused_blocks = false, ddbg = false, edbg = false, no_fused_store = false,
-             nohash = false, no_roles = false, no_fz = false, fz_only = false, no_bx = false, tdbg = false, no_fuse_hash = false, trace = false, no_rx = false, no_pack = false;
+             nohash = false, no_roles = false, no_fz = false, fz_only = false, no_bx = false, tdbg = false, no_fuse_hash = false, trace = false, no_rx = false, no_pack = false, no_lean = false;
         // ZNIPPY_ROLES_MIN: small tiles from which the role-split persistent kernel takes the table (0 = never; below
         // a few CU-fillings a persistent grid only adds start-up latency)
         unsigned roles_min = 2048;
@@ -147,6 +147,7 @@ static void read_switches(znippy_ctx *ctx) {
     ctx->sw.no_fz = on("ZNIPPY_NO_FZ");
     ctx->sw.tdbg = on("ZNIPPY_TDBG");
     ctx->sw.trace = on("ZNIPPY_TRACE");
+    ctx->sw.no_lean = on("ZNIPPY_NO_LEAN");  // A/B: every run launches the kernels behind the role-split one
     ctx->sw.no_pack = on("ZNIPPY_NO_PACK");  // A/B: the index columns always as four 64-bit copies
     ctx->sw.no_rx = on("ZNIPPY_NO_RX");  // A/B: big foreign frames executed by a wave each (round 3's first form)
     ctx->sw.no_fuse_hash = on("ZNIPPY_NO_FUSE_HASH");  // A/B: the write side's hash as a kernel of its own beside the encoder (round 2)
@@ -372,6 +373,16 @@ struct znippy_rows {
     // safety net), 1 something was.
     int bx_hint = -1;
     uint64_t hint_seq = 0;  // runs whose mirror has been looked at
+    // Lean runs.  A table of small rows whose last finished run left nothing behind the role-split kernel — no tile on its
+    // list, no row handed over — is run as memset + that kernel + verify: the three launches behind it (left-over tiles,
+    // serial decoder, second hash pass) cost ~25 us of a 0.5 ms step for looking at empty lists.  The verify kernel checks
+    // the lists; if this run did leave something (the blobs changed), its counters come back flagged and whoever reads the
+    // run's results first runs it again in full (rows_settle) — same inputs, the results the caller would have had.
+    bool lean_ok = false;      // the table's shape allows it (set at creation)
+    int lean_hint = -1;        // last finished run: 1 nothing left behind the roles kernel, 0 something was, -1 not known
+    bool last_lean = false;
+    const void *last_blobs = nullptr; void *last_out = nullptr;
+    uint64_t last_base = 0, last_cap = 0;
     hipEvent_t ev_done[2] = {nullptr, nullptr};
     uint64_t run_seq = 0;  // async runs queued so far
     // Host copies of the columns a run is validated against (one pass per distinct (blob_base, blob_cap, out_cap)):
@@ -386,6 +397,7 @@ struct znippy_rows {
     uint64_t val_base = 0, val_bcap = 0, val_ocap = 0;
     bool val_done = false;
     uint32_t n_bad = 0;
+    bool force_full = false;  // a lean run came back flagged: this table runs in full from now on
     uint8_t *status_init = nullptr;  // image of ctl with the host-decided statuses (rows_validate)
     bool odd_out = false;  // some stored row's output offset is not a multiple of 16 (store-path kernel variant)
     uint64_t *corrupt = nullptr;
@@ -1182,6 +1194,8 @@ int znippy_rows_create(znippy_ctx *ctx, const uint64_t *blob_offset, const uint6
     r->wide_rows = n_big && big_bytes / n_big >= (1u << 20) && big_blob * 50 < big_bytes;
     r->n_cand = (uint32_t)cand_row.size();
     r->n_items = (uint32_t)item_row.size();
+    r->lean_ok = allc && !ctx->sw.no_lean && r->n_list_a == 0 && r->n_cand == 0 && p.big.empty() && r->n_small_tiles == (uint32_t)p.tiles.size() &&
+                 r->n_small_tiles > 0;
     if (r->n_cand) {
         if ((rc = dev_upload(ctx, &r->cand_row, cand_row.data(), cand_row.size())) ||
             (rc = dev_upload(ctx, &r->cand_base, cand_base.data(), cand_base.size())) ||
@@ -1300,6 +1314,7 @@ static int rows_validate(znippy_ctx *ctx, znippy_rows *r, uint64_t blob_base, ui
 static void rows_note_hint(znippy_rows *r, unsigned slot) {
     const uint32_t *pc = reinterpret_cast<const uint32_t *>(r->h_counters + 16 * slot + 8);
     r->bx_hint = (pc[0] || pc[1] || pc[5] || r->n_list_a) ? 1 : 0;  // ([1]: what went to the serial decoder)
+    r->lean_hint = (pc[0] || pc[1] || pc[3] || pc[5]) ? 0 : 1;       // ([3]: tiles the role-split kernel left on its list)
 }
 
 int znippy_decode_verify_rows_async(znippy_ctx *ctx, znippy_rows *r, const void *d_blobs,
@@ -1326,6 +1341,8 @@ int znippy_decode_verify_rows_async(znippy_ctx *ctx, znippy_rows *r, const void 
     }
     const bool bx = r->bx_slots && ctx->fz_lit_pool && ctx->fz_seq_pool && ctx->bx_fse_pool && ctx->bx_huf_pool && r->bx_hint != 0;
     const int preset = r->n_bad ? 1 : 0;
+    r->last_blobs = d_blobs; r->last_base = blob_base; r->last_out = d_out; r->last_cap = out_cap;
+    bool lean = false;
     // counters, hand-over counts, work cursors and the status column: one stream operation
     if (preset) HIPCHK(ctx, hipMemcpyAsync(r->ctl, r->status_init, r->ctl_bytes, hipMemcpyDeviceToDevice, s));
     else HIPCHK(ctx, hipMemsetAsync(r->ctl, 0, r->ctl_bytes, s));
@@ -1378,8 +1395,9 @@ int znippy_decode_verify_rows_async(znippy_ctx *ctx, znippy_rows *r, const void 
             ktime_begin(ctx, "decode_verify_roles");
             launch_fused_roles(f, ctx->cus, s);
             ktime_end(ctx);
+            lean = r->lean_ok && r->lean_hint == 1 && r->bx_hint == 0 && !preset && !r->force_full && !f.dbg;
         }
-        if (r->n_small_tiles) {
+        if (r->n_small_tiles && !lean) {
             ktime_begin(ctx, "decode_verify_fused");
             launch_fused_small(f, s, roles ? ctx->cus * 5 : 0);
             ktime_end(ctx);
@@ -1389,6 +1407,7 @@ int znippy_decode_verify_rows_async(znippy_ctx *ctx, znippy_rows *r, const void 
     //    auxiliary stream, the general decoder (single-block big rows + whatever the fused kernel handed over) on the
     //    main one — each is latency-bound on its own and leaves most of the chip idle.  Frames the block path gives up
     //    on are decoded by a second general launch afterwards.
+    if (!lean) {  // (a lean run: nothing is expected behind the roles kernel; k_verify checks that — rows_settle)
     BlockScanArgs b{};
     if (r->n_cand) {
         if (!ctx->lit_scratch_b && hipMalloc(&ctx->lit_scratch_b, decode_lit_scratch_bytes(ctx->decode_grid)) != hipSuccess) return ZNIPPY_E_NOMEM;
@@ -1677,9 +1696,11 @@ int znippy_decode_verify_rows_async(znippy_ctx *ctx, znippy_rows *r, const void 
         launch_merge_big(r->plan.big, r->plan.n_big, r->plan.tile_cv, r->digests, r->plan.grp_big, r->plan.grp_k, r->plan.n_grp, s);
         ktime_end(ctx);
     }
+    }  // !lean
+    r->last_lean = lean;
     ktime_begin(ctx, "verify");
     launch_verify(r->digests, r->checksum, r->usize, r->status, r->n, r->row_begin, r->counters, r->corrupt,
-                  r->corrupt_cap, s);
+                  r->corrupt_cap, s, lean ? r->pending_count : nullptr);
     ktime_end(ctx);
     {
         const unsigned slot = (unsigned)(r->run_seq & 1);
@@ -1688,6 +1709,22 @@ int znippy_decode_verify_rows_async(znippy_ctx *ctx, znippy_rows *r, const void 
         r->run_seq++;
     }
     HIPCHK(ctx, hipGetLastError());
+    return ZNIPPY_OK;
+}
+
+// A lean run whose lists were not empty after all (counters[7] set by k_verify): run the table again in full with the same
+// arguments, and give both mirror slots the full run's counters (a second lean run may be in flight behind the first: its
+// results are the same).  Called by everything that hands a run's results to the caller.
+static int rows_settle(znippy_ctx *ctx, znippy_rows *r, unsigned slot) {
+    if (!r->n || !r->run_seq || !(r->h_counters[16 * slot + 7])) return ZNIPPY_OK;
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    r->force_full = true;
+    r->lean_hint = 0;
+    const int rc = znippy_decode_verify_rows_async(ctx, r, r->last_blobs, r->last_base, r->last_out, r->last_cap);
+    if (rc) return rc;
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    const unsigned now = (unsigned)((r->run_seq - 1) & 1);
+    memcpy(r->h_counters + 16 * (now ^ 1), r->h_counters + 16 * now, 128);
     return ZNIPPY_OK;
 }
 
@@ -1701,6 +1738,7 @@ int znippy_rows_results_lagged(znippy_ctx *ctx, znippy_rows *r, unsigned lag, zn
     if (r->n) {
         const unsigned slot = (unsigned)((r->run_seq - 1 - lag) & 1);
         HIPCHK(ctx, hipEventSynchronize(r->ev_done[slot]));
+        { const int rc = rows_settle(ctx, r, slot); if (rc) return rc; }
         memcpy(c, r->h_counters + 16 * slot, 64);
         rows_note_hint(r, slot);
     }
@@ -1717,6 +1755,7 @@ int znippy_rows_results(znippy_ctx *ctx, znippy_rows *r, znippy_verify_counters 
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     uint64_t c[8] = {0};
     if (r->n && r->run_seq) {
+        { const int rc = rows_settle(ctx, r, (unsigned)((r->run_seq - 1) & 1)); if (rc) return rc; }
         memcpy(c, r->h_counters + 16 * ((r->run_seq - 1) & 1), 64);  // copied by the run itself (pinned)
         rows_note_hint(r, (unsigned)((r->run_seq - 1) & 1));
     }
@@ -1754,6 +1793,7 @@ int znippy_rows_digests(znippy_ctx *ctx, znippy_rows *r, uint8_t *digests) {
     if (!ctx || !r || !digests) return ZNIPPY_E_INVAL;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (r->n && r->run_seq) { const int rc = rows_settle(ctx, r, (unsigned)((r->run_seq - 1) & 1)); if (rc) return rc; }
     if (r->n) HIPCHK(ctx, hipMemcpy(digests, r->digests, 32 * (size_t)r->n, hipMemcpyDeviceToHost));
     return ZNIPPY_OK;
 }
