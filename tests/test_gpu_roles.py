@@ -232,3 +232,67 @@ def test_lean_runs_notice_changed_blobs(oracle):
     assert lean[2][0]["corrupt_rows"] == 0 and lean[2][0]["decode_errors"] == 0
     bad = lean[3][0]["corrupt_rows"] + lean[3][0]["decode_errors"]
     assert bad == 2, lean[3][0]                   # both changed rows are reported by the run that met them
+
+
+def test_lean_runs_in_a_pipeline_with_alternating_buffers(oracle):
+    """The read loop keeps two runs in flight and reads run k's counters while run k + 1 executes
+    (znippy_rows_results_lagged); here the runs alternate between two output buffers and a frame is damaged while lean runs
+    are queued (the role-split kernel no longer recognises it: the row is handed over, nobody is there to take it, the run
+    comes back flagged).  A flagged run is repeated with the arguments IT was given: the counters of every run and both
+    buffers' bytes equal a ZNIPPY_NO_LEAN context's."""
+    import os
+    import torch
+    import gen
+    from znippy_amd import hip
+    n = 6 * 500
+    data = gen.text(10240)
+    frame = oracle.libzstd_compress(data, 19)
+    slot = len(frame) + 9
+    bo = np.arange(n, dtype=np.uint64) * np.uint64(slot)
+    bs = np.full(n, len(frame), np.uint64)
+    us = np.full(n, 10240, np.uint64)
+    oo = np.arange(n, dtype=np.uint64) * np.uint64(10240)
+    ck = np.tile(np.frombuffer(oracle.blake3(data), dtype=np.uint8), (n, 1))
+    blob = np.zeros(n * slot + 64, np.uint8)
+    for i in range(n):
+        blob[i * slot:i * slot + len(frame)] = np.frombuffer(frame, np.uint8)
+
+    def run(env):
+        old = {k: os.environ.get(k) for k in ("ZNIPPY_ROLES_MIN", "ZNIPPY_NO_LEAN")}
+        os.environ["ZNIPPY_ROLES_MIN"] = "1"
+        os.environ.update(env)
+        try:
+            ctx = hip.Context(0)
+        finally:
+            for k, v in old.items():
+                if v is None: os.environ.pop(k, None)
+                else: os.environ[k] = v
+        d_blobs = torch.from_numpy(blob.copy()).cuda()
+        outs = [torch.zeros(n * 10240 + 64, dtype=torch.uint8, device="cuda") for _ in range(2)]
+        rt = hip.RowTable(ctx, bo, bs, us, oo, None, ck)
+        counters, lean_seen = [], []
+        for step in range(9):
+            if step == 5:   # rows 42 and 2900: a byte of the sequence section flipped
+                torch.cuda.synchronize()
+                d_blobs[42 * slot + 20] ^= 0x55
+                d_blobs[2900 * slot + len(frame) - 3] ^= 0x0F
+                torch.cuda.synchronize()
+            rt.decode_verify_async(d_blobs, outs[step & 1])
+            lean_seen.append("blake3_second_pass" not in dict(ctx.kernel_times()))
+            if step >= 1:
+                counters.append(rt.results_lagged(1))
+        counters.append(rt.results_lagged(0))
+        ctx.sync()
+        got = [o[:n * 10240].cpu().numpy().copy() for o in outs]
+        rt.close(); ctx.close()
+        return counters, got, lean_seen
+
+    lean, full = run({}), run({"ZNIPPY_NO_LEAN": "1"})
+    assert not any(full[2]) and any(lean[2][2:5]), (lean[2], full[2])   # lean runs were queued before the change
+    assert lean[0] == full[0], (lean[0], full[0])
+    assert sum(c["corrupt_rows"] + c["decode_errors"] for c in lean[0][:4]) == 0
+    assert all(c["corrupt_rows"] + c["decode_errors"] == 2 for c in lean[0][5:]), lean[0]
+    for a, b in zip(lean[1], full[1]):
+        assert (a == b).all()
+    for o in lean[1]:
+        assert o[:42 * 10240].tobytes() == data * 42 and o[43 * 10240:2900 * 10240].tobytes() == data * (2900 - 43)

@@ -381,8 +381,7 @@ struct znippy_rows {
     bool lean_ok = false;      // the table's shape allows it (set at creation)
     int lean_hint = -1;        // last finished run: 1 nothing left behind the roles kernel, 0 something was, -1 not known
     bool last_lean = false;
-    const void *last_blobs = nullptr; void *last_out = nullptr;
-    uint64_t last_base = 0, last_cap = 0;
+    struct RunArgs { const void *blobs = nullptr; void *out = nullptr; uint64_t base = 0, cap = 0; } run_args[2];  // per mirror slot: what the run was given
     hipEvent_t ev_done[2] = {nullptr, nullptr};
     uint64_t run_seq = 0;  // async runs queued so far
     // Host copies of the columns a run is validated against (one pass per distinct (blob_base, blob_cap, out_cap)):
@@ -1341,7 +1340,7 @@ int znippy_decode_verify_rows_async(znippy_ctx *ctx, znippy_rows *r, const void 
     }
     const bool bx = r->bx_slots && ctx->fz_lit_pool && ctx->fz_seq_pool && ctx->bx_fse_pool && ctx->bx_huf_pool && r->bx_hint != 0;
     const int preset = r->n_bad ? 1 : 0;
-    r->last_blobs = d_blobs; r->last_base = blob_base; r->last_out = d_out; r->last_cap = out_cap;
+    { auto &ra = r->run_args[r->run_seq & 1]; ra.blobs = d_blobs; ra.base = blob_base; ra.out = d_out; ra.cap = out_cap; }
     bool lean = false;
     // counters, hand-over counts, work cursors and the status column: one stream operation
     if (preset) HIPCHK(ctx, hipMemcpyAsync(r->ctl, r->status_init, r->ctl_bytes, hipMemcpyDeviceToDevice, s));
@@ -1712,19 +1711,25 @@ int znippy_decode_verify_rows_async(znippy_ctx *ctx, znippy_rows *r, const void 
     return ZNIPPY_OK;
 }
 
-// A lean run whose lists were not empty after all (counters[7] set by k_verify): run the table again in full with the same
-// arguments, and give both mirror slots the full run's counters (a second lean run may be in flight behind the first: its
-// results are the same).  Called by everything that hands a run's results to the caller.
+// A lean run whose lists were not empty after all (counters[7] set by k_verify): the run of mirror slot `slot` is done again
+// in full with the arguments IT was given (a caller that alternates buffers gets the right buffer completed), and the slot
+// gets the full run's counters.  The repeat is run k + 2 when another run is queued behind the flagged one — the same slot
+// — or run k + 1 otherwise; a flagged run k + 1 is settled when its own results are read.  Called by everything that hands
+// a run's results to the caller.
 static int rows_settle(znippy_ctx *ctx, znippy_rows *r, unsigned slot) {
     if (!r->n || !r->run_seq || !(r->h_counters[16 * slot + 7])) return ZNIPPY_OK;
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     r->force_full = true;
     r->lean_hint = 0;
-    const int rc = znippy_decode_verify_rows_async(ctx, r, r->last_blobs, r->last_base, r->last_out, r->last_cap);
+    const znippy_rows::RunArgs ra = r->run_args[slot];
+    const int rc = znippy_decode_verify_rows_async(ctx, r, ra.blobs, ra.base, ra.out, ra.cap);
     if (rc) return rc;
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     const unsigned now = (unsigned)((r->run_seq - 1) & 1);
-    memcpy(r->h_counters + 16 * (now ^ 1), r->h_counters + 16 * now, 128);
+    if (now != slot) {
+        memcpy(r->h_counters + 16 * slot, r->h_counters + 16 * now, 128);
+        r->run_args[slot] = ra;
+    }
     return ZNIPPY_OK;
 }
 
