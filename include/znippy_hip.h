@@ -125,7 +125,13 @@ int znippy_rows_set_blob_cap(znippy_rows *rows, uint64_t blob_cap);
  * batch path sized from the table's content (literals 1 byte, sequence records 1.5, decoding tables 1 per content byte of
  * its compressed rows, each capped at 16 GiB) and — only for tables with compressed rows above 64 KiB — 4 bytes per byte of
  * those rows for the resolve path, capped at 8 GiB (ZNIPPY_NO_RX=1 in the environment of znippy_ctx_create: none, such
- * frames are then executed by one wave each).  A pool that cannot be allocated is not an error: its path is not used. */
+ * frames are then executed by one wave each).  A pool that cannot be allocated is not an error: its path is not used.
+ * The bytes in d_out belong to the caller once a results call for that run has returned (znippy_rows_results,
+ * znippy_rows_results_lagged, znippy_rows_digests — the synchronous call ends in one): a table whose previous run needed
+ * nothing behind its main kernel is run without the kernels that stand behind it, and a run that turns out to have needed
+ * them after all (the blobs changed) is repeated in full, with the arguments it was given, inside the first results call
+ * that looks at it.  d_blobs / d_out of a queued run must therefore stay valid until its results have been read
+ * (ZNIPPY_NO_LEAN=1 in the environment of znippy_ctx_create: every run is a full one). */
 int znippy_decode_verify_rows(znippy_ctx *ctx, znippy_rows *rows, const void *d_blobs,
                               uint64_t blob_base, void *d_out, uint64_t out_cap,
                               znippy_verify_counters *counters, uint64_t *corrupt_rows,
