@@ -1408,6 +1408,11 @@ int znippy_decode_verify_rows_async(znippy_ctx *ctx, znippy_rows *r, const void 
     //    on are decoded by a second general launch afterwards.
     if (!lean) {  // (a lean run: nothing is expected behind the roles kernel; k_verify checks that — rows_settle)
     BlockScanArgs b{};
+    // The block items run on the auxiliary stream beside whatever the main stream has — unless it has nothing: a table of big
+    // rows only whose last run handed nothing over (`behind` below: the serial decoder is launched after the join anyway).
+    // Then everything goes down one stream: the fork and the join between two streams were ~0.1 ms of C3's 1.09 ms step.
+    const bool one_stream = r->n_cand && r->bx_hint == 0 && r->n_small_tiles == 0;
+    const hipStream_t ba = one_stream ? s : ctx->aux;
     if (r->n_cand) {
         if (!ctx->lit_scratch_b && hipMalloc(&ctx->lit_scratch_b, decode_lit_scratch_bytes(ctx->decode_grid)) != hipSuccess) return ZNIPPY_E_NOMEM;
         b.cand_row = r->cand_row; b.cand_base = r->cand_base; b.cand_nblocks = r->cand_nblocks; b.n_cand = r->n_cand;
@@ -1416,14 +1421,16 @@ int znippy_decode_verify_rows_async(znippy_ctx *ctx, znippy_rows *r, const void 
         b.item_src = r->item_src; b.row_flag = r->row_flag; b.status = r->status;
         b.preset = preset;
         b.pending = r->pending2; b.pending_count = r->pending_count + 1;  // its own hand-over list (count: second word of the control block)
-        HIPCHK(ctx, hipEventRecord(ctx->ev_fork, s));
-        HIPCHK(ctx, hipStreamWaitEvent(ctx->aux, ctx->ev_fork, 0));
-        ktime_begin(ctx, "zstd_block_scan", ctx->aux);
-        launch_scan_blocks(b, ctx->aux);
-        ktime_end(ctx, ctx->aux);
+        if (!one_stream) {
+            HIPCHK(ctx, hipEventRecord(ctx->ev_fork, s));
+            HIPCHK(ctx, hipStreamWaitEvent(ba, ctx->ev_fork, 0));
+        }
+        ktime_begin(ctx, "zstd_block_scan", ba);
+        launch_scan_blocks(b, ba);
+        ktime_end(ctx, ba);
         if (r->n_bt) {  // blocks of the common shape: written and hashed in one go, skipped by the two passes below
-            HIPCHK(ctx, hipMemsetAsync(r->tile_done, 0, r->plan.n_tiles, ctx->aux));
-            HIPCHK(ctx, hipMemsetAsync(r->item_done, 0, r->n_items, ctx->aux));
+            HIPCHK(ctx, hipMemsetAsync(r->tile_done, 0, r->plan.n_tiles, ba));
+            HIPCHK(ctx, hipMemsetAsync(r->item_done, 0, r->n_items, ba));
             FusedBlocksArgs fb{};
             fb.h = h;
             fb.h.pass = 0;  // PASS_ALL
@@ -1432,10 +1439,10 @@ int znippy_decode_verify_rows_async(znippy_ctx *ctx, znippy_rows *r, const void 
             fb.item_src = r->item_src; fb.row_flag = r->row_flag;
             fb.tile_done = r->tile_done; fb.item_done = r->item_done;
             fb.dbg = ctx->sw.dbg;
-            ktime_begin(ctx, "decode_verify_fused_blocks", ctx->aux);
-            launch_fused_blocks(fb, ctx->aux);
-            ktime_end(ctx, ctx->aux);
-            launch_compact_items(r->item_done, r->n_items, r->todo, r->pending_count + 2, ctx->aux);
+            ktime_begin(ctx, "decode_verify_fused_blocks", ba);
+            launch_fused_blocks(fb, ba);
+            ktime_end(ctx, ba);
+            launch_compact_items(r->item_done, r->n_items, r->todo, r->pending_count + 2, ba);
         }
         DecodeArgs a{};
         a.preset = preset;
@@ -1456,16 +1463,16 @@ int znippy_decode_verify_rows_async(znippy_ctx *ctx, znippy_rows *r, const void 
             if (!dbg) { (void)hipMalloc(&dbg, 64); (void)hipMemset(dbg, 0, 64); }
             unsigned long long h[8];
             (void)hipStreamSynchronize(s);
-            (void)hipStreamSynchronize(ctx->aux);
+            (void)hipStreamSynchronize(ba);
             (void)hipMemcpy(h, dbg, 64, hipMemcpyDeviceToHost);
             if (h[0]) fprintf(stderr, "[znippy ddbg] block items=%llu  cycles per item: literals=%.0f seq-tables=%.0f seq-decode=%.0f execute=%.0f tail=%.0f\n", h[0],
                               (double)h[1] / h[0], (double)h[2] / h[0], (double)h[3] / h[0], (double)h[4] / h[0], (double)h[5] / h[0]);
             (void)hipMemset(dbg, 0, 64);
             a.dbg = dbg;
         }
-        ktime_begin(ctx, "zstd_decode_blocks", ctx->aux);
-        launch_decode(a, std::min<int>(ctx->decode_grid, (int)r->n_items), false, ctx->aux);
-        ktime_end(ctx, ctx->aux);
+        ktime_begin(ctx, "zstd_decode_blocks", ba);
+        launch_decode(a, std::min<int>(ctx->decode_grid, (int)r->n_items), false, ba);
+        ktime_end(ctx, ba);
         if (r->fz_total) {
             // Foreign frames (what the block items gave up on): entropy-decode every block at once, then execute frame by
             // frame.  On the auxiliary stream, behind the block items and BESIDE the general decoder on the main stream:
@@ -1486,7 +1493,7 @@ int znippy_decode_verify_rows_async(znippy_ctx *ctx, znippy_rows *r, const void 
                 if (!dbg) { (void)hipMalloc(&dbg, 256); (void)hipMemset(dbg, 0, 256); }
                 unsigned long long h[32];
                 (void)hipStreamSynchronize(s);
-                (void)hipStreamSynchronize(ctx->aux);
+                (void)hipStreamSynchronize(ba);
                 (void)hipMemcpy(h, dbg, 256, hipMemcpyDeviceToHost);
                 if (h[0]) fprintf(stderr, "[znippy ddbg] fz exec: frames=%llu groups=%llu seqs=%llu big=%llu rounds=%llu flushes=%llu histreads=%llu rep_groups=%llu | kcycles/frame: total=%.0f records=%.0f rep+scan=%.0f big=%.0f flush=%.0f histread=%.0f lits=%.0f matches=%.0f tail=%.0f\n",
                                   h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7], h[8] / 1e3 / h[0], h[9] / 1e3 / h[0], h[10] / 1e3 / h[0], h[11] / 1e3 / h[0],
@@ -1496,15 +1503,15 @@ int znippy_decode_verify_rows_async(znippy_ctx *ctx, znippy_rows *r, const void 
                 (void)hipMemset(dbg, 0, 256);
                 z.dbg = dbg;
             }
-            launch_fz_scan(z, r->fz_work, r->cursor + 13, ctx->aux);
-            ktime_begin(ctx, "zstd_foreign_entropy", ctx->aux);
-            launch_fz_entropy(z, ctx->cus, r->fz_work, r->cursor + 13, ctx->aux);
-            ktime_end(ctx, ctx->aux);
-            ktime_begin(ctx, "zstd_foreign_execute", ctx->aux);
-            launch_fz_exec(z, ctx->aux);
-            ktime_end(ctx, ctx->aux);
+            launch_fz_scan(z, r->fz_work, r->cursor + 13, ba);
+            ktime_begin(ctx, "zstd_foreign_entropy", ba);
+            launch_fz_entropy(z, ctx->cus, r->fz_work, r->cursor + 13, ba);
+            ktime_end(ctx, ba);
+            ktime_begin(ctx, "zstd_foreign_execute", ba);
+            launch_fz_exec(z, ba);
+            ktime_end(ctx, ba);
         }
-        HIPCHK(ctx, hipEventRecord(ctx->ev_join, ctx->aux));
+        if (!one_stream) HIPCHK(ctx, hipEventRecord(ctx->ev_join, ctx->aux));
     }
     if (r->n_compressed) {
         DecodeArgs a{};
@@ -1659,7 +1666,7 @@ int znippy_decode_verify_rows_async(znippy_ctx *ctx, znippy_rows *r, const void 
             // waiting for CUs next to the block kernels: C3's 0.25 ms "general decoder" that only waited).
             const bool behind = r->n_cand && r->bx_hint == 0;
             if (behind) {
-                HIPCHK(ctx, hipStreamWaitEvent(s, ctx->ev_join, 0));
+                if (!one_stream) HIPCHK(ctx, hipStreamWaitEvent(s, ctx->ev_join, 0));
                 launch_finish_blocks(b, s, false);
             }
             ktime_begin(ctx, "zstd_decode_general");
