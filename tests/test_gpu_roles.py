@@ -296,3 +296,60 @@ def test_lean_runs_in_a_pipeline_with_alternating_buffers(oracle):
         assert (a == b).all()
     for o in lean[1]:
         assert o[:42 * 10240].tobytes() == data * 42 and o[43 * 10240:2900 * 10240].tobytes() == data * (2900 - 43)
+
+
+def test_lean_runs_of_big_row_tables_notice_changed_blobs(oracle):
+    """The same for a table of big multi-block rows (this encoder's frames of periodic text: the fused block kernel writes and
+    hashes every block, the serial block decoder and the serial decoder behind it find empty lists): the third run leaves
+    their launches out; then a block of one frame is damaged and a frame is replaced by a libzstd frame (blocks that refer
+    to each other: the batch path's business) — the run that meets them reports what a ZNIPPY_NO_LEAN context reports."""
+    import os
+    import torch
+    import gen
+    from znippy_amd import hip
+    n, size = 24, 4 * 131072   # whole blocks: a short last block is the serial block decoder's every time (no lean runs then)
+    rows = [gen.text(size) if i % 3 else gen.binary(size) for i in range(n)]
+    ctx0 = hip.Context(0)
+    frames = [ctx0.compress(r_) for r_ in rows]
+    ctx0.close()
+    foreign = oracle.libzstd_compress(rows[7], 3)
+    slot = max(max(len(f) for f in frames), len(foreign)) + 11
+    bo = np.arange(n, dtype=np.uint64) * np.uint64(slot)
+    bs = np.array([len(f) for f in frames], np.uint64)
+    us = np.full(n, size, np.uint64)
+    oo = np.arange(n, dtype=np.uint64) * np.uint64(size)
+    ck = np.stack([np.frombuffer(oracle.blake3(r_), dtype=np.uint8) for r_ in rows])
+    blob = np.zeros(n * slot + 64, np.uint8)
+    for i, f in enumerate(frames):
+        blob[i * slot:i * slot + len(f)] = np.frombuffer(f, np.uint8)
+
+    def run(env):
+        old = os.environ.get("ZNIPPY_NO_LEAN")
+        os.environ.update(env)
+        try:
+            ctx = hip.Context(0)
+        finally:
+            if old is None: os.environ.pop("ZNIPPY_NO_LEAN", None)
+            else: os.environ["ZNIPPY_NO_LEAN"] = old
+        d_blobs = torch.from_numpy(blob.copy()).cuda()
+        d_out = torch.zeros(n * size + 64, dtype=torch.uint8, device="cuda")
+        rt = hip.RowTable(ctx, bo, bs, us, oo, None, ck)
+        seen = []
+        for step in range(6):
+            if step == 3:
+                d_blobs[3 * slot + 40] ^= 0x7F                      # row 3: a byte of its first block
+            d_out.zero_()
+            torch.cuda.synchronize()
+            c, corrupt, status = rt.decode_verify(d_blobs, d_out)
+            kt = dict(ctx.kernel_times())
+            seen.append((dict(c), sorted(int(x) for x in corrupt), status.copy(), rt.digests().copy(), d_out[:n * size].cpu().numpy().copy(),
+                         "zstd_decode_blocks" in kt))
+        rt.close(); ctx.close()
+        return seen
+
+    lean, full = run({}), run({"ZNIPPY_NO_LEAN": "1"})
+    assert all(s[5] for s in full) and lean[0][5] and not lean[2][5], [s[5] for s in lean]
+    for a, b in zip(lean, full):
+        assert a[0] == b[0] and a[1] == b[1] and (a[2] == b[2]).all() and (a[3] == b[3]).all() and (a[4] == b[4]).all()
+    assert lean[2][0]["corrupt_rows"] + lean[2][0]["decode_errors"] == 0
+    assert lean[3][0]["corrupt_rows"] + lean[3][0]["decode_errors"] == 1, lean[3][0]

@@ -380,6 +380,8 @@ struct znippy_rows {
     // run's results first runs it again in full (rows_settle) — same inputs, the results the caller would have had.
     bool lean_ok = false;      // the table's shape allows it (set at creation)
     int lean_hint = -1;        // last finished run: 1 nothing left behind the roles kernel, 0 something was, -1 not known
+    bool lean_blocks_ok = false;  // the same for tables of big multi-block rows only (the fused block kernel in front)
+    int lean_hint2 = -1;
     bool last_lean = false;
     struct RunArgs { const void *blobs = nullptr; void *out = nullptr; uint64_t base = 0, cap = 0; } run_args[2];  // per mirror slot: what the run was given
     hipEvent_t ev_done[2] = {nullptr, nullptr};
@@ -1193,6 +1195,7 @@ int znippy_rows_create(znippy_ctx *ctx, const uint64_t *blob_offset, const uint6
     r->wide_rows = n_big && big_bytes / n_big >= (1u << 20) && big_blob * 50 < big_bytes;
     r->n_cand = (uint32_t)cand_row.size();
     r->n_items = (uint32_t)item_row.size();
+    r->lean_blocks_ok = allc && !ctx->sw.no_lean && r->n_list_a == 0 && r->n_cand > 0 && r->n_small_tiles == 0;
     r->lean_ok = allc && !ctx->sw.no_lean && r->n_list_a == 0 && r->n_cand == 0 && p.big.empty() && r->n_small_tiles == (uint32_t)p.tiles.size() &&
                  r->n_small_tiles > 0;
     if (r->n_cand) {
@@ -1314,6 +1317,7 @@ static void rows_note_hint(znippy_rows *r, unsigned slot) {
     const uint32_t *pc = reinterpret_cast<const uint32_t *>(r->h_counters + 16 * slot + 8);
     r->bx_hint = (pc[0] || pc[1] || pc[5] || r->n_list_a) ? 1 : 0;  // ([1]: what went to the serial decoder)
     r->lean_hint = (pc[0] || pc[1] || pc[3] || pc[5]) ? 0 : 1;       // ([3]: tiles the role-split kernel left on its list)
+    r->lean_hint2 = (pc[0] || pc[1] || pc[2] || pc[5]) ? 0 : 1;      // ([2]: block items the fused block kernel left)
 }
 
 int znippy_decode_verify_rows_async(znippy_ctx *ctx, znippy_rows *r, const void *d_blobs,
@@ -1341,7 +1345,7 @@ int znippy_decode_verify_rows_async(znippy_ctx *ctx, znippy_rows *r, const void 
     const bool bx = r->bx_slots && ctx->fz_lit_pool && ctx->fz_seq_pool && ctx->bx_fse_pool && ctx->bx_huf_pool && r->bx_hint != 0;
     const int preset = r->n_bad ? 1 : 0;
     { auto &ra = r->run_args[r->run_seq & 1]; ra.blobs = d_blobs; ra.base = blob_base; ra.out = d_out; ra.cap = out_cap; }
-    bool lean = false;
+    bool lean = false, lean_blocks = false;
     // counters, hand-over counts, work cursors and the status column: one stream operation
     if (preset) HIPCHK(ctx, hipMemcpyAsync(r->ctl, r->status_init, r->ctl_bytes, hipMemcpyDeviceToDevice, s));
     else HIPCHK(ctx, hipMemsetAsync(r->ctl, 0, r->ctl_bytes, s));
@@ -1413,6 +1417,10 @@ int znippy_decode_verify_rows_async(znippy_ctx *ctx, znippy_rows *r, const void 
     // Then everything goes down one stream: the fork and the join between two streams were ~0.1 ms of C3's 1.09 ms step.
     const bool one_stream = r->n_cand && r->bx_hint == 0 && r->n_small_tiles == 0;
     const hipStream_t ba = one_stream ? s : ctx->aux;
+    // ... and when its last run needed neither the serial block decoder nor the serial decoder behind it (every block item
+    // was written and hashed by the fused block kernel), those three launches are left out, the way a lean run of a table
+    // of small rows leaves out what stands behind the roles kernel: k_verify looks at the lists, a flagged run is repeated.
+    lean_blocks = one_stream && r->lean_blocks_ok && r->lean_hint2 == 1 && !preset && !r->force_full && r->n_bt && !ctx->sw.ddbg && !r->fz_total;
     if (r->n_cand) {
         if (!ctx->lit_scratch_b && hipMalloc(&ctx->lit_scratch_b, decode_lit_scratch_bytes(ctx->decode_grid)) != hipSuccess) return ZNIPPY_E_NOMEM;
         b.cand_row = r->cand_row; b.cand_base = r->cand_base; b.cand_nblocks = r->cand_nblocks; b.n_cand = r->n_cand;
@@ -1470,9 +1478,11 @@ int znippy_decode_verify_rows_async(znippy_ctx *ctx, znippy_rows *r, const void 
             (void)hipMemset(dbg, 0, 64);
             a.dbg = dbg;
         }
-        ktime_begin(ctx, "zstd_decode_blocks", ba);
-        launch_decode(a, std::min<int>(ctx->decode_grid, (int)r->n_items), false, ba);
-        ktime_end(ctx, ba);
+        if (!lean_blocks) {
+            ktime_begin(ctx, "zstd_decode_blocks", ba);
+            launch_decode(a, std::min<int>(ctx->decode_grid, (int)r->n_items), false, ba);
+            ktime_end(ctx, ba);
+        }
         if (r->fz_total) {
             // Foreign frames (what the block items gave up on): entropy-decode every block at once, then execute frame by
             // frame.  On the auxiliary stream, behind the block items and BESIDE the general decoder on the main stream:
@@ -1669,6 +1679,7 @@ int znippy_decode_verify_rows_async(znippy_ctx *ctx, znippy_rows *r, const void 
                 if (!one_stream) HIPCHK(ctx, hipStreamWaitEvent(s, ctx->ev_join, 0));
                 launch_finish_blocks(b, s, false);
             }
+            if (!lean_blocks) {
             ktime_begin(ctx, "zstd_decode_general");
             // A full grid of this kernel (4 workgroups per CU at 128 VGPRs) is the whole register file: whatever the auxiliary
             // stream launches then waits until workgroups run out of rows.  With candidates for the block / foreign-frame
@@ -1676,7 +1687,8 @@ int znippy_decode_verify_rows_async(znippy_ctx *ctx, znippy_rows *r, const void 
             const int gen_grid = r->n_cand && !behind ? ctx->decode_grid / 4 * ctx->gen_share : ctx->decode_grid;
             launch_decode(a, std::min<int>(gen_grid, (int)r->n_compressed), r->wide_rows, s);
             ktime_end(ctx);
-            if (r->n_cand) {  // join (block items and the foreign-frame path on the auxiliary stream), then what both gave up on
+            }
+            if (r->n_cand && !lean_blocks) {  // join (block items and the foreign-frame path on the auxiliary stream), then what both gave up on
                 if (!behind) {
                     HIPCHK(ctx, hipStreamWaitEvent(s, ctx->ev_join, 0));
                     launch_finish_blocks(b, s, false);
@@ -1703,10 +1715,12 @@ int znippy_decode_verify_rows_async(znippy_ctx *ctx, znippy_rows *r, const void 
         ktime_end(ctx);
     }
     }  // !lean
-    r->last_lean = lean;
+    r->last_lean = lean || lean_blocks;
     ktime_begin(ctx, "verify");
+    // the lists a lean run must have left empty: [0] rows handed over by the fused kernels, [1] rows for the serial decoder, [5]
+    // flagged candidates; [3] tiles the roles kernel left (small rows), [2] block items the fused block kernel left (big rows)
     launch_verify(r->digests, r->checksum, r->usize, r->status, r->n, r->row_begin, r->counters, r->corrupt,
-                  r->corrupt_cap, s, lean ? r->pending_count : nullptr);
+                  r->corrupt_cap, s, (lean || lean_blocks) ? r->pending_count : nullptr, lean ? 0x2Bu : 0x27u);
     ktime_end(ctx);
     {
         const unsigned slot = (unsigned)(r->run_seq & 1);
@@ -1727,7 +1741,7 @@ static int rows_settle(znippy_ctx *ctx, znippy_rows *r, unsigned slot) {
     if (!r->n || !r->run_seq || !(r->h_counters[16 * slot + 7])) return ZNIPPY_OK;
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     r->force_full = true;
-    r->lean_hint = 0;
+    r->lean_hint = 0; r->lean_hint2 = 0;
     const znippy_rows::RunArgs ra = r->run_args[slot];
     const int rc = znippy_decode_verify_rows_async(ctx, r, ra.blobs, ra.base, ra.out, ra.cap);
     if (rc) return rc;

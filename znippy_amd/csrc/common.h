@@ -133,7 +133,7 @@ void launch_merge_big(const BigUnit *big, uint32_t n_big, uint32_t *tile_cv, uin
                       const uint32_t *grp_k, uint32_t n_grp, hipStream_t s);
 void launch_verify(const uint32_t *digests, const uint8_t *checksum, const uint64_t *usize,
                    const int32_t *status, uint32_t n_rows, uint64_t row_begin, uint64_t *counters,
-                   uint64_t *corrupt_rows, uint32_t corrupt_cap, hipStream_t s, const uint32_t *lean_lists = nullptr);
+                   uint64_t *corrupt_rows, uint32_t corrupt_cap, hipStream_t s, const uint32_t *lean_lists = nullptr, uint32_t lean_mask = 0);
 int decode_grid_size(int device);
 void launch_decode(const DecodeArgs &a, int grid, bool wide, hipStream_t s);
 // block-item path: header scan of the candidate frames, then (after the block-mode decode) the per-row verdict

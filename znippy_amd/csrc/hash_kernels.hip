@@ -161,10 +161,14 @@ void launch_merge_big(const BigUnit *big, uint32_t n_big, uint32_t *tile_cv, uin
 __global__ __launch_bounds__(256) void k_verify(const uint32_t *digests, const uint8_t *checksum,
                                                 const uint64_t *usize, const int32_t *status, uint32_t n_rows,
                                                 uint64_t row_begin, unsigned long long *counters,
-                                                uint64_t *corrupt_rows, uint32_t corrupt_cap, const uint32_t *lean_lists) {
+                                                uint64_t *corrupt_rows, uint32_t corrupt_cap, const uint32_t *lean_lists, uint32_t lean_mask) {
     // lean run (api.hip, rows_settle): the kernels behind the role-split one were not launched — if it did hand a row over or
     // leave a tile on its list ([0], [3]; [1], [5]: nobody ran who could have), the run's counters are flagged
-    if (lean_lists && blockIdx.x == 0 && threadIdx.x == 0 && (lean_lists[0] | lean_lists[1] | lean_lists[3] | lean_lists[5])) counters[7] = 1;
+    if (lean_lists && blockIdx.x == 0 && threadIdx.x == 0) {
+        uint32_t any = 0;
+        for (uint32_t i = 0; i < 8; i++) if ((lean_mask >> i) & 1u) any |= lean_lists[i];
+        if (any) counters[7] = 1;
+    }
     unsigned long long v[6] = {0, 0, 0, 0, 0, 0};
     // grid-stride: a few dozen workgroups, so that the counters' cache line takes a few hundred atomics per run
     // (one workgroup per 256 rows put 1,200 on it for 100k rows: ~13 us of the step)
@@ -209,10 +213,10 @@ __global__ __launch_bounds__(256) void k_verify(const uint32_t *digests, const u
 
 void launch_verify(const uint32_t *digests, const uint8_t *checksum, const uint64_t *usize,
                    const int32_t *status, uint32_t n_rows, uint64_t row_begin, uint64_t *counters,
-                   uint64_t *corrupt_rows, uint32_t corrupt_cap, hipStream_t s, const uint32_t *lean_lists) {
+                   uint64_t *corrupt_rows, uint32_t corrupt_cap, hipStream_t s, const uint32_t *lean_lists, uint32_t lean_mask) {
     if (!n_rows) return;
     hipLaunchKernelGGL(k_verify, dim3(std::min<uint32_t>((n_rows + 255) / 256, 128)), dim3(256), 0, s, digests, checksum, usize, status,
-                       n_rows, row_begin, reinterpret_cast<unsigned long long *>(counters), corrupt_rows, corrupt_cap, lean_lists);
+                       n_rows, row_begin, reinterpret_cast<unsigned long long *>(counters), corrupt_rows, corrupt_cap, lean_lists, lean_mask);
 }
 
 // ---- measurement hook: the VALU floor of the hash ------------------------------------------------------------
