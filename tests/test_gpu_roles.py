@@ -353,3 +353,62 @@ def test_lean_runs_of_big_row_tables_notice_changed_blobs(oracle):
         assert a[0] == b[0] and a[1] == b[1] and (a[2] == b[2]).all() and (a[3] == b[3]).all() and (a[4] == b[4]).all()
     assert lean[2][0]["corrupt_rows"] + lean[2][0]["decode_errors"] == 0
     assert lean[3][0]["corrupt_rows"] + lean[3][0]["decode_errors"] == 1, lean[3][0]
+
+
+def test_lean_runs_of_mixed_tables_notice_changed_blobs(oracle):
+    """Small compressed rows beside big stored rows (BASELINE configs[4]'s shape): when the last run handed nothing over, the
+    small rows' kernel runs beside the second hash pass instead of in front of it and the serial decoder is not launched.
+    A small row is then damaged: the run that meets it reports what a ZNIPPY_NO_LEAN context reports, bytes included."""
+    import os
+    import torch
+    import gen
+    from znippy_amd import hip
+    rng = np.random.default_rng(11)
+    small = [gen.text(int(rng.integers(1024, 8192))) for _ in range(900)]
+    big = [gen.incompressible(20 + i, (1 << 20) + 4096 * i) for i in range(6)]
+    entries = small + big
+    ctx0 = hip.Context(0)
+    frames = [ctx0.compress(e) for e in small] + big                  # the big rows are stored as they are
+    ctx0.close()
+    comp = np.array([1] * len(small) + [0] * len(big), np.uint8)
+    n = len(entries)
+    bs = np.array([len(f) for f in frames], np.uint64)
+    bo = (np.cumsum(bs) - bs).astype(np.uint64)
+    us = np.array([len(e) for e in entries], np.uint64)
+    oo = (np.cumsum(us) - us).astype(np.uint64)
+    ck = np.stack([np.frombuffer(oracle.blake3(e), dtype=np.uint8) for e in entries])
+    bm = np.packbits(comp.astype(bool), bitorder="little")
+    blob = np.frombuffer(b"".join(frames) + bytes(64), np.uint8)
+    total = int(us.sum())
+
+    def run(env):
+        old = os.environ.get("ZNIPPY_NO_LEAN")
+        os.environ.update(env)
+        try:
+            ctx = hip.Context(0)
+        finally:
+            if old is None: os.environ.pop("ZNIPPY_NO_LEAN", None)
+            else: os.environ["ZNIPPY_NO_LEAN"] = old
+        d_blobs = torch.from_numpy(blob.copy()).cuda()
+        d_out = torch.zeros(total + 64, dtype=torch.uint8, device="cuda")
+        rt = hip.RowTable(ctx, bo, bs, us, oo, bm, ck)
+        seen = []
+        for step in range(6):
+            if step == 3:
+                d_blobs[int(bo[100]) + int(bs[100]) - 2] ^= 0x3C      # row 100: a byte of its sequence section
+            d_out.zero_()
+            torch.cuda.synchronize()
+            c, corrupt, status = rt.decode_verify(d_blobs, d_out)
+            kt = dict(ctx.kernel_times())
+            seen.append((dict(c), sorted(int(x) for x in corrupt), status.copy(), rt.digests().copy(), d_out[:total].cpu().numpy().copy(),
+                         sorted(kt)))
+        rt.close(); ctx.close()
+        return seen
+
+    lean, full = run({}), run({"ZNIPPY_NO_LEAN": "1"})
+    gen_in = lambda names: "zstd_decode_general" in names or "zstd_decode_fallback" in names
+    assert all(gen_in(s[5]) for s in full) and gen_in(lean[0][5]) and not gen_in(lean[2][5]), ([s[5] for s in lean], full[2][5])
+    for a, b in zip(lean, full):
+        assert a[0] == b[0] and a[1] == b[1] and (a[2] == b[2]).all() and (a[3] == b[3]).all() and (a[4] == b[4]).all()
+    assert lean[2][0]["corrupt_rows"] + lean[2][0]["decode_errors"] == 0 and lean[2][4].tobytes() == b"".join(entries)
+    assert lean[3][0]["corrupt_rows"] + lean[3][0]["decode_errors"] == 1, lean[3][0]

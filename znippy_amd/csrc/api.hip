@@ -381,6 +381,7 @@ struct znippy_rows {
     bool lean_ok = false;      // the table's shape allows it (set at creation)
     int lean_hint = -1;        // last finished run: 1 nothing left behind the roles kernel, 0 something was, -1 not known
     bool lean_blocks_ok = false;  // the same for tables of big multi-block rows only (the fused block kernel in front)
+    bool lean_mixed_ok = false;   // small rows beside big stored / hashed units: the small rows' kernel beside the second hash pass
     int lean_hint2 = -1;
     bool last_lean = false;
     struct RunArgs { const void *blobs = nullptr; void *out = nullptr; uint64_t base = 0, cap = 0; } run_args[2];  // per mirror slot: what the run was given
@@ -1195,6 +1196,7 @@ int znippy_rows_create(znippy_ctx *ctx, const uint64_t *blob_offset, const uint6
     r->wide_rows = n_big && big_bytes / n_big >= (1u << 20) && big_blob * 50 < big_bytes;
     r->n_cand = (uint32_t)cand_row.size();
     r->n_items = (uint32_t)item_row.size();
+    r->lean_mixed_ok = !ctx->sw.no_lean && r->n_list_a == 0 && r->n_cand == 0 && r->n_small_tiles > 0 && r->n_small_tiles < (uint32_t)p.tiles.size();
     r->lean_blocks_ok = allc && !ctx->sw.no_lean && r->n_list_a == 0 && r->n_cand > 0 && r->n_small_tiles == 0;
     r->lean_ok = allc && !ctx->sw.no_lean && r->n_list_a == 0 && r->n_cand == 0 && p.big.empty() && r->n_small_tiles == (uint32_t)p.tiles.size() &&
                  r->n_small_tiles > 0;
@@ -1345,7 +1347,7 @@ int znippy_decode_verify_rows_async(znippy_ctx *ctx, znippy_rows *r, const void 
     const bool bx = r->bx_slots && ctx->fz_lit_pool && ctx->fz_seq_pool && ctx->bx_fse_pool && ctx->bx_huf_pool && r->bx_hint != 0;
     const int preset = r->n_bad ? 1 : 0;
     { auto &ra = r->run_args[r->run_seq & 1]; ra.blobs = d_blobs; ra.base = blob_base; ra.out = d_out; ra.cap = out_cap; }
-    bool lean = false, lean_blocks = false;
+    bool lean = false, lean_blocks = false, lean_mixed = false;
     // counters, hand-over counts, work cursors and the status column: one stream operation
     if (preset) HIPCHK(ctx, hipMemcpyAsync(r->ctl, r->status_init, r->ctl_bytes, hipMemcpyDeviceToDevice, s));
     else HIPCHK(ctx, hipMemsetAsync(r->ctl, 0, r->ctl_bytes, s));
@@ -1391,26 +1393,37 @@ int znippy_decode_verify_rows_async(znippy_ctx *ctx, znippy_rows *r, const void 
         // tables, where a persistent grid only adds start-up latency — is k_fused_small's.
         const bool roles = !ctx->sw.no_roles && ctx->sw.roles_min != 0 && r->n_small_tiles >= ctx->sw.roles_min && r->n_small_tiles > 0 &&
                            !(f.dbg & (1 | 2 | 4 | 8 | 128));
+        // A table of small rows AND big stored / hashed units (BASELINE configs[4]: 3,500 small files beside 6 GB of jars) whose
+        // last run handed nothing over: the small rows' kernel runs on the auxiliary stream beside the second hash pass, which
+        // then has only the big units' slices to do — nothing of the one depends on the other (C5: 0.28 ms of a 3.45 ms
+        // step ran in front of the pass).  k_verify checks the hand-over lists as in a lean run.
+        lean_mixed = r->lean_mixed_ok && r->lean_hint == 1 && r->bx_hint == 0 && !preset && !r->force_full && !f.dbg && !ctx->sw.ddbg;
+        const hipStream_t fs = lean_mixed ? ctx->aux : s;
+        if (lean_mixed) {
+            HIPCHK(ctx, hipEventRecord(ctx->ev_fork, s));
+            HIPCHK(ctx, hipStreamWaitEvent(ctx->aux, ctx->ev_fork, 0));
+        }
         if (roles) {
             f.cursor = r->cursor + 2;
             f.tile_list = r->slow_list;
             f.tile_count = r->pending_count + 3;
-            ktime_begin(ctx, "decode_verify_roles");
-            launch_fused_roles(f, ctx->cus, s);
-            ktime_end(ctx);
+            ktime_begin(ctx, "decode_verify_roles", fs);
+            launch_fused_roles(f, ctx->cus, fs);
+            ktime_end(ctx, fs);
             lean = r->lean_ok && r->lean_hint == 1 && r->bx_hint == 0 && !preset && !r->force_full && !f.dbg;
         }
         if (r->n_small_tiles && !lean) {
-            ktime_begin(ctx, "decode_verify_fused");
-            launch_fused_small(f, s, roles ? ctx->cus * 5 : 0);
-            ktime_end(ctx);
+            ktime_begin(ctx, "decode_verify_fused", fs);
+            launch_fused_small(f, fs, roles ? ctx->cus * 5 : 0);
+            ktime_end(ctx, fs);
         }
+        if (lean_mixed) HIPCHK(ctx, hipEventRecord(ctx->ev_join, ctx->aux));
     }
     // 2) the two decode paths run side by side: block items (frames of >= 2 blocks, every block a work item) on the
     //    auxiliary stream, the general decoder (single-block big rows + whatever the fused kernel handed over) on the
     //    main one — each is latency-bound on its own and leaves most of the chip idle.  Frames the block path gives up
     //    on are decoded by a second general launch afterwards.
-    if (!lean) {  // (a lean run: nothing is expected behind the roles kernel; k_verify checks that — rows_settle)
+    if (!lean && !lean_mixed) {  // (a lean run: nothing is expected behind the fused kernels; k_verify checks that — rows_settle)
     BlockScanArgs b{};
     // The block items run on the auxiliary stream beside whatever the main stream has — unless it has nothing: a table of big
     // rows only whose last run handed nothing over (`behind` below: the serial decoder is launched after the join anyway).
@@ -1703,6 +1716,8 @@ int znippy_decode_verify_rows_async(znippy_ctx *ctx, znippy_rows *r, const void 
             }
         }
     }
+    }
+    if (!lean) {
     // 3) second hash pass: slices of big rows + rows the general decoder finished
     h.pass = 2;  // PASS_SECOND
     h.tile_done = r->n_bt ? r->tile_done : nullptr;
@@ -1715,12 +1730,13 @@ int znippy_decode_verify_rows_async(znippy_ctx *ctx, znippy_rows *r, const void 
         ktime_end(ctx);
     }
     }  // !lean
-    r->last_lean = lean || lean_blocks;
+    if (lean_mixed) HIPCHK(ctx, hipStreamWaitEvent(s, ctx->ev_join, 0));
+    r->last_lean = lean || lean_blocks || lean_mixed;
     ktime_begin(ctx, "verify");
     // the lists a lean run must have left empty: [0] rows handed over by the fused kernels, [1] rows for the serial decoder, [5]
     // flagged candidates; [3] tiles the roles kernel left (small rows), [2] block items the fused block kernel left (big rows)
     launch_verify(r->digests, r->checksum, r->usize, r->status, r->n, r->row_begin, r->counters, r->corrupt,
-                  r->corrupt_cap, s, (lean || lean_blocks) ? r->pending_count : nullptr, lean ? 0x2Bu : 0x27u);
+                  r->corrupt_cap, s, (lean || lean_blocks || lean_mixed) ? r->pending_count : nullptr, (lean || lean_mixed) ? 0x2Bu : 0x27u);
     ktime_end(ctx);
     {
         const unsigned slot = (unsigned)(r->run_seq & 1);
