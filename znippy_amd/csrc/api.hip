@@ -382,6 +382,7 @@ struct znippy_rows {
     int lean_hint = -1;        // last finished run: 1 nothing left behind the roles kernel, 0 something was, -1 not known
     bool lean_blocks_ok = false;  // the same for tables of big multi-block rows only (the fused block kernel in front)
     bool lean_mixed_ok = false;   // small rows beside big stored / hashed units: the small rows' kernel beside the second hash pass
+    bool roles_off = false;       // a run of the role-split kernel left every tile on its list (rows of no shape it takes: 0.15 ms of looking)
     int lean_hint2 = -1;
     bool last_lean = false;
     struct RunArgs { const void *blobs = nullptr; void *out = nullptr; uint64_t base = 0, cap = 0; } run_args[2];  // per mirror slot: what the run was given
@@ -1320,6 +1321,7 @@ static void rows_note_hint(znippy_rows *r, unsigned slot) {
     r->bx_hint = (pc[0] || pc[1] || pc[5] || r->n_list_a) ? 1 : 0;  // ([1]: what went to the serial decoder)
     r->lean_hint = (pc[0] || pc[1] || pc[3] || pc[5]) ? 0 : 1;       // ([3]: tiles the role-split kernel left on its list)
     r->lean_hint2 = (pc[0] || pc[1] || pc[2] || pc[5]) ? 0 : 1;      // ([2]: block items the fused block kernel left)
+    if (r->n_small_tiles && pc[3] >= r->n_small_tiles) r->roles_off = true;  // the role-split kernel took not one tile: not this table's kernel
 }
 
 int znippy_decode_verify_rows_async(znippy_ctx *ctx, znippy_rows *r, const void *d_blobs,
@@ -1392,7 +1394,7 @@ int znippy_decode_verify_rows_async(znippy_ctx *ctx, znippy_rows *r, const void 
         // rows are all whole-leaf rows of the recognised periodic shape); what it leaves on its list — and small
         // tables, where a persistent grid only adds start-up latency — is k_fused_small's.
         const bool roles = !ctx->sw.no_roles && ctx->sw.roles_min != 0 && r->n_small_tiles >= ctx->sw.roles_min && r->n_small_tiles > 0 &&
-                           !(f.dbg & (1 | 2 | 4 | 8 | 128));
+                           !(f.dbg & (1 | 2 | 4 | 8 | 128)) && !r->roles_off;
         // A table of small rows AND big stored / hashed units (BASELINE configs[4]: 3,500 small files beside 6 GB of jars) whose
         // last run handed nothing over: the small rows' kernel runs on the auxiliary stream beside the second hash pass, which
         // then has only the big units' slices to do — nothing of the one depends on the other (C5: 0.28 ms of a 3.45 ms
