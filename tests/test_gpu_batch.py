@@ -154,3 +154,54 @@ def test_more_blocks_than_item_slots(gpu_ctx, oracle):
     c, status, out, st, kt = _decode(gpu_ctx, A)
     assert c["corrupt_rows"] == 0 and c["decode_errors"] == 0, (c, np.nonzero(status)[0][:10])
     assert out.tobytes() == b"".join(entries)
+
+
+def test_tables_the_fused_kernels_hand_over_entirely_skip_them(gpu_ctx, oracle):
+    """When the fused kernels handed every row of a table over to the batch path (rows of real text: nothing a recogniser
+    takes), later runs of the table give the rows to the batch path themselves and launch neither fused kernel.  Every run
+    returns every row; rows replaced later by frames of other kinds (a periodic one the fused kernel would have taken, a raw
+    one, a tiny one) still decode, through the batch path."""
+    import torch
+    from znippy_amd import hip
+    data = _py_corpus(8 << 20)
+    n = 2500
+    entries = [data[i * 3000:i * 3000 + 2048 + (i % 9) * 700] for i in range(n)]
+    frames = [workloads.libzstd_compress(e, 19 if i % 2 else 3) for i, e in enumerate(entries)]
+    # replacements of the same content size, used after the third run
+    swaps = {5: gen.text(len(entries[5])), 900: gen.incompressible(3, len(entries[900])), 2499: bytes(len(entries[2499]))}
+    slot = [max(len(frames[i]), len(workloads.libzstd_compress(swaps[i], 3)) if i in swaps else 0) + 3 for i in range(n)]
+    bo = (np.cumsum(slot) - np.array(slot)).astype(np.uint64)
+    bs = np.array([len(f) for f in frames], np.uint64)
+    us = np.array([len(e) for e in entries], np.uint64)
+    oo = (np.cumsum(us) - us).astype(np.uint64)
+    blob = np.zeros(int(sum(slot)) + 64, np.uint8)
+    for i, f in enumerate(frames):
+        blob[int(bo[i]):int(bo[i]) + len(f)] = np.frombuffer(f, np.uint8)
+    ck = np.stack([np.frombuffer(oracle.blake3(e), dtype=np.uint8) for e in entries])
+    d_blobs = torch.from_numpy(blob.copy()).cuda()
+    total = int(us.sum())
+    d_out = torch.zeros(total + 64, dtype=torch.uint8, device="cuda")
+    rt = hip.RowTable(gpu_ctx, bo, bs, us, oo, None, ck)
+    names = []
+    for step in range(3):
+        d_out.zero_()
+        c, corrupt, status = rt.decode_verify(d_blobs, d_out)
+        names.append(sorted(dict(gpu_ctx.kernel_times())))
+        assert c["corrupt_rows"] == 0 and c["decode_errors"] == 0 and c["verified_bytes"] == total, (step, c)
+        assert d_out[:total].cpu().numpy().tobytes() == b"".join(entries)
+    assert "decode_verify_fused" in names[0] and "decode_verify_fused" not in names[2], names
+    rt.close()
+    # the same slots with other frames in three rows: a new table over the changed blobs, run until it skips the fused kernels too
+    entries2, bs2 = list(entries), bs.copy()
+    for i, e in swaps.items():
+        f = workloads.libzstd_compress(e, 3)
+        d_blobs[int(bo[i]):int(bo[i]) + len(f)] = torch.from_numpy(np.frombuffer(f, np.uint8).copy()).cuda()
+        entries2[i] = e; bs2[i] = len(f)
+    ck2 = np.stack([np.frombuffer(oracle.blake3(e), dtype=np.uint8) for e in entries2])
+    rt = hip.RowTable(gpu_ctx, bo, bs2, us, oo, None, ck2)
+    for step in range(3):
+        d_out.zero_()
+        c, corrupt, status = rt.decode_verify(d_blobs, d_out)
+        assert c["corrupt_rows"] == 0 and c["decode_errors"] == 0, (step, c)
+        assert d_out[:total].cpu().numpy().tobytes() == b"".join(entries2)
+    rt.close()

@@ -383,6 +383,8 @@ struct znippy_rows {
     bool lean_blocks_ok = false;  // the same for tables of big multi-block rows only (the fused block kernel in front)
     bool lean_mixed_ok = false;   // small rows beside big stored / hashed units: the small rows' kernel beside the second hash pass
     bool roles_off = false;       // a run of the role-split kernel left every tile on its list (rows of no shape it takes: 0.15 ms of looking)
+    bool small_ok = false, small_off = false;  // the fused kernels handed over every row: later runs skip them (all_rows = the batch path's list)
+    uint32_t *all_rows = nullptr;
     int lean_hint2 = -1;
     bool last_lean = false;
     struct RunArgs { const void *blobs = nullptr; void *out = nullptr; uint64_t base = 0, cap = 0; } run_args[2];  // per mirror slot: what the run was given
@@ -661,6 +663,11 @@ __global__ __launch_bounds__(256) void k_rows_unpack_fill(const uint32_t *bs32, 
         bo[lo + k] = pb; bs[lo + k] = vb[k]; oo[lo + k] = po; us[lo + k] = vu[k];
         pb += vb[k]; po += vu[k];
     }
+}
+
+__global__ void k_iota32(uint32_t *p, uint32_t n) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) p[i] = i;
 }
 
 // rows: the bit column -> one byte per row, and a stored row's length = its blob (the reference hashes and writes the
@@ -988,7 +995,7 @@ void znippy_rows_destroy(znippy_rows *r) {
                     r->cand_row, r->cand_base, r->cand_nblocks, r->fz_base, r->fz_cap, r->fz_it_cand, r->fz_nb, r->fz_work, r->fz_items, r->item_row, r->item_k, r->item_src, r->row_flag, r->pending2,
                     r->bt_tile, r->bt_item, r->tile_done, r->item_done, r->todo, r->status_init, r->slow_list,
                     r->bx_cand_row, r->bx_cand_base, r->bx_cand_nb, r->bx_huf_list, r->bx_seq_list, r->bx_items, r->bx_prep, r->d_bitmap, r->bx_sort_tmp,
-                    r->rx_base, r->rx_fail, r->rx_blk, r->rx_list, r->d_pack, r->d_pack_sums};
+                    r->rx_base, r->rx_fail, r->rx_blk, r->rx_list, r->d_pack, r->d_pack_sums, r->all_rows};
     for (void *p : ptrs)
         tfree(r->ctx, p);
     if (r->h_counters) {
@@ -1197,6 +1204,8 @@ int znippy_rows_create(znippy_ctx *ctx, const uint64_t *blob_offset, const uint6
     r->wide_rows = n_big && big_bytes / n_big >= (1u << 20) && big_blob * 50 < big_bytes;
     r->n_cand = (uint32_t)cand_row.size();
     r->n_items = (uint32_t)item_row.size();
+    r->small_ok = allc && !ctx->sw.no_lean && !ctx->sw.no_bx && r->n_list_a == 0 && r->n_cand == 0 && r->n_small_tiles == (uint32_t)p.tiles.size() &&
+                  r->n_small_tiles > 0 && r->bx_slots;
     r->lean_mixed_ok = !ctx->sw.no_lean && r->n_list_a == 0 && r->n_cand == 0 && r->n_small_tiles > 0 && r->n_small_tiles < (uint32_t)p.tiles.size();
     r->lean_blocks_ok = allc && !ctx->sw.no_lean && r->n_list_a == 0 && r->n_cand > 0 && r->n_small_tiles == 0;
     r->lean_ok = allc && !ctx->sw.no_lean && r->n_list_a == 0 && r->n_cand == 0 && p.big.empty() && r->n_small_tiles == (uint32_t)p.tiles.size() &&
@@ -1322,6 +1331,10 @@ static void rows_note_hint(znippy_rows *r, unsigned slot) {
     r->lean_hint = (pc[0] || pc[1] || pc[3] || pc[5]) ? 0 : 1;       // ([3]: tiles the role-split kernel left on its list)
     r->lean_hint2 = (pc[0] || pc[1] || pc[2] || pc[5]) ? 0 : 1;      // ([2]: block items the fused block kernel left)
     if (r->n_small_tiles && pc[3] >= r->n_small_tiles) r->roles_off = true;  // the role-split kernel took not one tile: not this table's kernel
+    // ... and when the fused kernels handed over every row of a table of small compressed rows, the next runs give the rows to the
+    // batch path themselves (100k rows of real text: 0.26 ms of parsing each frame only to pass it on)
+    if (r->small_ok && pc[0] >= r->n) r->small_off = true;
+    if (r->small_off) r->bx_hint = 1;
 }
 
 int znippy_decode_verify_rows_async(znippy_ctx *ctx, znippy_rows *r, const void *d_blobs,
@@ -1347,6 +1360,11 @@ int znippy_decode_verify_rows_async(znippy_ctx *ctx, znippy_rows *r, const void 
         else (void)hipGetLastError();
     }
     const bool bx = r->bx_slots && ctx->fz_lit_pool && ctx->fz_seq_pool && ctx->bx_fse_pool && ctx->bx_huf_pool && r->bx_hint != 0;
+    const bool small_off = bx && r->small_off && !r->n_bad && !r->force_full && !ctx->sw.dbg;
+    if (small_off && !r->all_rows) {
+        if (tmalloc(ctx, &r->all_rows, 4 * (size_t)r->n) != hipSuccess) return ZNIPPY_E_NOMEM;
+        hipLaunchKernelGGL(k_iota32, dim3((r->n + 255) / 256), dim3(256), 0, s, r->all_rows, r->n);
+    }
     const int preset = r->n_bad ? 1 : 0;
     { auto &ra = r->run_args[r->run_seq & 1]; ra.blobs = d_blobs; ra.base = blob_base; ra.out = d_out; ra.cap = out_cap; }
     bool lean = false, lean_blocks = false, lean_mixed = false;
@@ -1354,6 +1372,8 @@ int znippy_decode_verify_rows_async(znippy_ctx *ctx, znippy_rows *r, const void 
     if (preset) HIPCHK(ctx, hipMemcpyAsync(r->ctl, r->status_init, r->ctl_bytes, hipMemcpyDeviceToDevice, s));
     else HIPCHK(ctx, hipMemsetAsync(r->ctl, 0, r->ctl_bytes, s));
     if (!r->n) { r->run_seq++; return ZNIPPY_OK; }
+    // (the second hash pass looks at small tiles only when rows were handed over: word 0 of the hand-over counts)
+    if (small_off) HIPCHK(ctx, hipMemsetD32Async((hipDeviceptr_t)(r->ctl + 64), (int)r->n, 1, s));
     // 1) fused small-row kernel: decode simple frames + hash (+ copy stored rows), one wave per tile
     HashArgs h{};
     h.tiles = r->plan.tiles; h.n_tiles = r->plan.n_tiles;
@@ -1364,7 +1384,7 @@ int znippy_decode_verify_rows_async(znippy_ctx *ctx, znippy_rows *r, const void 
     h.copy_to_B = 1;
     h.misaligned_dst = r->odd_out || ((uintptr_t)d_out & 15) != 0;
     h.digests = r->digests; h.tile_cv = r->plan.tile_cv;
-    {
+    if (!small_off) {
         FusedArgs f{};
         f.h = h;
         f.h.pass = 1;  // PASS_FUSED
@@ -1572,6 +1592,10 @@ int znippy_decode_verify_rows_async(znippy_ctx *ctx, znippy_rows *r, const void 
             BxArgs x{};
             x.list_a = r->list_a; x.n_list_a = r->n_list_a;
             x.pending = r->pending; x.pending_count = r->pending_count;
+            if (small_off) {  // every row is the batch path's: its list is all rows, nothing was handed over (a word that stays zero)
+                x.list_a = r->all_rows; x.n_list_a = r->n;
+                x.pending_count = reinterpret_cast<uint32_t *>(r->ctl + 448) + 15;
+            }
             x.bc_row = r->cand_row; x.n_bc = r->n_cand;
             x.blobs = (const uint8_t *)d_blobs; x.blob_base = blob_base;
             x.blob_off = r->blob_off; x.blob_size = r->blob_size; x.usize = r->usize; x.out_off = r->out_off; x.out_cap = out_cap;
