@@ -2212,6 +2212,7 @@ extern "C" int znippy_encode_hash_rounds_async(znippy_ctx *ctx, znippy_rounds *r
     g.blob_offset = r->blob_offset; g.blob_size = r->blob_size; g.total = r->total; g.overflow = r->overflow;
     g.stored = r->store_incompressible ? r->stored : nullptr;
     g.skip_stored_copy = fuse_store ? 1 : 0;
+    g.small_pieces = r->n_items && r->in_bytes / r->n_items <= 16384 ? 1 : 0;  // (tables of small rounds: their pieces are at most that, mostly far less)
     ktime_begin(ctx, "gather");
     launch_gather(g, s);
     ktime_end(ctx);

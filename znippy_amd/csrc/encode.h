@@ -77,6 +77,7 @@ struct GatherArgs {
     uint32_t *overflow;
     const uint8_t *stored;  // optional: rounds the store-if-incompressible pass turned into raw payloads
     int skip_stored_copy;   // store-heavy tables: the hash kernel copies the stored rounds while it hashes them
+    int small_pieces;       // the table's rounds average <= 16 KiB: lane = piece (k_gather); else wave = piece (k_gather_wide)
 };
 
 void launch_encode(const EncodeArgs &a, int grid, bool small_blocks, bool high, hipStream_t s);
