@@ -437,7 +437,8 @@ struct znippy_rows {
     // fused block kernel: big-slice tiles of the candidate rows, the item each belongs to, and what it got done
     uint32_t n_bt = 0;
     uint32_t *bt_tile = nullptr, *bt_item = nullptr;
-    uint8_t *tile_done = nullptr, *item_done = nullptr;
+    uint8_t *tile_done = nullptr, *item_done = nullptr;  // one allocation (item_done lies behind tile_done)
+    size_t done_bytes = 0;
     uint32_t *todo = nullptr;  // items left to the block decoder (count: third word of the control block)
     uint32_t n_small_tiles = 0;     // tiles of whole small rows (the fused kernels' work)
     uint32_t *slow_list = nullptr;  // tiles the role-split kernel leaves to k_fused_small (count: fourth word of the control block)
@@ -993,7 +994,7 @@ void znippy_rows_destroy(znippy_rows *r) {
     void *ptrs[] = {r->blob_off, r->blob_size, r->usize, r->out_off, r->compressed, r->checksum,
                     r->ctl, r->digests, r->corrupt, r->list_a, r->pending,
                     r->cand_row, r->cand_base, r->cand_nblocks, r->fz_base, r->fz_cap, r->fz_it_cand, r->fz_nb, r->fz_work, r->fz_items, r->item_row, r->item_k, r->item_src, r->row_flag, r->pending2,
-                    r->bt_tile, r->bt_item, r->tile_done, r->item_done, r->todo, r->status_init, r->slow_list,
+                    r->bt_tile, r->bt_item, r->tile_done, r->todo, r->status_init, r->slow_list,
                     r->bx_cand_row, r->bx_cand_base, r->bx_cand_nb, r->bx_huf_list, r->bx_seq_list, r->bx_items, r->bx_prep, r->d_bitmap, r->bx_sort_tmp,
                     r->rx_base, r->rx_fail, r->rx_blk, r->rx_list, r->d_pack, r->d_pack_sums, r->all_rows};
     for (void *p : ptrs)
@@ -1254,12 +1255,15 @@ int znippy_rows_create(znippy_ctx *ctx, const uint64_t *blob_offset, const uint6
             znippy_rows_destroy(r);
             return rc;
         }
-        if (tmalloc(ctx, &r->tile_done, std::max<size_t>(p.tiles.size(), 16)) != hipSuccess ||
-            tmalloc(ctx, &r->item_done, std::max<size_t>(r->n_items, 16)) != hipSuccess ||
+        // (the two arrays of done flags in one allocation: one clear per run instead of two)
+        const size_t td_bytes = (std::max<size_t>(p.tiles.size(), 16) + 15) & ~(size_t)15;
+        r->done_bytes = td_bytes + std::max<size_t>(r->n_items, 16);
+        if (tmalloc(ctx, &r->tile_done, r->done_bytes) != hipSuccess ||
             tmalloc(ctx, &r->todo, std::max<size_t>(4 * (size_t)r->n_items, 16)) != hipSuccess) {
             znippy_rows_destroy(r);
             return ZNIPPY_E_NOMEM;
         }
+        r->item_done = r->tile_done + td_bytes;
     }
     if ((rc = dev_upload(ctx, &r->list_a, la.data(), la.size()))) {
         znippy_rows_destroy(r);
@@ -1472,8 +1476,7 @@ int znippy_decode_verify_rows_async(znippy_ctx *ctx, znippy_rows *r, const void 
         launch_scan_blocks(b, ba);
         ktime_end(ctx, ba);
         if (r->n_bt) {  // blocks of the common shape: written and hashed in one go, skipped by the two passes below
-            HIPCHK(ctx, hipMemsetAsync(r->tile_done, 0, r->plan.n_tiles, ba));
-            HIPCHK(ctx, hipMemsetAsync(r->item_done, 0, r->n_items, ba));
+            HIPCHK(ctx, hipMemsetAsync(r->tile_done, 0, r->done_bytes, ba));
             FusedBlocksArgs fb{};
             fb.h = h;
             fb.h.pass = 0;  // PASS_ALL
