@@ -370,6 +370,68 @@ def test_stored_big_rows_every_output_alignment(gpu_ctx, oracle):
     assert np.array_equal(out, want)
 
 
+@pytest.mark.parametrize("tiles_per_wave", ["1", "2"])
+def test_stored_rows_one_and_two_tiles_per_wave(oracle, tiles_per_wave):
+    """Store path kernel, both forms (hash_kernels.hip: k_hash_tiles<COPY, 1 | 2>; picked from the tile count, forced here
+    through ZNIPPY_STORE_G): with two tiles per wave the first tile's leaf CVs wait in LDS in front of the stage and the two
+    parent trees are folded together.  Rows whose tiles pair up across row boundaries, ragged last tiles, a last wave
+    with one tile, small rows between the big ones (their tiles fold on the spot or queue, by their unit count) — every
+    digest equal to the oracle's, every byte in place, guard bytes untouched."""
+    import os
+    import torch
+    from znippy_amd import hip
+    old = os.environ.get("ZNIPPY_STORE_G")
+    os.environ["ZNIPPY_STORE_G"] = tiles_per_wave
+    try:
+        ctx = hip.Context(0)
+    finally:
+        if old is None:
+            del os.environ["ZNIPPY_STORE_G"]
+        else:
+            os.environ["ZNIPPY_STORE_G"] = old
+    try:
+        rng = np.random.default_rng(77)
+        sizes = [1 << 16, (1 << 16) + 1, 3 << 16, (5 << 16) + 1024 * 7, (2 << 16) + 999, 100, 0, 10240, 1 << 20, 65, (1 << 20) + 65536 + 3,
+                 (7 << 16) - 1, 4 << 20] + [int(x) for x in rng.integers(1, 30000, 150)] + [(9 << 16) + 512]
+        rows = [gen.incompressible(300 + i, n) for i, n in enumerate(sizes)]
+        GAP = 32
+        out_off, pos = [], 0
+        for n in sizes:
+            pos = (pos + 15) // 16 * 16
+            out_off.append(pos)
+            pos += n + GAP
+        total = pos + 64
+        blobs = np.frombuffer(b"".join(rows) + bytes(64), dtype=np.uint8)
+        bs = np.array(sizes, dtype=np.uint64)
+        bo = np.concatenate([[0], np.cumsum(bs)[:-1]]).astype(np.uint64)
+        ck = np.stack([np.frombuffer(oracle.blake3(d), dtype=np.uint8) for d in rows])
+        d_blobs = torch.from_numpy(blobs.copy()).cuda()
+        bitmap = np.zeros((len(sizes) + 7) // 8, np.uint8)   # nothing compressed
+        rt = hip.RowTable(ctx, bo, bs, bs, np.array(out_off, dtype=np.uint64), bitmap, ck)
+        want = np.full(total, 0xA5, np.uint8)
+        for o, d in zip(out_off, rows):
+            want[o:o + len(d)] = np.frombuffer(d, dtype=np.uint8)
+        for _ in range(2):
+            d_out = torch.full((total,), 0xA5, dtype=torch.uint8, device="cuda")
+            counters, corrupt, status = rt.decode_verify(d_blobs, d_out)
+            assert (status == 0).all() and len(corrupt) == 0 and counters["verified_bytes"] == sum(sizes)
+            assert np.array_equal(d_out.cpu().numpy(), want)
+        rt.close()
+        # the write side's hash + copy (rounds marked skip: stored as they are) runs the same kernel
+        rounds = hip.RoundTable(ctx, [int(x) for x in bo], sizes, skip=np.ones(len(sizes), np.uint8))
+        d_blob_out = torch.full((rounds.blob_bound() + 64,), 0x5A, dtype=torch.uint8, device="cuda")
+        res = rounds.encode_hash(d_blobs, d_blob_out)
+        blob = d_blob_out.cpu().numpy()
+        for i, d in enumerate(rows):
+            assert res["checksum"][i].tobytes() == oracle.blake3(d), i
+            o, n = int(res["blob_offset"][i]), int(res["blob_size"][i])
+            assert n == len(d) and blob[o:o + n].tobytes() == d, i
+        assert (blob[res["blob_bytes"]:] == 0x5A).all()
+        rounds.close()
+    finally:
+        ctx.close()
+
+
 @pytest.mark.parametrize("seed", [1, 2, 3])
 def test_random_archives_every_path_every_time(gpu_ctx, gpu_ctx_roles, oracle, seed):
     """Randomised archives — whole-leaf and ragged rows, text / binary / word-soup / incompressible / empty, stored and

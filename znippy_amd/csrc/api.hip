@@ -115,6 +115,7 @@ struct znippy_ctx {
     struct {
         int dbg = 0;             // ZNIPPY_DBG bit set (FusedArgs::dbg)
         unsigned lds_pad = 0;    // ZNIPPY_LDS_PAD
+        int store_g = 0;         // ZNIPPY_STORE_G: tiles per wave of the store path kernel (0 = from the tile count)
         bool no_block_items = false, no_fused_blocks = false, ddbg = false, edbg = false, no_fused_store = false,
              nohash = false, no_roles = false, no_fz = false, fz_only = false, no_bx = false, tdbg = false, no_fuse_hash = false, trace = false, no_rx = false, no_pack = false, no_lean = false;
         // ZNIPPY_ROLES_MIN: small tiles from which the role-split persistent kernel takes the table (0 = never; below
@@ -149,6 +150,7 @@ static void read_switches(znippy_ctx *ctx) {
     ctx->sw.trace = on("ZNIPPY_TRACE");
     ctx->sw.no_lean = on("ZNIPPY_NO_LEAN");  // A/B: every run launches the kernels behind the role-split one
     ctx->sw.no_pack = on("ZNIPPY_NO_PACK");  // A/B: the index columns always as four 64-bit copies
+    if (const char *e = getenv("ZNIPPY_STORE_G")) ctx->sw.store_g = atoi(e) == 1 ? 1 : (atoi(e) == 2 ? 2 : 0);  // A/B, tests: tiles per wave of the store path kernel
     ctx->sw.no_rx = on("ZNIPPY_NO_RX");  // A/B: big foreign frames executed by a wave each (round 3's first form)
     ctx->sw.no_fuse_hash = on("ZNIPPY_NO_FUSE_HASH");  // A/B: the write side's hash as a kernel of its own beside the encoder (round 2)
     ctx->sw.no_bx = on("ZNIPPY_NO_BX");
@@ -1386,6 +1388,7 @@ int znippy_decode_verify_rows_async(znippy_ctx *ctx, znippy_rows *r, const void 
     h.srcB = (uint8_t *)d_out; h.offB = r->out_off;
     h.sel = r->compressed; h.status = r->status; h.pending_count = r->pending_count;
     h.copy_to_B = 1;
+    h.store_tiles = ctx->sw.store_g;
     h.misaligned_dst = r->odd_out || ((uintptr_t)d_out & 15) != 0;
     h.digests = r->digests; h.tile_cv = r->plan.tile_cv;
     if (!small_off) {
@@ -1999,6 +2002,7 @@ static int hash_rounds_async(znippy_ctx *ctx, znippy_rounds *r, const void *d_sr
     h.digests = r->digests; h.tile_cv = r->plan.tile_cv;
     if (d_copy_out) {
         h.srcB = (uint8_t *)d_copy_out; h.offB = r->blob_offset; h.copy_to_B = 1;
+        h.store_tiles = ctx->sw.store_g;
         h.copy_mask = r->skip; h.copy_cap = copy_cap;
         h.misaligned_dst = !(r->all_stored_aligned && ((uintptr_t)d_copy_out & 15) == 0);
     }

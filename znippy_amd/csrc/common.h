@@ -49,6 +49,7 @@ struct HashArgs {
     int copy_to_B;
     uint32_t *digests;  // 8 words per unit
     uint32_t *tile_cv;  // 8 words per big-unit tile
+    int store_tiles;     // store path (copy_to_B): 0 = tiles per wave picked from the tile count; 1 / 2 = forced (ZNIPPY_STORE_G, A/B and tests)
     int fold_tiles_max;  // 0 = pick from the tile count; 1 = no deferred folding (no LDS: the launch shares the CUs with the encoder)
     const uint8_t *tile_done;  // optional, PASS_SECOND: tiles already hashed by the fused block kernel
     // optional (write side, store-heavy tables): copy only units with copy_mask != 0, and only if they end inside copy_cap

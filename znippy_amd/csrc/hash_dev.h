@@ -13,12 +13,17 @@ typedef uint32_t u4v __attribute__((ext_vector_type(4)));
 typedef u4v __attribute__((aligned(1))) u4v_unaligned;
 typedef __attribute__((address_space(3))) u4v_unaligned lds_u4;
 
+// 16 bytes at any byte address of device memory.  The pointers that reach these two have often been through an integer
+// (a 64-bit address handed from lane to lane as two dwords), which leaves the compiler with a generic pointer and FLAT
+// instructions: those count on lgkmcnt as well as vmcnt, so every LDS read behind them waits for all of the wave's
+// outstanding loads AND stores.  Address space 1 says what they are: global_load / global_store_dwordx4.
+typedef __attribute__((address_space(1))) u4v_unaligned glb_u4;
+typedef __attribute__((address_space(1))) uint8_t glb_u8;
 __device__ __forceinline__ uint4 ld16(const uint8_t *p) {
-    uint4 v;
-    __builtin_memcpy(&v, p, 16);  // unaligned-access-mode: one global_load_dwordx4
-    return v;
+    const u4v v = *(const glb_u4 *)(uintptr_t)p;  // unaligned-access-mode: one global_load_dwordx4
+    return make_uint4(v.x, v.y, v.z, v.w);
 }
-__device__ __forceinline__ void st16(uint8_t *p, uint4 v) { __builtin_memcpy(p, &v, 16); }
+__device__ __forceinline__ void st16(uint8_t *p, uint4 v) { *(glb_u4 *)(uintptr_t)p = u4v{v.x, v.y, v.z, v.w}; }
 
 // Load one (possibly partial) 64-byte block into 16 little-endian words, zero padded.
 __device__ __forceinline__ void load_block(const uint8_t *p, uint32_t n, uint32_t m[16]) {
@@ -29,13 +34,14 @@ __device__ __forceinline__ void load_block(const uint8_t *p, uint32_t n, uint32_
         m[8] = c.x; m[9] = c.y; m[10] = c.z; m[11] = c.w;
         m[12] = d.x; m[13] = d.y; m[14] = d.z; m[15] = d.w;
     } else {
+        const glb_u8 *const g = (const glb_u8 *)(uintptr_t)p;
 #pragma unroll
         for (int i = 0; i < 16; i++) {
             uint32_t w = 0;
 #pragma unroll
             for (int k = 0; k < 4; k++) {
                 uint32_t idx = 4 * i + k;
-                if (idx < n) w |= (uint32_t)p[idx] << (8 * k);
+                if (idx < n) w |= (uint32_t)g[idx] << (8 * k);
             }
             m[i] = w;
         }
@@ -49,7 +55,8 @@ __device__ __forceinline__ void store_block(uint8_t *p, uint32_t n, const uint32
         st16(p + 32, make_uint4(m[8], m[9], m[10], m[11]));
         st16(p + 48, make_uint4(m[12], m[13], m[14], m[15]));
     } else {
-        for (uint32_t i = 0; i < n; i++) p[i] = (uint8_t)(m[i >> 2] >> (8 * (i & 3)));
+        glb_u8 *const g = (glb_u8 *)(uintptr_t)p;
+        for (uint32_t i = 0; i < n; i++) g[i] = (uint8_t)(m[i >> 2] >> (8 * (i & 3)));
     }
 }
 
@@ -133,6 +140,11 @@ typedef __attribute__((address_space(3))) u4v lds_u4a;  // 16-byte aligned LDS v
 
 constexpr uint32_t STAGE_FULL_SLOT = 144;  // 128 + 16: whole cache lines per leaf (big-slice tiles of the store path)
 constexpr uint32_t STAGE_FULL_BYTES = 64 * STAGE_FULL_SLOT;
+// The store path kernel's own stage (k_hash_tiles<COPY>): 128-byte slots with no padding — 8 KiB per wave, five blocks of
+// four waves per CU instead of four.  Piece p of slot l sits at piece p ^ ((l >> 1) & 7): 16 consecutive lanes reading the
+// same piece of their own slots then touch 16 different 16-byte columns x {low, high} half of the 64 banks, and the eight
+// lanes that write one slot's eight pieces still write its 128 contiguous bytes.
+constexpr uint32_t STAGE_SWZ_BYTES = 64 * 128;
 
 // `raw_src` (big-slice tiles, fused block kernel): the tile's bytes are copied from raw_src + leaf offset instead of
 // the unit's own source column (a raw block of a compressed frame: blob -> output while hashing).
@@ -409,38 +421,52 @@ __device__ __forceinline__ void hash_tile_leaves(const HashArgs &a, const Tile &
                 bool actj[8];
 #pragma unroll
                 for (int j = 0; j < 8; j++) actj[j] = (act >> (8 * j + (lane >> 3))) & 1;
-                lds_u4a *const r0 = (lds_u4a *)(stage + (lane >> 3) * STAGE_FULL_SLOT + 16 * (lane & 7));
-                const lds_u4a *const ws = (const lds_u4a *)(stage + lane * STAGE_FULL_SLOT);
-                uint4 v[8], vn[8];
+                // the stage: 128-byte slots, piece p of slot l at piece p ^ ((l >> 1) & 7) (STAGE_SWZ_BYTES).  Loading lane
+                // (lane >> 3, lane & 7) fills slot lane >> 3 (+ 8j), whose key is (lane >> 4) + 4 * (j & 1).
+                uint8_t *const rz0 = stage + (lane >> 3) * 128 + 16 * ((lane & 7) ^ (lane >> 4));
+                uint8_t *const rz1 = stage + (lane >> 3) * 128 + 16 * ((lane & 7) ^ ((lane >> 4) + 4));
+                const uint8_t *const wz = stage + lane * 128;
+                const uint32_t wkey = 16 * ((lane >> 1) & 7);
+                // FULL: all 64 leaves of the tile are there (every tile of a big unit but its last) — no lane-dependent
+                // branch in the loop, so its waits are counted ones (with the per-group branches of the ragged form every
+                // memory instruction sits behind an s_waitcnt vmcnt(0)).
+                // Order of a step, measured (C4 store / C5, same box): stores of this pair, loads of the next over the same
+                // registers, two compressions — 3 % / 5 % faster than loads before stores, with or without a second set of
+                // registers; five waves per SIMD instead of four change nothing.
+                auto pairs = [&](auto full_tile) {
+                    constexpr bool FULL = decltype(full_tile)::value;
+                    uint4 v[8];
 #pragma unroll
-                for (int j = 0; j < 8; j++) { v[j] = make_uint4(0, 0, 0, 0); vn[j] = v[j]; if (actj[j]) v[j] = ld16(s0 + j * 8192); }
+                    for (int j = 0; j < 8; j++) { v[j] = make_uint4(0, 0, 0, 0); if (FULL || actj[j]) v[j] = ld16(s0 + j * 8192); }
 #pragma unroll 1
-                for (uint32_t bb = 0; bb < 8; bb++) {
-#pragma unroll
-                    for (int j = 0; j < 8; j++)
-                        if (actj[j]) r0[j * (8 * STAGE_FULL_SLOT / 16)] = u4v{v[j].x, v[j].y, v[j].z, v[j].w};
-                    if (bb < 7) {
+                    for (uint32_t bb = 0; bb < 8; bb++) {
 #pragma unroll
                         for (int j = 0; j < 8; j++)
-                            if (actj[j]) vn[j] = ld16(s0 + j * 8192 + (bb + 1) * 128);
-                    }
+                            if (FULL || actj[j]) *(lds_u4a *)(((j & 1) ? rz1 : rz0) + j * 1024) = u4v{v[j].x, v[j].y, v[j].z, v[j].w};
 #pragma unroll
-                    for (int j = 0; j < 8; j++)
-                        if (actj[j]) st16(d0 + j * 8192 + bb * 128, v[j]);
+                        for (int j = 0; j < 8; j++)
+                            if (FULL || actj[j]) st16(d0 + j * 8192 + bb * 128, v[j]);
+                        if (bb < 7) {
 #pragma unroll
-                    for (int h = 0; h < 2; h++) {
-                        if (active) {
-                            const u4v a0 = ws[4 * h], a1 = ws[4 * h + 1], a2 = ws[4 * h + 2], a3 = ws[4 * h + 3];
-                            uint32_t m[16] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w, a2.x, a2.y, a2.z, a2.w, a3.x, a3.y, a3.z, a3.w};
-                            const uint32_t b = 2 * bb + h;
-                            const uint32_t flags = (b == 0 ? b3::CHUNK_START : 0u) |
-                                                   (b == 15 ? (b3::CHUNK_END | (single ? b3::ROOT : 0u)) : 0u);
-                            b3::compress(cv, m, k, 0, 64, flags);
+                            for (int j = 0; j < 8; j++)
+                                if (FULL || actj[j]) v[j] = ld16(s0 + j * 8192 + (bb + 1) * 128);
+                        }
+#pragma unroll
+                        for (int h = 0; h < 2; h++) {
+                            if (FULL || active) {
+                                const u4v a0 = *(const lds_u4a *)(wz + ((64 * h) ^ wkey)), a1 = *(const lds_u4a *)(wz + ((64 * h + 16) ^ wkey)),
+                                          a2 = *(const lds_u4a *)(wz + ((64 * h + 32) ^ wkey)), a3 = *(const lds_u4a *)(wz + ((64 * h + 48) ^ wkey));
+                                uint32_t m[16] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w, a2.x, a2.y, a2.z, a2.w, a3.x, a3.y, a3.z, a3.w};
+                                const uint32_t b = 2 * bb + h;
+                                const uint32_t flags = (b == 0 ? b3::CHUNK_START : 0u) |
+                                                       (b == 15 ? (b3::CHUNK_END | (single ? b3::ROOT : 0u)) : 0u);
+                                b3::compress(cv, m, k, 0, 64, flags);
+                            }
                         }
                     }
-#pragma unroll
-                    for (int j = 0; j < 8; j++) v[j] = vn[j];
-                }
+                };
+                if (act == ~0ull) pairs(std::true_type{});
+                else pairs(std::false_type{});
             } else if (COPY && stage && !LDSRC && ZN_STAGE_LOADS) {
                 // both directions through the stage: lane l moves piece l%4 of leaves 16j + l/4 (j = 0..3), so a load
                 // or a store instruction covers 16 leaves x 64 contiguous bytes.  A block's registers are written to
@@ -615,6 +641,11 @@ struct FoldQueue {
             d[0] = make_uint4(lo.cv[0], lo.cv[1], lo.cv[2], lo.cv[3]);
             d[1] = make_uint4(lo.cv[4], lo.cv[5], lo.cv[6], lo.cv[7]);
         }
+        add_entry(g, t, lo);
+    }
+    // the table entries alone: the caller puts the tile's leaf CVs at nodes[g * 64 + lane] itself, before the fold
+    __device__ __forceinline__ void add_entry(uint32_t g, const Tile &t, const LeafOut &lo) {
+        const uint32_t lane = threadIdx.x & 63;
         const uint32_t units = t.n_units ? t.n_units : 1u;
         // descriptor of tile-local unit i on lane i, then moved to table lanes [n_tab, n_tab + units)
         const uint32_t act = __shfl(lo.active ? 1u : 0u, lo.u_head & 63);

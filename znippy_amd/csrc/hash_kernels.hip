@@ -14,9 +14,15 @@ namespace zn {
 // SHIFT (store path only): the variant that can re-cut the bytes for destinations that are not 16-byte aligned; it
 // needs more registers and LDS than the plain one, so it is launched only when the host knows of such a destination.
 template <bool COPY, int FOLD_G, bool SHIFT = false>
-__global__ __launch_bounds__(256, SHIFT ? 4 : 1) void k_hash_tiles(HashArgs a) {  // SHIFT: 40 KB of stage per block, held at 128 registers
-    __shared__ __attribute__((aligned(16))) uint32_t s_nodes[FOLD_G > 1 ? 4 : 1][FOLD_G > 1 ? FOLD_G * 64 * 8 : 4];
-    __shared__ __attribute__((aligned(16))) uint8_t s_stage[COPY ? 4 : 1][COPY ? (SHIFT ? STAGE_SHIFT_BYTES : STAGE_FULL_BYTES) : 16];
+__global__ __launch_bounds__(256, COPY ? (FOLD_G == 1 && !SHIFT ? 5 : 4) : 1) void k_hash_tiles(HashArgs a) {  // store path: registers follow the LDS (32 / 40 KB per block)
+    // Store path: a wave's LDS is [FOLD_G - 1 tiles of nodes][stage].  The stage is in use while a tile's leaves are hashed,
+    // so the leaf CVs of the wave's earlier tiles wait in front of it; the last tile's go to the head of the stage (free by
+    // then) and the node array the fold works on is one piece.
+    constexpr uint32_t KEEP_BYTES = COPY ? (FOLD_G - 1) * 64 * 32 : 0;
+    constexpr uint32_t AREA = COPY ? KEEP_BYTES + (SHIFT ? STAGE_SHIFT_BYTES : STAGE_SWZ_BYTES) : 16;
+    static_assert(!COPY || FOLD_G * 64 * 32 <= (int)AREA, "the area must hold the queued tiles' nodes");
+    __shared__ __attribute__((aligned(16))) uint32_t s_nodes[FOLD_G > 1 && !COPY ? 4 : 1][FOLD_G > 1 && !COPY ? FOLD_G * 64 * 8 : 4];
+    __shared__ __attribute__((aligned(16))) uint8_t s_area[COPY ? 4 : 1][AREA];
     const uint32_t w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const uint32_t first = (blockIdx.x * 4 + w) * FOLD_G;
     if (first >= a.n_tiles) return;
@@ -28,7 +34,8 @@ __global__ __launch_bounds__(256, SHIFT ? 4 : 1) void k_hash_tiles(HashArgs a) {
         if (!any_big) return;
     }
     FoldQueue<FOLD_G> fq;
-    uint32_t *nodes = s_nodes[FOLD_G > 1 ? w : 0];
+    uint32_t *nodes = COPY ? reinterpret_cast<uint32_t *>(s_area[w]) : s_nodes[FOLD_G > 1 ? w : 0];
+    uint8_t *const stage = COPY ? s_area[w] + KEEP_BYTES : nullptr;
     for (uint32_t g = 0; g < FOLD_G && first + g < a.n_tiles; g++) {
         const Tile t = a.tiles[first + g];
         if (a.pass == PASS_SECOND && a.tile_done && a.tile_done[first + g]) continue;  // hashed by the fused block kernel
@@ -39,21 +46,27 @@ __global__ __launch_bounds__(256, SHIFT ? 4 : 1) void k_hash_tiles(HashArgs a) {
             if (__ballot(mine) == 0ull) continue;
         }
         LeafOut lo;
-        hash_tile_leaves<COPY, false, COPY, SHIFT>(a, t, nullptr, lo, COPY ? s_stage[w] : nullptr);
+        hash_tile_leaves<COPY, false, COPY, SHIFT>(a, t, nullptr, lo, stage);
         if (FOLD_G > 1 && FoldQueue<FOLD_G>::fits(t)) fq.add(nodes, g, t, lo);
         else fold_tile_now(a, t, lo);
     }
-    if (FOLD_G > 1) fq.fold_and_write(nodes, a);
+    if (FOLD_G > 1) {
+        uint32_t U = 0;
+        const uint32_t n = COPY ? fq.uniform(&U) : 0u;
+        if (n) fq.fold_uniform_and_write(nodes, a, n, U);  // whole slices of big units: every queued tile has 64 leaves
+        else fq.fold_and_write(nodes, a);
+    }
 }
 
 template <int G>
 static void launch_hash_tiles_g(const HashArgs &a, hipStream_t s) {
     const uint32_t waves = (a.n_tiles + G - 1) / G;
     dim3 grid((waves + 3) / 4), block(256);
-    if constexpr (G == 1) {  // the store path runs one tile per wave: its stage leaves no LDS for a node array
+    if constexpr (G <= 2) {
         if (a.copy_to_B) {
-            if (a.misaligned_dst) hipLaunchKernelGGL((k_hash_tiles<true, 1, true>), grid, block, 0, s, a);
-            else hipLaunchKernelGGL((k_hash_tiles<true, 1, false>), grid, block, 0, s, a);
+            // (a destination that is not 16-byte aligned: the re-cutting stage is 10 KiB — one tile per wave)
+            if (a.misaligned_dst) hipLaunchKernelGGL((k_hash_tiles<true, 1, true>), dim3((a.n_tiles + 3) / 4), block, 0, s, a);
+            else hipLaunchKernelGGL((k_hash_tiles<true, G, false>), grid, block, 0, s, a);
             return;
         }
     }
@@ -69,8 +82,17 @@ void launch_hash_tiles(const HashArgs &a, hipStream_t s) {
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
     }
     const uint64_t resident = (uint64_t)cus * 20;  // 5 waves per SIMD at this kernel's register count
-    // store path: the copy stage takes 9 KiB of LDS per wave (whole lines for big-slice tiles): no node array beside it
-    const int cap = a.fold_tiles_max > 0 ? a.fold_tiles_max : (a.copy_to_B ? 1 : 4);
+    const int cap = a.fold_tiles_max > 0 ? a.fold_tiles_max : 4;
+    if (a.copy_to_B) {
+        // store path: 16-20 waves per CU (the stage), and a tile's six parent levels are 6 of its 22 compress passes: two
+        // tiles per wave (19 passes each) as soon as that still gives every wave slot a wave.  (Four would need 14 KiB of LDS
+        // per wave, or the waiting CVs in registers: measured, the spills cost more than the passes saved.)
+        const uint64_t slots = (uint64_t)cus * 16;
+        const int force = a.store_tiles;
+        if (force == 2 || (force == 0 && cap >= 2 && a.n_tiles >= 2 * slots - slots / 8)) launch_hash_tiles_g<2>(a, s);
+        else launch_hash_tiles_g<1>(a, s);
+        return;
+    }
     if (cap >= 4 && a.n_tiles >= 6 * resident) launch_hash_tiles_g<4>(a, s);
     else if (cap >= 2 && a.n_tiles >= 3 * resident) launch_hash_tiles_g<2>(a, s);
     else launch_hash_tiles_g<1>(a, s);
