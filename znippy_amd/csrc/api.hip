@@ -2220,6 +2220,12 @@ extern "C" int znippy_encode_hash_rounds_async(znippy_ctx *ctx, znippy_rounds *r
     g.stored = r->store_incompressible ? r->stored : nullptr;
     g.skip_stored_copy = fuse_store ? 1 : 0;
     g.small_pieces = r->n_items && r->in_bytes / r->n_items <= 16384 ? 1 : 0;  // (tables of small rounds: their pieces are at most that, mostly far less)
+    // store-heavy table: the stored rounds' 64 KiB slices are not copied here (the hash kernel does it) — only their
+    // bookkeeping is left, a lane's work; what decides is the size of the pieces that ARE copied
+    if (fuse_store) {
+        const uint64_t n_enc = (uint64_t)r->n_small + r->n_wide;
+        g.small_pieces = !n_enc || r->enc_bytes / n_enc <= 16384 ? 1 : 0;
+    }
     ktime_begin(ctx, "gather");
     launch_gather(g, s);
     ktime_end(ctx);
