@@ -313,11 +313,14 @@ struct DevPlan {
     uint32_t *grp_big = nullptr, *grp_k = nullptr;
     uint32_t n_grp = 0;
     uint32_t n_tiles = 0, n_big = 0;
+    uint32_t max_cvs = 0;  // tile CVs of the biggest unit (picks the merge launch)
 };
 
 static int upload_plan(znippy_ctx *ctx, const PlanBuf &p, DevPlan &d) {
     d.n_tiles = (uint32_t)p.tiles.size();
     d.n_big = (uint32_t)p.big.size();
+    d.max_cvs = 0;
+    for (const BigUnit &b : p.big) d.max_cvs = std::max(d.max_cvs, b.n_cvs);
     if (d.n_tiles) {
         HIPCHK(ctx, tmalloc(ctx, &d.tiles, sizeof(Tile) * d.n_tiles));
         HIPCHK(ctx, hipMemcpy(d.tiles, p.tiles.data(), sizeof(Tile) * d.n_tiles, hipMemcpyHostToDevice));
@@ -1758,7 +1761,7 @@ int znippy_decode_verify_rows_async(znippy_ctx *ctx, znippy_rows *r, const void 
     ktime_end(ctx);
     if (r->plan.n_big) {
         ktime_begin(ctx, "blake3_merge_big");
-        launch_merge_big(r->plan.big, r->plan.n_big, r->plan.tile_cv, r->digests, r->plan.grp_big, r->plan.grp_k, r->plan.n_grp, s);
+        launch_merge_big(r->plan.big, r->plan.n_big, r->plan.tile_cv, r->digests, r->plan.grp_big, r->plan.grp_k, r->plan.n_grp, r->plan.max_cvs, s);
         ktime_end(ctx);
     }
     }  // !lean
@@ -2013,7 +2016,7 @@ static int hash_rounds_async(znippy_ctx *ctx, znippy_rounds *r, const void *d_sr
     ktime_end(ctx, s);
     if (r->plan.n_big) {
         ktime_begin(ctx, "blake3_merge_big", s);
-        launch_merge_big(r->plan.big, r->plan.n_big, r->plan.tile_cv, r->digests, r->plan.grp_big, r->plan.grp_k, r->plan.n_grp, s);
+        launch_merge_big(r->plan.big, r->plan.n_big, r->plan.tile_cv, r->digests, r->plan.grp_big, r->plan.grp_k, r->plan.n_grp, r->plan.max_cvs, s);
         ktime_end(ctx, s);
     }
     HIPCHK(ctx, hipGetLastError());

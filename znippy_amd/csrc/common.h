@@ -131,7 +131,7 @@ void launch_fused_small(const FusedArgs &a, hipStream_t s, int grid_cap = 0);
 void launch_fused_roles(const FusedArgs &a, int cus, hipStream_t s);
 void init_fused_tables();
 void launch_merge_big(const BigUnit *big, uint32_t n_big, uint32_t *tile_cv, uint32_t *digests, const uint32_t *grp_big,
-                      const uint32_t *grp_k, uint32_t n_grp, hipStream_t s);
+                      const uint32_t *grp_k, uint32_t n_grp, uint32_t max_cvs, hipStream_t s);
 void launch_verify(const uint32_t *digests, const uint8_t *checksum, const uint64_t *usize,
                    const int32_t *status, uint32_t n_rows, uint64_t row_begin, uint64_t *counters,
                    uint64_t *corrupt_rows, uint32_t corrupt_cap, hipStream_t s, const uint32_t *lean_lists = nullptr, uint32_t lean_mask = 0);
