@@ -553,15 +553,21 @@ __global__ __launch_bounds__(128, 4) void k_fz_entropy(FzArgs a, const uint32_t 
 
 // One frame, executed by one wave: the blocks' records and literals come from the pools, W is the wave's LDS window.
 constexpr uint32_t BX_SMALL_HIST = 2048, BX_SMALL_CAP = 4096;  // the small window (k_bx_exec)
-constexpr int BX_SMALL_WAVES = 5;                                // ... and the waves per SIMD its kernel is compiled for
+#ifndef ZN_BXW
+#define ZN_BXW 5
+#endif
+constexpr int BX_SMALL_WAVES = ZN_BXW;                                // ... and the waves per SIMD its kernel is compiled for
 template <bool PROF, uint32_t WH = WIN_HIST, uint32_t WC = WIN_CAP, uint32_t WSM = WIN_SEQ_MAX>
 __device__ __forceinline__ bool fz_exec_frame(const FzArgs &a, const uint32_t c, uint8_t *const W, const uint32_t lane) {  // true: the frame is decoded
-    const uint32_t nb = a.cand_nb[c];
+    // (one frame per wave: everything about the frame is wave-uniform, and said to be — values loaded through vector
+    // loads otherwise live in vector registers, and the small-window form, held at 102 of them, spilled these pointers
+    // and reloaded them inside its copy loops)
+    const uint32_t nb = uni(a.cand_nb[c]);
     if (!nb) return false;
-    const uint32_t row = a.cand_row[c], base = a.cand_fzbase[c];
-    const uint8_t *const src = a.blobs + (a.blob_off[row] - a.blob_base);
-    uint8_t *const out = a.out + a.out_off[row];
-    const uint64_t fcs = a.usize[row];
+    const uint32_t row = uni(a.cand_row[c]), base = uni(a.cand_fzbase[c]);
+    const uint8_t *const src = a.blobs + (uni64(a.blob_off[row]) - a.blob_base);
+    uint8_t *const out = a.out + uni64(a.out_off[row]);
+    const uint64_t fcs = uni64(a.usize[row]);
     {   // every block came through the entropy phase and the sizes add up to the frame's content size
         unsigned long long tot = 0, seqs = 0;
         uint32_t bad = 0;
