@@ -52,28 +52,27 @@ def test_rounds_mixed_sizes_unaligned(gpu_ctx, oracle):
 
 
 def test_rounds_around_the_one_launch_merge_limit(gpu_ctx, oracle):
-    """Units of more than 64 tile CVs (rounds above 4 MiB): up to 64 groups of 64 (256 MiB) the groups and the unit's top
+    """Units of more than 64 tile CVs (rounds above 4 MiB): up to 4 groups of 64 (16 MiB) the groups and the unit's top
     are folded by one launch (k_merge_units: a workgroup per unit, a wave per group); a table holding a bigger round takes
-    the two launches (k_merge_groups, k_merge_big).  Sizes with a ragged last group, a last group of one CV, exactly 64
-    groups, and one round beyond the limit in a table of its own — every digest equal to the oracle's."""
+    the two launches (k_merge_groups, k_merge_big).  Sizes with a ragged last group, a last group of one CV, exactly 4
+    groups, and tables with a round beyond the limit — every digest equal to the oracle's."""
     import torch
     import gen_gpu
     from znippy_amd import hip
-    sizes = [(4 << 20) + 1, (4 << 20) + 65536 + 7, 40 << 20, (64 << 20) - 5, 256 << 20, 3, (12 << 20) + 64 * 1024 * 64 + 1]
-    offs = np.concatenate([[0], np.cumsum(sizes)[:-1]]).astype(np.uint64)
-    d = gen_gpu.incompressible(4242, int(sum(sizes)) + 16)
+    d = gen_gpu.incompressible(4242, (300 << 20) + 16)
     h = d.cpu().numpy()
-    rt = hip.RoundTable(gpu_ctx, offs, sizes)
-    got = rt.hash(d)
-    names = dict(gpu_ctx.kernel_times())
-    for i, (o, n) in enumerate(zip(offs, sizes)):
-        assert got[i].tobytes() == oracle.blake3(h[int(o):int(o) + n]), (i, n)
-    rt.close()
-    big = (256 << 20) + (4 << 20) + 1000        # 65 groups and a bit: beyond the one-launch form
-    rt = hip.RoundTable(gpu_ctx, [5, 5 + big], [big, 10 << 20])
-    got = rt.hash(d)
-    assert got[0].tobytes() == oracle.blake3(h[5:5 + big]) and got[1].tobytes() == oracle.blake3(h[5 + big:5 + big + (10 << 20)])
-    rt.close()
+
+    def check(sizes, first=0):
+        offs = (first + np.concatenate([[0], np.cumsum(sizes)[:-1]])).astype(np.uint64)
+        rt = hip.RoundTable(gpu_ctx, offs, sizes)
+        got = rt.hash(d)
+        for i, (o, n) in enumerate(zip(offs, sizes)):
+            assert got[i].tobytes() == oracle.blake3(h[int(o):int(o) + n]), (i, n)
+        rt.close()
+
+    check([(4 << 20) + 1, (4 << 20) + 65536 + 7, 8 << 20, (12 << 20) - 5, 16 << 20, 3, (12 << 20) + 65536 + 1, 70000])   # one launch
+    check([(16 << 20) + 1, 8 << 20, 100], first=3)                      # five groups: the two launches
+    check([(256 << 20) + (4 << 20) + 1000, 10 << 20], first=5)          # 65 groups and a bit
 
 
 def test_100k_small_chunks_checksum_of_checksums(gpu_ctx, oracle):

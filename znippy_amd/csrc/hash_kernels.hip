@@ -170,18 +170,19 @@ __global__ __launch_bounds__(64) void k_merge_big(const BigUnit *big, uint32_t n
     }
 }
 
-// Both steps in one launch for tables whose biggest unit has at most 64 groups (rows up to 256 MiB): a workgroup of 16
-// waves per unit, a wave per group (round robin), the group nodes through LDS, wave 0 finishes.  One dependent launch
-// less behind the hash kernel (~8 us of every run of a table of multi-MiB rows).
-constexpr uint32_t MERGE_UNIT_MAX_CVS = 64 * 64;
-__global__ __launch_bounds__(1024) void k_merge_units(const BigUnit *big, uint32_t n_big, const uint32_t *tile_cv, uint32_t *digests) {
-    __shared__ __attribute__((aligned(16))) uint32_t s_grp[64 * 8];
+// Both steps in one launch for tables whose biggest unit has at most 4 groups (rows up to 16 MiB: the reference's 8 MiB
+// file slices): a workgroup of 4 waves per unit — one per SIMD, a wave per group — the group nodes through LDS, wave 0
+// finishes.  One dependent launch less behind the hash kernel.  (Not for bigger units: a workgroup lives on one CU, and
+// 16 waves folding 50 groups of a 200 MiB row there took 0.19 ms where the two launches, a workgroup per group, take 0.03.)
+constexpr uint32_t MERGE_UNIT_WAVES = 4, MERGE_UNIT_MAX_CVS = 64 * MERGE_UNIT_WAVES;
+__global__ __launch_bounds__(64 * MERGE_UNIT_WAVES) void k_merge_units(const BigUnit *big, uint32_t n_big, const uint32_t *tile_cv, uint32_t *digests) {
+    __shared__ __attribute__((aligned(16))) uint32_t s_grp[MERGE_UNIT_WAVES * 8];
     const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const BigUnit u = big[blockIdx.x < n_big ? blockIdx.x : 0];
     const bool grouped = u.n_cvs > 64;
     const uint32_t n_grp = (u.n_cvs + 63) / 64;
     if (grouped) {
-        for (uint32_t g = w; g < n_grp; g += 16) {  // (wave-uniform)
+        for (uint32_t g = w; g < n_grp; g += MERGE_UNIT_WAVES) {  // (wave-uniform; at most one round)
             const uint32_t cnt = u.n_cvs - 64 * g < 64 ? u.n_cvs - 64 * g : 64;
             const uint32_t *base = tile_cv + ((size_t)u.cv_base + 64 * g) * 8;
             uint32_t cv[8];
@@ -217,7 +218,7 @@ void launch_merge_big(const BigUnit *big, uint32_t n_big, uint32_t *tile_cv, uin
                       const uint32_t *grp_k, uint32_t n_grp, uint32_t max_cvs, hipStream_t s) {
     if (!n_big) return;
     if (n_grp && max_cvs <= MERGE_UNIT_MAX_CVS) {
-        hipLaunchKernelGGL(k_merge_units, dim3(n_big), dim3(1024), 0, s, big, n_big, tile_cv, digests);
+        hipLaunchKernelGGL(k_merge_units, dim3(n_big), dim3(64 * MERGE_UNIT_WAVES), 0, s, big, n_big, tile_cv, digests);
         return;
     }
     if (n_grp) hipLaunchKernelGGL(k_merge_groups, dim3(n_grp), dim3(64), 0, s, big, grp_big, grp_k, n_grp, tile_cv);
