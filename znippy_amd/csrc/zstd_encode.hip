@@ -1783,13 +1783,40 @@ __global__ __launch_bounds__(256) void k_gather(GatherArgs g) {
         }
         for (; o < len; o++) d[o] = s[o];
     }
+    // (wave-uniform) the longer pieces, the whole wave on each — four at a time: the first KiB of each of the four is
+    // loaded (16 bytes per lane) before any of it is stored, so a step's round trips overlap (one piece per step, load
+    // then store: 64 pieces of 1-2 KB, a table of small real-text rounds, were 64 dependent round trips per wave);
+    // what a piece has beyond its first KiB follows piece by piece
     uint64_t bigm = __ballot(copy && len > GATHER_SMALL);
-    while (bigm) {  // (wave-uniform) the long pieces, the whole wave on each
-        const uint32_t j = (uint32_t)__ffsll((long long)bigm) - 1;
-        bigm &= bigm - 1;
-        const uint64_t sj = ((uint64_t)rdlane((uint32_t)((uint64_t)(uintptr_t)s >> 32), j) << 32) | rdlane((uint32_t)(uintptr_t)s, j);
-        const uint64_t dj = ((uint64_t)rdlane((uint32_t)((uint64_t)(uintptr_t)d >> 32), j) << 32) | rdlane((uint32_t)(uintptr_t)d, j);
-        wave_copy(reinterpret_cast<uint8_t *>((uintptr_t)dj), reinterpret_cast<const uint8_t *>((uintptr_t)sj), rdlane(len, j), lane);
+    while (bigm) {
+        uint32_t jj[4], nn[4];
+        uint64_t sj[4], dj[4];
+        uint4 v[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            nn[q] = 0; sj[q] = 0; dj[q] = 0; jj[q] = 0;
+            if (bigm) {
+                jj[q] = (uint32_t)__ffsll((long long)bigm) - 1;
+                bigm &= bigm - 1;
+                sj[q] = ((uint64_t)rdlane((uint32_t)((uint64_t)(uintptr_t)s >> 32), jj[q]) << 32) | rdlane((uint32_t)(uintptr_t)s, jj[q]);
+                dj[q] = ((uint64_t)rdlane((uint32_t)((uint64_t)(uintptr_t)d >> 32), jj[q]) << 32) | rdlane((uint32_t)(uintptr_t)d, jj[q]);
+                nn[q] = rdlane(len, jj[q]);
+            }
+            v[q] = make_uint4(0, 0, 0, 0);
+            if (16 * lane + 16 <= nn[q]) __builtin_memcpy(&v[q], reinterpret_cast<const uint8_t *>((uintptr_t)sj[q]) + 16 * lane, 16);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            uint8_t *const dq = reinterpret_cast<uint8_t *>((uintptr_t)dj[q]);
+            const uint8_t *const sq = reinterpret_cast<const uint8_t *>((uintptr_t)sj[q]);
+            if (16 * lane + 16 <= nn[q]) __builtin_memcpy(dq + 16 * lane, &v[q], 16);
+            const uint32_t first = nn[q] < 1024 ? nn[q] : 1024u, whole = first & ~15u;   // bytes of the first KiB moved as 16-byte pieces
+            if (lane < first - whole) dq[whole + lane] = sq[whole + lane];
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+            if (nn[q] > 1024)  // (wave-uniform)
+                wave_copy(reinterpret_cast<uint8_t *>((uintptr_t)dj[q]) + 1024, reinterpret_cast<const uint8_t *>((uintptr_t)sj[q]) + 1024, nn[q] - 1024, lane);
     }
 }
 
