@@ -236,6 +236,38 @@ def test_small_real_rounds_are_handed_to_the_wide_variant(gpu_ctx, oracle):
     assert (sizes[40:48] < 200).all()
 
 
+def test_gather_of_small_rounds_every_piece_size(gpu_ctx, oracle):
+    """Tables of rounds of at most 16 KiB are gathered a lane per piece (zstd_encode.hip, k_gather): pieces of up to 512 bytes
+    by their own lanes, longer ones by the whole wave, four at a time (the first KiB of each of the four loaded before any
+    of it is stored, the rest piece by piece).  Incompressible rounds make frames a few bytes longer than their input, so
+    the piece sizes here sit on every boundary of that code: 0, around 16 / 512 / 1024 / 1040, odd lengths, 16 KiB, in an
+    order that mixes them inside a wave — the blob region must be the frames back to back, every frame must decode."""
+    import torch
+    from znippy_amd import hip
+    rng = np.random.default_rng(11)
+    edge = [0, 1, 5, 15, 16, 17, 480, 495, 500, 503, 505, 511, 512, 513, 1000, 1005, 1010, 1015, 1023, 1024, 1025, 1039, 1040, 1041,
+            2047, 2048, 2049, 4095, 5000, 8191, 16000, 16384]
+    sizes = edge + [int(x) for x in rng.integers(0, 16385, 380)] + edge[::-1]
+    ents = [gen.incompressible(900 + i, n) if i % 3 else gen.pseudo_text(n, seed=i) for i, n in enumerate(sizes)]
+    lens = np.array([len(e) for e in ents], np.uint64)
+    offs = np.concatenate([[0], np.cumsum(lens)[:-1]]).astype(np.uint64)
+    d_src = torch.from_numpy(np.frombuffer(b"".join(ents) + bytes(64), np.uint8).copy()).cuda()
+    rt = hip.RoundTable(gpu_ctx, offs, lens)
+    d_blob = torch.full((rt.blob_bound() + 64,), 0x3C, dtype=torch.uint8, device="cuda")
+    enc = rt.encode_hash(d_src, d_blob)
+    assert "gather" in dict(gpu_ctx.kernel_times())
+    blob = d_blob.cpu().numpy()
+    pos = 0
+    for i, e in enumerate(ents):
+        o, n = int(enc["blob_offset"][i]), int(enc["blob_size"][i])
+        assert o == pos, i                                     # packed without gaps, in round order
+        pos += n
+        assert oracle.libzstd_decompress(blob[o:o + n].tobytes(), len(e)) == e, (i, len(e), n)
+        assert enc["checksum"][i].tobytes() == oracle.blake3(e)
+    assert pos == enc["blob_bytes"] and (blob[pos:] == 0x3C).all()
+    rt.close()
+
+
 @pytest.mark.parametrize("sizes", [[5 << 20], [1 << 20, 3 << 20, 160, 70000 * 16, (2 << 20) + 7],
                                    [1 << 20, (1 << 20) + 3, 1 << 20], [100, 1 << 20]])
 def test_store_path_tables_blob_is_the_input(gpu_ctx, oracle, sizes):
