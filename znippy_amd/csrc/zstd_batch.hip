@@ -1535,6 +1535,36 @@ __global__ __launch_bounds__(64) void k_bx_huf(BxArgs a) {
                 const uint32_t mask = (1u << hlog) - 1;
                 uint32_t i = 0;
                 int64_t pos = b.pos;
+                // Far from the stream's first bytes: the 16 bytes the NEXT step needs are loaded while this step decodes.  A step
+                // takes 4 .. 44 bits, so the next step's 44 bits lie inside the 16 bytes that end at byte ceil((pos - 4) / 8),
+                // whatever this step consumes — the load's round trip runs beside the four dependent table lookups instead of
+                // in front of them (the plain loop below: load, then lookups, ~1,300 cycles per four symbols).
+                if (i + 4 <= n_out && pos >= 192) {
+                    int64_t E = (pos + 7) >> 3;  // the window = stream bytes [E - 16, E)
+                    uint4 W;
+                    __builtin_memcpy(&W, p + E - 16, 16);
+                    while (i + 4 <= n_out && pos >= 192) {
+                        const int64_t En = (pos + 3) >> 3;
+                        uint4 Wn;
+                        __builtin_memcpy(&Wn, p + En - 16, 16);
+                        const uint32_t s = (uint32_t)(8 * E - pos);  // bits of the window above the position: 0 .. 84
+                        const uint64_t lo = (uint64_t)W.x | ((uint64_t)W.y << 32), hi = (uint64_t)W.z | ((uint64_t)W.w << 32);
+                        uint64_t val = s < 64 ? (hi << s) | ((lo >> 1) >> (63 - s)) : lo << (s - 64);  // the next 64 bits, top-aligned
+                        uint32_t w = 0, used = 0;
+#pragma unroll
+                        for (int q = 0; q < 4; q++) {
+                            const uint32_t e = huf[(uint32_t)(val >> (64 - hlog))];
+                            w |= (e & 0xFFu) << (8 * q);
+                            val <<= e >> 8;
+                            used += e >> 8;
+                        }
+                        pos -= used;
+                        __builtin_memcpy(dst + i, &w, 4);
+                        i += 4;
+                        W = Wn;
+                        E = En;
+                    }
+                }
                 while (i + 4 <= n_out && pos >= 64) {  // four symbols (<= 44 bits) out of one 8-byte load, one 4-byte store
                     const int64_t b0 = ((pos + 7) >> 3) - 8;
                     uint64_t c;
