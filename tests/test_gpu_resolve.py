@@ -99,3 +99,22 @@ def test_damaged_big_frames_agree_with_oracle(gpu_ctx, oracle):
     data = _py_corpus(2 << 20)
     bases = [(data[:400_000], 3), (data[300_000:300_000 + 280_000], 19), (_mixed(300_000, 8), 1)]
     fuzz_run(gpu_ctx, oracle, bases, 40, 99, 5, 40)
+
+
+@pytest.mark.parametrize("tiles_per_wave", ["1", "2"])
+def test_a_64_leaf_row_beside_a_big_rows_first_slice(oracle, tiles_per_wave):
+    """The second hash pass with two tiles per wave (hash_kernels.hip; forced here, by itself from 7,680 tiles on): a row of
+    exactly 64 KiB is one unit of 64 leaves — a root —, the first slice of a bigger row is 64 leaves too — a tile CV for
+    the merge.  Queued by one wave they are the same node count and different kinds: they must not take the fold that
+    assumes one kind (the slice's CV got the ROOT flag and landed in the digest column: a verified row reported corrupt).
+    Foreign frames, so that both rows reach the second pass; every order of the two kinds, with ragged neighbours."""
+    data = _py_corpus(3 << 20)
+    entries = [data[:65_536], data[100_000:100_000 + 200_000], data[400_000:400_000 + 65_536], data[500_000:500_000 + 65_536],
+               data[600_000:600_000 + 65_537], data[700_000:700_000 + 64 * 1024 * 3], data[1_000_000:1_000_000 + 65_536], data[1_100_000:1_100_000 + 1_048_577]]
+    frames = [workloads.libzstd_compress(e, 3) for e in entries]
+    A = _table(oracle, entries, frames)
+    for pad in (0, 3):
+        c, status, out, kt, st = _decode_with({"ZNIPPY_STORE_G": tiles_per_wave}, A, pad, reps=1)
+        total = int(A["us"].sum())
+        assert c["corrupt_rows"] == 0 and c["decode_errors"] == 0, (pad, c)
+        assert out[pad:pad + total].tobytes() == b"".join(entries)

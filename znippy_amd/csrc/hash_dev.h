@@ -766,6 +766,11 @@ struct FoldQueue {
         // non-zero entries are lanes [0, U)) passed and the left-out unit's digest was never written: a valid row among
         // invalid ones reported corrupt, in whichever runs the left-over list happened to group the tiles that way.
         if (n0 < 2 || has != same || U == 0 || U != n_tab || has != (U == 64 ? ~0ull : ((1ull << U) - 1))) return 0;
+        // all units or all slices: fold_uniform_and_write takes the kind from entry 0.  (A wave of the store path kernel
+        // can queue a 64-leaf row — one unit, a root — beside the first 64-leaf slice of a big row: same node count,
+        // different kinds; folded as one kind the slice's CV got the ROOT flag and went to the digest column.)
+        const uint32_t root0 = __shfl(tb_root, 0);
+        if (__ballot(lane < n_tab && tb_root != root0) != 0ull) return 0;
         return n0;
     }
     __device__ __forceinline__ void fold_uniform_and_write(uint32_t *nodes, const HashArgs &a, uint32_t n, uint32_t U) {
