@@ -11,26 +11,34 @@ namespace zn {
 // Workgroup-level fold of the store path (k_hash_tiles<COPY, 2>), out of line: their registers are their own.  The node
 // arrays are LDS and said to be (address space 3: ds_read / ds_write, not FLAT instructions through a generic pointer).
 typedef __attribute__((address_space(3))) uint32_t lds_u32;
-// First level of a wave's 128 nodes, in place: lane l = parent of nodes 2l, 2l + 1.
-__device__ __noinline__ void fold_first_level_128(lds_u32 *nodes) {
+// First level of a wave's 64 * G leaf nodes (G whole slices), in place: lane l = parent of nodes 2l, 2l + 1.
+template <int G>
+__device__ __noinline__ void fold_first_level(lds_u32 *nodes) {
     const uint32_t lane = threadIdx.x & 63;
+    const bool on = lane < 32 * G;
     const lds_u4a *c = reinterpret_cast<const lds_u4a *>(nodes + (size_t)(2 * lane) * 8);
-    const u4v l0 = c[0], l1 = c[1], r0 = c[2], r1 = c[3];
+    u4v l0 = u4v{0, 0, 0, 0}, l1 = l0, r0 = l0, r1 = l0;
+    if (on) { l0 = c[0]; l1 = c[1]; r0 = c[2]; r1 = c[3]; }
     uint32_t L[8] = {l0.x, l0.y, l0.z, l0.w, l1.x, l1.y, l1.z, l1.w}, R[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w}, cv[8];
     b3::parent(cv, L, R, false);
     __builtin_amdgcn_wave_barrier();  // every lane has read its children (one wave: LDS operations in program order)
-    lds_u4a *d = reinterpret_cast<lds_u4a *>(nodes + (size_t)lane * 8);
-    d[0] = u4v{cv[0], cv[1], cv[2], cv[3]};
-    d[1] = u4v{cv[4], cv[5], cv[6], cv[7]};
+    if (on) {
+        lds_u4a *d = reinterpret_cast<lds_u4a *>(nodes + (size_t)lane * 8);
+        d[0] = u4v{cv[0], cv[1], cv[2], cv[3]};
+        d[1] = u4v{cv[4], cv[5], cv[6], cv[7]};
+    }
 }
-// Levels two to six of eight tiles: tile T = 2 * wave + g keeps its 32 first-level nodes at base + (wave * area_nodes + 32 g)
-// nodes; the levels' outputs go to the unused parts of areas 0 and 1 (behind their 4 KiB of nodes); cvi on lane T = where T's
-// CV goes.
-__device__ __noinline__ void fold_eight_tiles(lds_u32 *base, uint32_t area_nodes, uint32_t *tile_cv, uint32_t cvi) {
+// Levels two to six of the workgroup's NT = 4 G tiles (4 or 8): tile T = G * wave + g keeps its 32 first-level nodes at
+// base + (wave * area_nodes + 32 g) nodes; the levels' outputs go to parts of the areas nobody uses any more (G = 1: all
+// behind area 0's 2 KiB of leaf nodes; G = 2: 128 nodes behind area 0's 4 KiB, the rest behind area 1's); cvi on lane T =
+// where T's CV goes.
+template <int G>
+__device__ __noinline__ void fold_wg_tiles(lds_u32 *base, uint32_t area_nodes, uint32_t *tile_cv, uint32_t cvi) {
+    constexpr uint32_t NT = 4 * G;
     const uint32_t lane = threadIdx.x & 63;
-    lds_u32 *const C2 = base + 128 * 8;                  // 128 nodes
-    lds_u32 *const C3 = base + (area_nodes + 128) * 8;   // 64 + 32 + 16 nodes
-    lds_u32 *const C4 = C3 + 64 * 8, *const C5 = C4 + 32 * 8;
+    lds_u32 *const C2 = base + (size_t)(64 * G) * 8;                                         // NT x 16 nodes
+    lds_u32 *const C3 = G == 1 ? C2 + 64 * 8 : base + (size_t)(area_nodes + 128) * 8;        // NT x 8
+    lds_u32 *const C4 = C3 + NT * 8 * 8, *const C5 = C4 + NT * 4 * 8;                        // NT x 4, NT x 2
     auto parent_of = [&](const lds_u32 *src, bool on, uint32_t cv[8]) {  // parent(src[0], src[1]) on the lanes that have one
         uint32_t L[8], R[8];
         const lds_u4a *c = reinterpret_cast<const lds_u4a *>(src);
@@ -51,16 +59,19 @@ __device__ __noinline__ void fold_eight_tiles(lds_u32 *base, uint32_t area_nodes
         __builtin_amdgcn_wave_barrier();
     };
 #pragma unroll 1
-    for (uint32_t p = 0; p < 2; p++) {  // 8 tiles x 16 parents
+    for (uint32_t p = 0; p < NT * 16 / 64; p++) {  // NT tiles x 16 parents
         const uint32_t T = 4 * p + (lane >> 4), j = lane & 15;
-        level(base + ((size_t)(T >> 1) * area_nodes + 32 * (T & 1) + 2 * j) * 8, C2 + (size_t)(T * 16 + j) * 8, true);
+        level(base + ((size_t)(T / G) * area_nodes + 32 * (T % G) + 2 * j) * 8, C2 + (size_t)(T * 16 + j) * 8, true);
     }
-    level(C2 + (size_t)((lane >> 3) * 16 + 2 * (lane & 7)) * 8, C3 + (size_t)lane * 8, true);                  // 8 x 8
-    level(C3 + (size_t)(((lane & 31) >> 2) * 8 + 2 * (lane & 3)) * 8, C4 + (size_t)(lane & 31) * 8, lane < 32);   // 8 x 4
-    level(C4 + (size_t)(((lane & 15) >> 1) * 4 + 2 * (lane & 1)) * 8, C5 + (size_t)(lane & 15) * 8, lane < 16);   // 8 x 2
+    {   // NT x 8, NT x 4, NT x 2: lane = (tile, pair) while there are that many
+        const uint32_t k3 = lane % (NT * 8), k4 = lane % (NT * 4), k5 = lane % (NT * 2);
+        level(C2 + (size_t)((k3 >> 3) * 16 + 2 * (k3 & 7)) * 8, C3 + (size_t)k3 * 8, lane < NT * 8);
+        level(C3 + (size_t)((k4 >> 2) * 8 + 2 * (k4 & 3)) * 8, C4 + (size_t)k4 * 8, lane < NT * 4);
+        level(C4 + (size_t)((k5 >> 1) * 4 + 2 * (k5 & 1)) * 8, C5 + (size_t)k5 * 8, lane < NT * 2);
+    }
     uint32_t cv[8];
-    parent_of(C5 + (size_t)((lane & 7) * 2) * 8, lane < 8, cv);                                                   // 8 tile CVs
-    if (lane < 8) {
+    parent_of(C5 + (size_t)((lane % NT) * 2) * 8, lane < NT, cv);  // the tiles' CVs
+    if (lane < NT) {
         typedef __attribute__((address_space(1))) u4v glb_u4a;
         glb_u4a *o = (glb_u4a *)(uintptr_t)(tile_cv + (size_t)cvi * 8);
         o[0] = u4v{cv[0], cv[1], cv[2], cv[3]};
@@ -83,10 +94,11 @@ __global__ __launch_bounds__(256, COPY ? (FOLD_G == 1 && !SHIFT ? 5 : 4) : 1) vo
     static_assert(!COPY || FOLD_G * 64 * 32 <= (int)AREA, "the area must hold the queued tiles' nodes");
     __shared__ __attribute__((aligned(16))) uint32_t s_nodes[FOLD_G > 1 && !COPY ? 4 : 1][FOLD_G > 1 && !COPY ? FOLD_G * 64 * 8 : 4];
     __shared__ __attribute__((aligned(16))) uint8_t s_area[COPY ? 4 : 1][AREA];
-    // WGF (store path, two tiles per wave): when each of the workgroup's four waves has queued two whole slices, a wave folds
-    // only the first level of its own 128 nodes (64 parents: every lane busy) and ONE wave takes the sparse levels of all
-    // eight tiles together (128 + 64 + 32 + 16 + 8 parents: six passes) — 17.25 compress passes per tile instead of 19.
-    constexpr bool WGF = COPY && FOLD_G == 2 && !SHIFT;
+    // WGF (store path): when each of the workgroup's four waves holds nothing but whole slices of big units (FOLD_G of them),
+    // a wave folds only the first level of its own leaf nodes and ONE wave takes levels two to six of the workgroup's 4 or 8
+    // tiles together — per tile 16 leaf passes + 2.25 (one tile per wave; 6 when folded alone) or + 1.25 (two per wave; 3).
+    constexpr bool WGF = COPY;
+    constexpr int QG = FOLD_G > 1 ? FOLD_G : 2;  // (one tile per wave: the queue is only the fallback's vehicle)
     const uint32_t w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const uint32_t first = (blockIdx.x * 4 + w) * FOLD_G;
     bool live = first < a.n_tiles;
@@ -98,7 +110,7 @@ __global__ __launch_bounds__(256, COPY ? (FOLD_G == 1 && !SHIFT ? 5 : 4) : 1) vo
         if (!any_big) live = false;
     }
     if (!WGF && !live) return;  // (WGF: every wave reaches the workgroup's barrier below)
-    FoldQueue<FOLD_G> fq;
+    FoldQueue<QG> fq;
     uint32_t *nodes = COPY ? reinterpret_cast<uint32_t *>(s_area[w]) : s_nodes[FOLD_G > 1 ? w : 0];
     uint8_t *const stage = COPY ? s_area[w] + KEEP_BYTES : nullptr;
     for (uint32_t g = 0; live && g < FOLD_G && first + g < a.n_tiles; g++) {
@@ -112,20 +124,21 @@ __global__ __launch_bounds__(256, COPY ? (FOLD_G == 1 && !SHIFT ? 5 : 4) : 1) vo
         }
         LeafOut lo;
         hash_tile_leaves<COPY, false, COPY, SHIFT>(a, t, nullptr, lo, stage);
-        if (FOLD_G > 1 && FoldQueue<FOLD_G>::fits(t)) fq.add(nodes, g, t, lo);
+        // (one tile per wave on the store path: only a whole slice is queued — the stage's head is free by now)
+        if (FOLD_G > 1 ? FoldQueue<QG>::fits(t) : (WGF && t.n_units == 0 && t.n_leaves == 64 && __ballot(lo.active) == ~0ull)) fq.add(nodes, g, t, lo);
         else fold_tile_now(a, t, lo);
     }
     if constexpr (WGF) {
         uint32_t U = 0;
         const uint32_t n = fq.uniform(&U);
-        const bool simple = n == 64 && U == 2 && __shfl(fq.tb_root, 0) == 0;  // two whole slices (entry i on lane i)
+        const bool simple = n == 64 && U == (uint32_t)FOLD_G && __shfl(fq.tb_root, 0) == 0;  // FOLD_G whole slices (entry i on lane i)
         // the wave's word to the others: the last 32 bytes of its own area (the stage's end: free once its tiles are through,
         // and no level's output reaches there): [simple, where tile 0's CV goes, where tile 1's goes]
         uint32_t *const mine = reinterpret_cast<uint32_t *>(s_area[w] + AREA - 32);
         if (simple) {
-            fold_first_level_128((lds_u32 *)nodes);
-            if (lane < 2) mine[1 + lane] = fq.tb_out;
-            fq.tb_n = lane < 2 ? 32u : 0u;  // what is left of the wave's table: two units of 32 nodes
+            fold_first_level<FOLD_G>((lds_u32 *)nodes);
+            if (lane < (uint32_t)FOLD_G) mine[1 + lane] = fq.tb_out;
+            fq.tb_n = lane < (uint32_t)FOLD_G ? 32u : 0u;  // what is left of the wave's table: units of 32 nodes
             fq.tb_off = 32 * lane;
         }
         if (lane == 0) mine[0] = simple ? 1u : 0u;
@@ -134,16 +147,16 @@ __global__ __launch_bounds__(256, COPY ? (FOLD_G == 1 && !SHIFT ? 5 : 4) : 1) vo
 #pragma unroll
         for (int v = 0; v < 4; v++) all &= *reinterpret_cast<const uint32_t *>(s_area[v] + AREA - 32);
         if (!all) {  // a workgroup with anything else in it (a table's edges, rows of other shapes): every wave finishes its own
-            if (simple) fq.fold_uniform_and_write(nodes, a, 32, 2);
+            if (simple) fq.fold_uniform_and_write(nodes, a, 32, FOLD_G);
             else if (n) fq.fold_uniform_and_write(nodes, a, n, U);
             else fq.fold_and_write(nodes, a);
             return;
         }
         if (w != (blockIdx.x * 2654435761u) >> 30) return;
-        static_assert(AREA % 32 == 0 && AREA >= 8192 + 32, "room for the levels' outputs between the nodes and the waves' words");
+        static_assert(AREA % 32 == 0 && AREA >= (FOLD_G == 1 ? 64 + 64 + 32 + 16 + 8 : 128 + 128) * 32 + 32, "room for the levels' outputs between the nodes and the waves' words");
         uint32_t cvi = 0;
-        if (lane < 8) cvi = reinterpret_cast<const uint32_t *>(s_area[lane >> 1] + AREA - 32)[1 + (lane & 1)];
-        fold_eight_tiles((lds_u32 *)reinterpret_cast<uint32_t *>(&s_area[0][0]), AREA / 32, a.tile_cv, cvi);
+        if (lane < 4 * FOLD_G) cvi = reinterpret_cast<const uint32_t *>(s_area[lane / FOLD_G] + AREA - 32)[1 + lane % FOLD_G];
+        fold_wg_tiles<FOLD_G>((lds_u32 *)reinterpret_cast<uint32_t *>(&s_area[0][0]), AREA / 32, a.tile_cv, cvi);
     } else if (FOLD_G > 1) {
         fq.fold_and_write(nodes, a);
     }
