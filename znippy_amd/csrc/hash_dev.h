@@ -360,53 +360,69 @@ __device__ __forceinline__ void hash_tile_leaves(const HashArgs &a, const Tile &
                 uint8_t *const slot = stage + (lane >> 3) * STAGE_SHIFT_SLOT;  // leaf lane/8 (+ 8j: j * 8 slots further)
                 constexpr uint32_t JS = 8 * STAGE_SHIFT_SLOT;
                 const lds_u4a *const own = (const lds_u4a *)(stage + lane * STAGE_SHIFT_SLOT + 16);
-                uint4 v[8], vn[8];
+                // FULL: all 64 leaves are there — no lane-dependent branch around the memory instructions (counted waits), and
+                // the step's order of the aligned form below: stage write, this pair's stores, the next pair's loads over the
+                // same registers, two compressions (C5's write side 3.55 -> 3.36 ms same box; the branch-free loop alone, with
+                // the ragged form's loads before stores into a second set of registers: no gain).
+                auto recut = [&](auto full_tile) {
+                    constexpr bool FULL = decltype(full_tile)::value;
+                    constexpr bool ONE_SET = FULL;  // stores before the next loads, over one set of registers
+                    uint4 v[8], vn[8];
 #pragma unroll
-                for (int j = 0; j < 8; j++) { v[j] = make_uint4(0, 0, 0, 0); vn[j] = v[j]; if (actj[j]) v[j] = ld16(s0 + j * 8192); }
+                    for (int j = 0; j < 8; j++) { v[j] = make_uint4(0, 0, 0, 0); vn[j] = v[j]; if (FULL || actj[j]) v[j] = ld16(s0 + j * 8192); }
 #pragma unroll 1
-                for (uint32_t bb = 0; bb < 8; bb++) {
-                    if (bb && q == 7) {  // the previous 128 bytes' tail moves in front before they are overwritten
+                    for (uint32_t bb = 0; bb < 8; bb++) {
+                        if (bb && q == 7) {  // the previous 128 bytes' tail moves in front before they are overwritten
 #pragma unroll
-                        for (int j = 0; j < 8; j++)
-                            if (actj[j]) *(lds_u4a *)(slot + j * JS) = *(const lds_u4a *)(slot + j * JS + 128);
-                    }
-#pragma unroll
-                    for (int j = 0; j < 8; j++)
-                        if (actj[j]) *(lds_u4a *)(slot + j * JS + 16 + 16 * q) = u4v{v[j].x, v[j].y, v[j].z, v[j].w};
-                    if (bb < 7) {
-#pragma unroll
-                        for (int j = 0; j < 8; j++)
-                            if (actj[j]) vn[j] = ld16(s0 + j * 8192 + (bb + 1) * 128);
-                    }
-                    // piece q, re-cut: bytes [16q - dl, 16q - dl + 16) of the slot's chunk to the boundary below; the
-                    // leaf's very first piece has nothing in front of it: it goes out as it is, to its own odd place
-                    const bool first = bb == 0 && q == 0;
-                    const uint32_t sh = first ? 0u : dl;
-#pragma unroll
-                    for (int j = 0; j < 8; j++)
-                        if (actj[j]) {
-                            const u4v o = *(const lds_u4 *)(slot + j * JS + 16 + 16 * q - sh);
-                            st16(d0 + j * 8192 + bb * 128 - sh, make_uint4(o.x, o.y, o.z, o.w));
+                            for (int j = 0; j < 8; j++)
+                                if (FULL || actj[j]) *(lds_u4a *)(slot + j * JS) = *(const lds_u4a *)(slot + j * JS + 128);
                         }
-                    if (bb == 7 && q == 7) {  // the leaf's last dl bytes: its last 16, to their own odd place
 #pragma unroll
                         for (int j = 0; j < 8; j++)
-                            if (actj[j]) st16(d0 + j * 8192 + bb * 128, v[j]);
-                    }
+                            if (FULL || actj[j]) *(lds_u4a *)(slot + j * JS + 16 + 16 * q) = u4v{v[j].x, v[j].y, v[j].z, v[j].w};
+                        if (!ONE_SET && bb < 7) {
 #pragma unroll
-                    for (int h = 0; h < 2; h++) {
-                        if (active) {
-                            const u4v a0 = own[4 * h], a1 = own[4 * h + 1], a2 = own[4 * h + 2], a3 = own[4 * h + 3];
-                            uint32_t m[16] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w, a2.x, a2.y, a2.z, a2.w, a3.x, a3.y, a3.z, a3.w};
-                            const uint32_t b = 2 * bb + h;
-                            const uint32_t flags = (b == 0 ? b3::CHUNK_START : 0u) |
-                                                   (b == 15 ? (b3::CHUNK_END | (single ? b3::ROOT : 0u)) : 0u);
-                            b3::compress(cv, m, k, 0, 64, flags);
+                            for (int j = 0; j < 8; j++)
+                                if (FULL || actj[j]) vn[j] = ld16(s0 + j * 8192 + (bb + 1) * 128);
+                        }
+                        // piece q, re-cut: bytes [16q - dl, 16q - dl + 16) of the slot's chunk to the boundary below; the
+                        // leaf's very first piece has nothing in front of it: it goes out as it is, to its own odd place
+                        const bool first = bb == 0 && q == 0;
+                        const uint32_t sh = first ? 0u : dl;
+#pragma unroll
+                        for (int j = 0; j < 8; j++)
+                            if (FULL || actj[j]) {
+                                const u4v o = *(const lds_u4 *)(slot + j * JS + 16 + 16 * q - sh);
+                                st16(d0 + j * 8192 + bb * 128 - sh, make_uint4(o.x, o.y, o.z, o.w));
+                            }
+                        if (bb == 7 && q == 7) {  // the leaf's last dl bytes: its last 16, to their own odd place
+#pragma unroll
+                            for (int j = 0; j < 8; j++)
+                                if (FULL || actj[j]) st16(d0 + j * 8192 + bb * 128, v[j]);
+                        }
+                        if (ONE_SET && bb < 7) {
+#pragma unroll
+                            for (int j = 0; j < 8; j++) v[j] = ld16(s0 + j * 8192 + (bb + 1) * 128);
+                        }
+#pragma unroll
+                        for (int h = 0; h < 2; h++) {
+                            if (FULL || active) {
+                                const u4v a0 = own[4 * h], a1 = own[4 * h + 1], a2 = own[4 * h + 2], a3 = own[4 * h + 3];
+                                uint32_t m[16] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w, a2.x, a2.y, a2.z, a2.w, a3.x, a3.y, a3.z, a3.w};
+                                const uint32_t b = 2 * bb + h;
+                                const uint32_t flags = (b == 0 ? b3::CHUNK_START : 0u) |
+                                                       (b == 15 ? (b3::CHUNK_END | (single ? b3::ROOT : 0u)) : 0u);
+                                b3::compress(cv, m, k, 0, 64, flags);
+                            }
+                        }
+                        if (!ONE_SET) {
+#pragma unroll
+                            for (int j = 0; j < 8; j++) v[j] = vn[j];
                         }
                     }
-#pragma unroll
-                    for (int j = 0; j < 8; j++) v[j] = vn[j];
-                }
+                };
+                if (act == ~0ull) recut(std::true_type{});
+                else recut(std::false_type{});
             } else if (COPY && STAGE_FULL && stage && !LDSRC && t.n_units == 0 && __ballot(active && dst == nullptr) == 0ull) {
                 // Big-slice tile of the store path, whole cache lines: a leaf's bytes move 128 at a time (two blocks), 8
                 // lanes per leaf, 8 leaves per instruction — the 64-byte form fetched every line from HBM twice (PMC:
