@@ -370,6 +370,60 @@ def test_stored_big_rows_every_output_alignment(gpu_ctx, oracle):
     assert np.array_equal(out, want)
 
 
+@pytest.mark.parametrize("switch", [{}, {"ZNIPPY_NO_STORED_ONLY": "1"}])
+def test_tables_without_a_compressed_row(oracle, switch):
+    """A table whose rows are all stored (nothing to recognise or decode: png / jpg / gz files, jars) takes one pass of the
+    store path kernel over all its tiles — small ones too — instead of the fused small-row kernels (api.hip: stored_only;
+    ZNIPPY_NO_STORED_ONLY=1 = the old route).  Small rows of every size class, empty rows, 64-leaf rows, big rows, odd and
+    even output offsets, a corrupted row: same counters, same corrupt list, same bytes either way and as the oracle says."""
+    import os
+    import torch
+    from znippy_amd import hip
+    old = {k: os.environ.get(k) for k in switch}
+    os.environ.update(switch)
+    try:
+        ctx = hip.Context(0)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                del os.environ[k]
+            else:
+                os.environ[k] = v
+    try:
+        rng = np.random.default_rng(5)
+        sizes = [10240] * 40 + [0, 1, 63, 64, 1023, 1024, 1025, 65535, 65536, 65537, 3 << 16, (1 << 20) + 77] + [int(x) for x in rng.integers(0, 40000, 300)] + [10240] * 25
+        rows = [gen.incompressible(7000 + i, n) for i, n in enumerate(sizes)]
+        for pad, gap in ((0, 0), (5, 3)):
+            out_off, pos = [], pad
+            for n in sizes:
+                out_off.append(pos)
+                pos += n + gap
+            total = pos + 64
+            blobs = np.frombuffer(b"".join(rows) + bytes(64), dtype=np.uint8).copy()
+            bs = np.array(sizes, dtype=np.uint64)
+            bo = np.concatenate([[0], np.cumsum(bs)[:-1]]).astype(np.uint64)
+            ck = np.stack([np.frombuffer(oracle.blake3(d), dtype=np.uint8) for d in rows])
+            bad_row = 17
+            blobs[int(bo[bad_row]) + 100] ^= 0x40            # one stored row damaged in the archive
+            d_blobs = torch.from_numpy(blobs).cuda()
+            bitmap = np.zeros((len(sizes) + 7) // 8, np.uint8)
+            rt = hip.RowTable(ctx, bo, bs, bs, np.array(out_off, dtype=np.uint64), bitmap, ck)
+            want = np.full(total, 0xA5, np.uint8)
+            for i, (o, d) in enumerate(zip(out_off, rows)):
+                want[o:o + len(d)] = blobs[int(bo[i]):int(bo[i]) + len(d)]
+            for _ in range(2):
+                d_out = torch.full((total,), 0xA5, dtype=torch.uint8, device="cuda")
+                counters, corrupt, status = rt.decode_verify(d_blobs, d_out)
+                assert (status == 0).all() and list(corrupt) == [bad_row], (list(corrupt), np.nonzero(status)[0][:5])
+                assert counters["corrupt_rows"] == 1 and counters["verified_bytes"] == sum(sizes) - sizes[bad_row]
+                assert np.array_equal(d_out.cpu().numpy(), want)
+            names = dict(ctx.kernel_times())
+            assert ("decode_verify_fused" in names) == bool(switch), sorted(names)
+            rt.close()
+    finally:
+        ctx.close()
+
+
 @pytest.mark.parametrize("tiles_per_wave", ["1", "2"])
 def test_stored_rows_one_and_two_tiles_per_wave(oracle, tiles_per_wave):
     """Store path kernel, both forms (hash_kernels.hip: k_hash_tiles<COPY, 1 | 2>; picked from the tile count, forced here

@@ -72,6 +72,10 @@ def layout(name):
         return dict(lens=np.array(lens, np.uint64), skip=np.array(skip, np.uint8), gen=g,
                     name=("mixed artifact repo stand-in: %d xml (1-8 KiB) + %d jars (100 KiB-%.1f MiB, store path), %.2f GB"
                           % (len(xml), len(jars), max(jars) / 2**20, (nx + nj) / 1e9)) + ({"c5": "", "c5text": "; the xml files hold real (non-periodic) text"}.get(name, " (reduced; NOT BASELINE's size)")))
+    if name == "c2store":  # BASELINE configs[1]'s shape with content the reference would not compress (skip list: png, jpg, gz ...)
+        n = 100_000
+        return dict(lens=np.full(n, 10240, np.uint64), skip=np.ones(n, np.uint8), gen=lambda torch, b0, b1: gen_gpu.random_lcg(b1 - b0, start=b0),
+                    name="100k x 10KiB incompressible chunks, store path (a repo of small pre-compressed files; NOT a BASELINE config)")
     if name in ("c4store", "c4codec"):
         size = 500 << 20
         lens = np.array([SLICE] * (size // SLICE) + ([size % SLICE] if size % SLICE else []), dtype=np.uint64)

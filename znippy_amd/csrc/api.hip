@@ -117,7 +117,7 @@ struct znippy_ctx {
         unsigned lds_pad = 0;    // ZNIPPY_LDS_PAD
         int store_g = 0;         // ZNIPPY_STORE_G: tiles per wave of the store path kernel (0 = from the tile count)
         bool no_block_items = false, no_fused_blocks = false, ddbg = false, edbg = false, no_fused_store = false,
-             nohash = false, no_roles = false, no_fz = false, fz_only = false, no_bx = false, tdbg = false, no_fuse_hash = false, trace = false, no_rx = false, no_pack = false, no_lean = false;
+             nohash = false, no_roles = false, no_fz = false, fz_only = false, no_bx = false, tdbg = false, no_fuse_hash = false, trace = false, no_rx = false, no_pack = false, no_lean = false, no_stored_only = false;
         // ZNIPPY_ROLES_MIN: small tiles from which the role-split persistent kernel takes the table (0 = never; below
         // a few CU-fillings a persistent grid only adds start-up latency)
         unsigned roles_min = 2048;
@@ -151,6 +151,7 @@ static void read_switches(znippy_ctx *ctx) {
     ctx->sw.no_lean = on("ZNIPPY_NO_LEAN");  // A/B: every run launches the kernels behind the role-split one
     ctx->sw.no_pack = on("ZNIPPY_NO_PACK");  // A/B: the index columns always as four 64-bit copies
     if (const char *e = getenv("ZNIPPY_STORE_G")) ctx->sw.store_g = atoi(e) == 1 ? 1 : (atoi(e) == 2 ? 2 : 0);  // A/B, tests: tiles per wave of the store path kernel
+    ctx->sw.no_stored_only = on("ZNIPPY_NO_STORED_ONLY");  // A/B: tables without a compressed row through the fused small-row kernels (until round 3's last day)
     ctx->sw.no_rx = on("ZNIPPY_NO_RX");  // A/B: big foreign frames executed by a wave each (round 3's first form)
     ctx->sw.no_fuse_hash = on("ZNIPPY_NO_FUSE_HASH");  // A/B: the write side's hash as a kernel of its own beside the encoder (round 2)
     ctx->sw.no_bx = on("ZNIPPY_NO_BX");
@@ -1394,7 +1395,12 @@ int znippy_decode_verify_rows_async(znippy_ctx *ctx, znippy_rows *r, const void 
     h.store_tiles = ctx->sw.store_g;
     h.misaligned_dst = r->odd_out || ((uintptr_t)d_out & 15) != 0;
     h.digests = r->digests; h.tile_cv = r->plan.tile_cv;
-    if (!small_off) {
+    // A table without a single compressed row (a repository of small files the reference stores as they are — png, jpg, gz —,
+    // or one big jar): nothing to recognise, nothing to decode — one pass of the store path kernel over ALL tiles (hash + copy,
+    // small tiles 64 bytes per leaf per step through the stage), the merge, the verify.  (The fused small-row kernel copies a
+    // stored row with each lane's own 64-byte stores: 100k x 10 KiB stored rows 0.85 ms there, 0.63 here.)
+    const bool stored_only = r->n_compressed == 0 && !preset && !ctx->sw.dbg && !ctx->sw.no_stored_only && !r->force_full;
+    if (!small_off && !stored_only) {
         FusedArgs f{};
         f.h = h;
         f.h.pass = 1;  // PASS_FUSED
@@ -1455,7 +1461,7 @@ int znippy_decode_verify_rows_async(znippy_ctx *ctx, znippy_rows *r, const void 
     //    auxiliary stream, the general decoder (single-block big rows + whatever the fused kernel handed over) on the
     //    main one — each is latency-bound on its own and leaves most of the chip idle.  Frames the block path gives up
     //    on are decoded by a second general launch afterwards.
-    if (!lean && !lean_mixed) {  // (a lean run: nothing is expected behind the fused kernels; k_verify checks that — rows_settle)
+    if (!lean && !lean_mixed && !stored_only) {  // (a lean run: nothing is expected behind the fused kernels; k_verify checks that — rows_settle)
     BlockScanArgs b{};
     // The block items run on the auxiliary stream beside whatever the main stream has — unless it has nothing: a table of big
     // rows only whose last run handed nothing over (`behind` below: the serial decoder is launched after the join anyway).
@@ -1754,8 +1760,8 @@ int znippy_decode_verify_rows_async(znippy_ctx *ctx, znippy_rows *r, const void 
     }
     if (!lean) {
     // 3) second hash pass: slices of big rows + rows the general decoder finished
-    h.pass = 2;  // PASS_SECOND
-    h.tile_done = r->n_bt ? r->tile_done : nullptr;
+    h.pass = stored_only ? 0 : 2;  // PASS_ALL : PASS_SECOND
+    h.tile_done = r->n_bt && !stored_only ? r->tile_done : nullptr;
     ktime_begin(ctx, "blake3_second_pass");
     launch_hash_tiles(h, s);
     ktime_end(ctx);
