@@ -154,6 +154,129 @@ constexpr uint32_t STAGE_SWZ_BYTES = 64 * 128;
 constexpr uint32_t STAGE_SHIFT_SLOT = 160;  // 16 (tail of the previous 128 bytes) + 128 + 16
 constexpr uint32_t STAGE_SHIFT_BYTES = 64 * STAGE_SHIFT_SLOT;
 
+// Ragged leaves on the store path, out of line (its registers are its own: inlined it cost the whole-leaf forms of the same
+// kernel 1-3 %).  Every lane of the wave must call it.  Returns the lane's chaining value.
+struct Cv8 { uint32_t v[8]; };
+__device__ __noinline__ Cv8 hash_ragged_through_stage(const uint8_t *src, uint8_t *dst, uint32_t leaf_len, uint32_t nblk, uint32_t k,
+                                                     bool single, bool active, uint8_t *stage) {
+    const uint32_t lane = threadIdx.x & 63;
+    uint32_t cv[8];
+    b3::set_iv(cv);
+    // Ragged leaves on the store path (the last leaf of a row that is not a whole number of KiB — nearly every row of a
+    // real archive — or an empty row): the same two-way stage as the whole-leaf form below it in the other branch (lane l
+    // moves piece l % 4 of leaves 16j + l / 4, 64 bytes per leaf per step, the next step's loads in flight), with every
+    // piece cut to what its leaf still has: whole pieces as 16-byte accesses, the one partial piece of a leaf byte by
+    // byte (nothing is read or written beyond a row's last byte), absent ones as zeros in the stage — the padding the
+    // hash wants.  A lane hashes as many blocks as its leaf has.  (Until this form every tile with one ragged leaf took
+    // the generic loop below: each lane its own 64-byte loads and stores 1 KiB apart, half the speed.)
+    const uint64_t has = __ballot(active && dst != nullptr), act = __ballot(active);
+    const uint8_t *sj[4];
+    uint8_t *pj[4];
+    bool onj[4], actj[4];
+    lds_u4a *rs[4];
+    int32_t lrem[4];  // bytes of my piece's leaf from my piece's first byte on (at step 0)
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const uint32_t leaf = 16 * j + (lane >> 2);
+        const uint64_t d64 = (uint64_t)(uintptr_t)dst, s64 = (uint64_t)(uintptr_t)src;
+        const uint64_t g = ((uint64_t)__shfl((uint32_t)(d64 >> 32), leaf) << 32) | __shfl((uint32_t)d64, leaf);
+        const uint64_t h = ((uint64_t)__shfl((uint32_t)(s64 >> 32), leaf) << 32) | __shfl((uint32_t)s64, leaf);
+        pj[j] = reinterpret_cast<uint8_t *>((uintptr_t)g) + 16 * (lane & 3);
+        sj[j] = reinterpret_cast<const uint8_t *>((uintptr_t)h) + 16 * (lane & 3);
+        onj[j] = (has >> leaf) & 1;
+        actj[j] = (act >> leaf) & 1;
+        rs[j] = (lds_u4a *)(stage + leaf * STAGE_SLOT + 16 * (lane & 3));
+        lrem[j] = (int32_t)__shfl(leaf_len, leaf) - 16 * (int32_t)(lane & 3);
+    }
+    const lds_u4a *ws = (const lds_u4a *)(stage + lane * STAGE_SLOT);
+    uint32_t maxblk = active ? nblk : 0;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        uint32_t o = __shfl_xor(maxblk, d);
+        maxblk = o > maxblk ? o : maxblk;
+    }
+    maxblk = __builtin_amdgcn_readfirstlane(maxblk);
+    // my piece of block b of leaf group j, zero padded.  PARTIAL = this step has a piece of 1 .. 15 bytes somewhere in the
+    // wave (wave-uniform: at most one step per ragged leaf); the other steps know only whole and absent pieces.
+    auto piece = [&](int j, uint32_t b, bool partial) -> uint4 {
+        uint4 v = make_uint4(0, 0, 0, 0);
+        const int32_t rem = lrem[j] - 64 * (int32_t)b;
+        if (actj[j] && rem >= 16) v = ld16(sj[j] + b * 64);
+        else if (partial && actj[j] && rem > 0) {
+            const glb_u8 *const gq = (const glb_u8 *)(uintptr_t)(sj[j] + b * 64);
+            uint32_t w[4] = {0, 0, 0, 0};
+#pragma unroll
+            for (int q = 0; q < 15; q++)
+                if (q < rem) w[q >> 2] |= (uint32_t)gq[q] << (8 * (q & 3));
+            v = make_uint4(w[0], w[1], w[2], w[3]);
+        }
+        return v;
+    };
+    auto any_partial = [&](uint32_t b) -> bool {
+        bool p = false;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int32_t rem = lrem[j] - 64 * (int32_t)b;
+            p |= actj[j] && rem > 0 && rem < 16;
+        }
+        return __ballot(p) != 0ull;
+    };
+    uint4 v[4], vn[4];
+    bool part = any_partial(0);
+#pragma unroll
+    for (int j = 0; j < 4; j++) { v[j] = piece(j, 0, part); vn[j] = make_uint4(0, 0, 0, 0); }
+#pragma unroll 1
+    for (uint32_t b = 0; b < maxblk; b++) {
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+            if (actj[j]) *rs[j] = u4v{v[j].x, v[j].y, v[j].z, v[j].w};
+        const bool part_next = b + 1 < maxblk && any_partial(b + 1);
+        if (b + 1 < maxblk) {
+            if (part_next) {
+#pragma unroll
+                for (int j = 0; j < 4; j++) vn[j] = piece(j, b + 1, true);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; j++) vn[j] = piece(j, b + 1, false);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int32_t rem = lrem[j] - 64 * (int32_t)b;
+            if (onj[j] && rem >= 16) st16(pj[j] + b * 64, v[j]);
+        }
+        if (part) {  // (wave-uniform) the step's partial pieces, byte by byte
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int32_t rem = lrem[j] - 64 * (int32_t)b;
+                if (onj[j] && rem > 0 && rem < 16) {
+                    glb_u8 *const gq = (glb_u8 *)(uintptr_t)(pj[j] + b * 64);
+                    const uint32_t w[4] = {v[j].x, v[j].y, v[j].z, v[j].w};
+#pragma unroll
+                    for (int q = 0; q < 15; q++)
+                        if (q < rem) gq[q] = (uint8_t)(w[q >> 2] >> (8 * (q & 3)));
+                }
+            }
+        }
+        if (active && b < nblk) {
+            const u4v a0 = ws[0], a1 = ws[1], a2 = ws[2], a3 = ws[3];
+            uint32_t m[16] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w, a2.x, a2.y, a2.z, a2.w, a3.x, a3.y, a3.z, a3.w};
+            const uint32_t rem = leaf_len - b * 64;
+            const uint32_t bl = leaf_len == 0 ? 0 : (rem < 64 ? rem : 64);
+            const uint32_t flags = (b == 0 ? b3::CHUNK_START : 0u) |
+                                   (b == nblk - 1 ? (b3::CHUNK_END | (single ? b3::ROOT : 0u)) : 0u);
+            b3::compress(cv, m, k, 0, bl, flags);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++) v[j] = vn[j];
+        part = part_next;
+    }
+    Cv8 r;
+#pragma unroll
+    for (int i = 0; i < 8; i++) r.v[i] = cv[i];
+    return r;
+}
+
 template <bool COPY, bool LDSRC = false, bool STAGE_FULL = false, bool STAGE_SHIFT = false>
 __device__ __forceinline__ void hash_tile_leaves(const HashArgs &a, const Tile &t, const LdsSrc *ls, LeafOut &out,
                                                  uint8_t *stage = nullptr, const uint8_t *raw_src = nullptr) {
@@ -589,115 +712,9 @@ __device__ __forceinline__ void hash_tile_leaves(const HashArgs &a, const Tile &
         if (LDSRC && __ballot(active && !Y) == 0ull) run(std::true_type{});
         else run(std::false_type{});
     } else if (COPY && !LDSRC && stage && ZN_STAGE_LOADS && ZN_RAGGED_STAGE) {
-        // Ragged leaves on the store path (the last leaf of a row that is not a whole number of KiB — nearly every row of a
-        // real archive — or an empty row): the same two-way stage as the whole-leaf form below it in the other branch (lane l
-        // moves piece l % 4 of leaves 16j + l / 4, 64 bytes per leaf per step, the next step's loads in flight), with every
-        // piece cut to what its leaf still has: whole pieces as 16-byte accesses, the one partial piece of a leaf byte by
-        // byte (nothing is read or written beyond a row's last byte), absent ones as zeros in the stage — the padding the
-        // hash wants.  A lane hashes as many blocks as its leaf has.  (Until this form every tile with one ragged leaf took
-        // the generic loop below: each lane its own 64-byte loads and stores 1 KiB apart, half the speed.)
-        const uint64_t has = __ballot(active && dst != nullptr), act = __ballot(active);
-        const uint8_t *sj[4];
-        uint8_t *pj[4];
-        bool onj[4], actj[4];
-        lds_u4a *rs[4];
-        int32_t lrem[4];  // bytes of my piece's leaf from my piece's first byte on (at step 0)
+        const Cv8 r = hash_ragged_through_stage(src, dst, leaf_len, nblk, k, single, active, stage);
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const uint32_t leaf = 16 * j + (lane >> 2);
-            const uint64_t d64 = (uint64_t)(uintptr_t)dst, s64 = (uint64_t)(uintptr_t)src;
-            const uint64_t g = ((uint64_t)__shfl((uint32_t)(d64 >> 32), leaf) << 32) | __shfl((uint32_t)d64, leaf);
-            const uint64_t h = ((uint64_t)__shfl((uint32_t)(s64 >> 32), leaf) << 32) | __shfl((uint32_t)s64, leaf);
-            pj[j] = reinterpret_cast<uint8_t *>((uintptr_t)g) + 16 * (lane & 3);
-            sj[j] = reinterpret_cast<const uint8_t *>((uintptr_t)h) + 16 * (lane & 3);
-            onj[j] = (has >> leaf) & 1;
-            actj[j] = (act >> leaf) & 1;
-            rs[j] = (lds_u4a *)(stage + leaf * STAGE_SLOT + 16 * (lane & 3));
-            lrem[j] = (int32_t)__shfl(leaf_len, leaf) - 16 * (int32_t)(lane & 3);
-        }
-        const lds_u4a *ws = (const lds_u4a *)(stage + lane * STAGE_SLOT);
-        uint32_t maxblk = active ? nblk : 0;
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) {
-            uint32_t o = __shfl_xor(maxblk, d);
-            maxblk = o > maxblk ? o : maxblk;
-        }
-        maxblk = __builtin_amdgcn_readfirstlane(maxblk);
-        // my piece of block b of leaf group j, zero padded.  PARTIAL = this step has a piece of 1 .. 15 bytes somewhere in the
-        // wave (wave-uniform: at most one step per ragged leaf); the other steps know only whole and absent pieces.
-        auto piece = [&](int j, uint32_t b, bool partial) -> uint4 {
-            uint4 v = make_uint4(0, 0, 0, 0);
-            const int32_t rem = lrem[j] - 64 * (int32_t)b;
-            if (actj[j] && rem >= 16) v = ld16(sj[j] + b * 64);
-            else if (partial && actj[j] && rem > 0) {
-                const glb_u8 *const gq = (const glb_u8 *)(uintptr_t)(sj[j] + b * 64);
-                uint32_t w[4] = {0, 0, 0, 0};
-#pragma unroll
-                for (int q = 0; q < 15; q++)
-                    if (q < rem) w[q >> 2] |= (uint32_t)gq[q] << (8 * (q & 3));
-                v = make_uint4(w[0], w[1], w[2], w[3]);
-            }
-            return v;
-        };
-        auto any_partial = [&](uint32_t b) -> bool {
-            bool p = false;
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const int32_t rem = lrem[j] - 64 * (int32_t)b;
-                p |= actj[j] && rem > 0 && rem < 16;
-            }
-            return __ballot(p) != 0ull;
-        };
-        uint4 v[4], vn[4];
-        bool part = any_partial(0);
-#pragma unroll
-        for (int j = 0; j < 4; j++) { v[j] = piece(j, 0, part); vn[j] = make_uint4(0, 0, 0, 0); }
-#pragma unroll 1
-        for (uint32_t b = 0; b < maxblk; b++) {
-#pragma unroll
-            for (int j = 0; j < 4; j++)
-                if (actj[j]) *rs[j] = u4v{v[j].x, v[j].y, v[j].z, v[j].w};
-            const bool part_next = b + 1 < maxblk && any_partial(b + 1);
-            if (b + 1 < maxblk) {
-                if (part_next) {
-#pragma unroll
-                    for (int j = 0; j < 4; j++) vn[j] = piece(j, b + 1, true);
-                } else {
-#pragma unroll
-                    for (int j = 0; j < 4; j++) vn[j] = piece(j, b + 1, false);
-                }
-            }
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const int32_t rem = lrem[j] - 64 * (int32_t)b;
-                if (onj[j] && rem >= 16) st16(pj[j] + b * 64, v[j]);
-            }
-            if (part) {  // (wave-uniform) the step's partial pieces, byte by byte
-#pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    const int32_t rem = lrem[j] - 64 * (int32_t)b;
-                    if (onj[j] && rem > 0 && rem < 16) {
-                        glb_u8 *const gq = (glb_u8 *)(uintptr_t)(pj[j] + b * 64);
-                        const uint32_t w[4] = {v[j].x, v[j].y, v[j].z, v[j].w};
-#pragma unroll
-                        for (int q = 0; q < 15; q++)
-                            if (q < rem) gq[q] = (uint8_t)(w[q >> 2] >> (8 * (q & 3)));
-                    }
-                }
-            }
-            if (active && b < nblk) {
-                const u4v a0 = ws[0], a1 = ws[1], a2 = ws[2], a3 = ws[3];
-                uint32_t m[16] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w, a2.x, a2.y, a2.z, a2.w, a3.x, a3.y, a3.z, a3.w};
-                const uint32_t rem = leaf_len - b * 64;
-                const uint32_t bl = leaf_len == 0 ? 0 : (rem < 64 ? rem : 64);
-                const uint32_t flags = (b == 0 ? b3::CHUNK_START : 0u) |
-                                       (b == nblk - 1 ? (b3::CHUNK_END | (single ? b3::ROOT : 0u)) : 0u);
-                b3::compress(cv, m, k, 0, bl, flags);
-            }
-#pragma unroll
-            for (int j = 0; j < 4; j++) v[j] = vn[j];
-            part = part_next;
-        }
+        for (int i = 0; i < 8; i++) cv[i] = r.v[i];
     } else {
         // generic path: ragged / partial / empty leaves
         uint32_t maxblk = active ? nblk : 0;
