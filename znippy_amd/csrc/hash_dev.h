@@ -165,8 +165,8 @@ __device__ __noinline__ Cv8 hash_ragged_through_stage(const uint8_t *src, uint8_
     // Ragged leaves on the store path (the last leaf of a row that is not a whole number of KiB — nearly every row of a
     // real archive — or an empty row): the same two-way stage as the whole-leaf form below it in the other branch (lane l
     // moves piece l % 4 of leaves 16j + l / 4, 64 bytes per leaf per step, the next step's loads in flight), with every
-    // piece cut to what its leaf still has: whole pieces as 16-byte accesses, the one partial piece of a leaf byte by
-    // byte (nothing is read or written beyond a row's last byte), absent ones as zeros in the stage — the padding the
+    // piece cut to what its leaf still has: whole pieces as 16-byte accesses, the one partial piece of a leaf as the 16
+    // bytes that end with the leaf (nothing is read or written beyond a row's last byte), absent ones as zeros in the stage — the padding the
     // hash wants.  A lane hashes as many blocks as its leaf has.  (Until this form every tile with one ragged leaf took
     // the generic loop below: each lane its own 64-byte loads and stores 1 KiB apart, half the speed.)
     const uint64_t has = __ballot(active && dst != nullptr), act = __ballot(active);
@@ -203,12 +203,20 @@ __device__ __noinline__ Cv8 hash_ragged_through_stage(const uint8_t *src, uint8_
         const int32_t rem = lrem[j] - 64 * (int32_t)b;
         if (actj[j] && rem >= 16) v = ld16(sj[j] + b * 64);
         else if (partial && actj[j] && rem > 0) {
-            const glb_u8 *const gq = (const glb_u8 *)(uintptr_t)(sj[j] + b * 64);
-            uint32_t w[4] = {0, 0, 0, 0};
+            // the leaf's last 1 .. 15 bytes: the 16 bytes that END with them (inside the row: the caller sends no row shorter
+            // than 16 bytes here), shifted down — nothing is read beyond the row's last byte
+            const uint4 o = ld16(sj[j] + b * 64 + rem - 16);
+            const uint32_t sh = 16u - (uint32_t)rem, ds = sh >> 2, bs = 8u * (sh & 3u);
+            const uint32_t x[4] = {o.x, o.y, o.z, o.w};
+            uint32_t t[5];
 #pragma unroll
-            for (int q = 0; q < 15; q++)
-                if (q < rem) w[q >> 2] |= (uint32_t)gq[q] << (8 * (q & 3));
-            v = make_uint4(w[0], w[1], w[2], w[3]);
+            for (int i = 0; i < 5; i++) {
+                const uint32_t a0 = i < 4 ? x[i < 4 ? i : 0] : 0u, a1 = i + 1 < 4 ? x[i + 1 < 4 ? i + 1 : 0] : 0u,
+                               a2 = i + 2 < 4 ? x[i + 2 < 4 ? i + 2 : 0] : 0u, a3 = i + 3 < 4 ? x[i + 3 < 4 ? i + 3 : 0] : 0u;
+                t[i] = ds == 0 ? a0 : (ds == 1 ? a1 : (ds == 2 ? a2 : a3));
+            }
+            v = make_uint4(__builtin_amdgcn_alignbit(t[1], t[0], bs), __builtin_amdgcn_alignbit(t[2], t[1], bs),
+                           __builtin_amdgcn_alignbit(t[3], t[2], bs), __builtin_amdgcn_alignbit(t[4], t[3], bs));
         }
         return v;
     };
@@ -245,17 +253,13 @@ __device__ __noinline__ Cv8 hash_ragged_through_stage(const uint8_t *src, uint8_
             const int32_t rem = lrem[j] - 64 * (int32_t)b;
             if (onj[j] && rem >= 16) st16(pj[j] + b * 64, v[j]);
         }
-        if (part) {  // (wave-uniform) the step's partial pieces, byte by byte
+        if (part) {  // (wave-uniform) the step's partial pieces: the 16 bytes that end with the leaf, to the 16 that end with it in
+            // the output — the bytes in front of the piece are rewritten with what their own lane wrote (in this instruction
+            // or an earlier step: the same row, the same wave, the same values)
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 const int32_t rem = lrem[j] - 64 * (int32_t)b;
-                if (onj[j] && rem > 0 && rem < 16) {
-                    glb_u8 *const gq = (glb_u8 *)(uintptr_t)(pj[j] + b * 64);
-                    const uint32_t w[4] = {v[j].x, v[j].y, v[j].z, v[j].w};
-#pragma unroll
-                    for (int q = 0; q < 15; q++)
-                        if (q < rem) gq[q] = (uint8_t)(w[q >> 2] >> (8 * (q & 3)));
-                }
+                if (onj[j] && rem > 0 && rem < 16) st16(pj[j] + b * 64 + rem - 16, ld16(sj[j] + b * 64 + rem - 16));
             }
         }
         if (active && b < nblk) {
@@ -711,7 +715,7 @@ __device__ __forceinline__ void hash_tile_leaves(const HashArgs &a, const Tile &
         };
         if (LDSRC && __ballot(active && !Y) == 0ull) run(std::true_type{});
         else run(std::false_type{});
-    } else if (COPY && !LDSRC && stage && ZN_STAGE_LOADS && ZN_RAGGED_STAGE) {
+    } else if (COPY && !LDSRC && stage && ZN_STAGE_LOADS && ZN_RAGGED_STAGE && __ballot(active && ulen != 0 && ulen < 16) == 0ull) {
         const Cv8 r = hash_ragged_through_stage(src, dst, leaf_len, nblk, k, single, active, stage);
 #pragma unroll
         for (int i = 0; i < 8; i++) cv[i] = r.v[i];
